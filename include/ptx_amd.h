@@ -1,0 +1,177 @@
+/*
+ * ptx_amd.h -- C ABI of libptx_amd.so, the MI355X (gfx950) forward-pass engine for the
+ * pretorched-x video model-zoo hot path.
+ *
+ * The reference (alexandonian/pretorched-x) is pure Python on top of torch.nn: it has no FFI of
+ * its own, so there is no reference-side binding to mirror symbol-for-symbol (SURVEY.md F1,
+ * section 8b last row).  Each entry point below replaces the ATen op(s) the reference invokes at
+ * the cited call site; INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, POD descriptors, a hipStream_t passed as void*.
+ *   - every function returns an int status (PTX_OK == 0); nothing throws across the ABI;
+ *     ptx_last_error() returns a thread-local message for the last non-zero status.
+ *   - all kernels are asynchronous on the given stream; the library never synchronises, never
+ *     allocates device memory, and keeps no per-call state (workspace is passed in), so calls
+ *     from different host threads on different streams are safe and everything is capturable
+ *     into a hipGraph.
+ *   - activations are fp32, channels-last:  NDHWC  [N][T][H][W][ld]  with ld >= C, ld % 4 == 0
+ *     and channels [C, ld) kept zero.  2-D tensors are the T == 1 case.
+ *   - arithmetic: fp32 operands, fp32 accumulate on v_mfma_f32_32x32x2_f32 /
+ *     v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain).
+ */
+#ifndef PTX_AMD_H
+#define PTX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_OK 0
+#define PTX_ERR_INVALID 1      /* bad descriptor / null pointer / misaligned */
+#define PTX_ERR_UNSUPPORTED 2  /* shape not supported by the requested tile configuration */
+#define PTX_ERR_HIP 3          /* a HIP runtime call failed (message has hipGetErrorString) */
+#define PTX_ERR_WORKSPACE 4    /* workspace too small */
+
+typedef void* ptx_stream_t; /* hipStream_t */
+
+/* epilogue / prologue flags of ptx_conv3d_fwd */
+#define PTX_EPI_RELU 1u      /* ReLU on the output            (resnet3D.py:131,135,142)          */
+#define PTX_EPI_RES_ADD 2u   /* + residual, same shape as y   (resnet3D.py:141 `out += residual`) */
+#define PTX_EPI_RES_PADA 4u  /* + shortcut-A residual: strided subsample of `res`, zero channels
+                                above res_C              (resnet3D.py:65-74, nonlocalnet.py:322) */
+#define PTX_PRO_RELU 8u      /* ReLU on the input operand while loading (trn.py:39-45)           */
+#define PTX_EPI_ACCUM 16u    /* ptx_linear_fwd only: y += result (trn.py:110 stack(...).sum(0))   */
+
+const char* ptx_version(void);
+const char* ptx_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on fp32 MFMA) with fused bias(+folded BN) + residual + ReLU.
+ * Replaces: conv3d -> batch_norm(eval) [-> relu] [-> add_ -> relu] as issued by
+ *   resnet3D.py:125-143 (Bottleneck), :93-106 (BasicBlock), :153-155 (stem), :176-185 (shortcut B),
+ *   r2plus1d.py:85-88 (factored convs), nonlocalnet.py:86-111 (g/theta/phi/W pointwise convs),
+ *   and any torch.matmul-shaped contraction expressed as a 1x1x1 conv (trn.py:39-45).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_conv3d_desc {
+    int32_t N, Ti, Hi, Wi;   /* input positions                                   */
+    int32_t Ci, ldx;         /* input channels, input channel stride (floats)     */
+    int32_t To, Ho, Wo;      /* output positions                                  */
+    int32_t Co, ldy;         /* output channels, output channel stride            */
+    int32_t kT, kH, kW;      /* filter taps                                       */
+    int32_t sT, sH, sW;      /* strides                                           */
+    int32_t pT, pH, pW;      /* zero padding                                      */
+    int32_t Kc;              /* packed-weight K extent per tap  (>= Ci, multiple of the pack granule) */
+    int32_t Co_pad;          /* packed-weight row count per tap (>= Co, multiple of 128)              */
+    uint32_t flags;          /* PTX_EPI_* | PTX_PRO_*                             */
+    /* residual operand (PTX_EPI_RES_ADD: ldr only; PTX_EPI_RES_PADA: all fields) */
+    int32_t ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
+} ptx_conv3d_desc;
+
+/* number of compiled tile configurations, and a printable name "BMxBNxBK/WMxWN/mfmaMT" */
+int ptx_conv3d_num_configs(void);
+const char* ptx_conv3d_config_name(int config);
+/* 1 if `config` can run `desc` (tile K-step divides Kc, etc.), else 0 */
+int ptx_conv3d_config_supported(const ptx_conv3d_desc* desc, int config);
+/* heuristic default configuration for a problem (never fails for a valid descriptor) */
+int ptx_conv3d_pick_config(const ptx_conv3d_desc* desc, int* split_k);
+/* bytes of fp32 partial-sum workspace needed when split_k > 1 (0 otherwise) */
+size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* desc, int split_k);
+/*
+ * y[m][co] = epilogue( sum_{tap,c} x[pos(m,tap)][c] * w_packed[tap][co][c] + bias[co] )
+ * x: NDHWC input; w_packed/bias: from ptx_pack_conv_weight; res: residual operand or NULL;
+ * y: NDHWC output (channels [Co, ldy) are written as zero); config < 0 -> ptx_conv3d_pick_config.
+ */
+int ptx_conv3d_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_packed,
+                   const float* bias, const float* res, float* y, void* workspace,
+                   size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Weight packing: fold eval-mode BatchNorm (+ conv bias) into the filter and re-lay it out
+ * K-major for the MFMA B operand.  One-off at load time.
+ * Replaces: the per-forward batch_norm after every conv (resnet3D.py:127,131,135; 154; 184).
+ *   scale[co] = gamma[co] / sqrt(var[co] + eps)         (1 when gamma == NULL)
+ *   w_packed[tap][co][k] = w[co][c][kt][kh][kw] * scale[co]
+ *   bias_out[co]         = beta[co] + (conv_bias[co] - mean[co]) * scale[co]
+ * fold_kw == 0: tap = (kt*kH + kh)*kW + kw, k = c            -> [kT*kH*kW][Co_pad][Kc]
+ * fold_kw == 1: tap = kt*kH + kh,          k = kw*Ci + c     -> [kT*kH   ][Co_pad][Kc]
+ *               (small-Cin stem: the kW taps are folded into the channel axis, see
+ *                ptx_fold_kw_ncdhw)
+ * Rows co >= Co and columns k >= K are written as zero.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_pack_desc {
+    int32_t Co, Ci, kT, kH, kW;
+    int32_t Kc, Co_pad;
+    int32_t fold_kw;
+} ptx_pack_desc;
+
+size_t ptx_packed_weight_elems(const ptx_pack_desc* desc);
+int ptx_pack_conv_weight(const ptx_pack_desc* desc, const float* w /* [Co][Ci][kT][kH][kW] */,
+                         const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, float bn_eps,
+                         float* w_packed, float* bias_out /* [Co_pad] */, ptx_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Layout transforms at the API edge (the reference's tensors are NCDHW, torchvision_models.py:448).
+ * ------------------------------------------------------------------------------------------ */
+/* x [N][C][S] -> y [N][S][ld]  (S = T*H*W; channels [C, ld) zero-filled) */
+int ptx_ncdhw_to_ndhwc(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                       ptx_stream_t stream);
+/* x [N][S][ld] -> y [N][C][S] */
+int ptx_ndhwc_to_ncdhw(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                       ptx_stream_t stream);
+/*
+ * Small-Cin stem input: x NCDHW [N][C][T][H][W]  ->  y [N][T][H][Wo][ld] with
+ *   y[n][t][h][wo][kw*C + c] = x[n][c][t][h][wo*sW - pW + kw]   (0 outside the image / k >= kW*C)
+ * so that the stem (resnet3D.py:153, Conv3d 3->64 k7 s(1,2,2) p3) becomes a (kT,kH,1) conv over
+ * ld = 24 "channels" with 96-byte contiguous rows.
+ */
+int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H,
+                      int32_t W, int32_t kW, int32_t sW, int32_t pW, int32_t Wo, int32_t ld,
+                      ptx_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Pooling and head.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_pool3d_desc {
+    int32_t N, Ti, Hi, Wi, C, ld; /* input NDHWC, ld shared by input and output */
+    int32_t To, Ho, Wo;
+    int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW;
+} ptx_pool3d_desc;
+/* max_pool3d with -inf padding (resnet3D.py:156: MaxPool3d k3 s2 p1) */
+int ptx_maxpool3d_fwd(const ptx_pool3d_desc* desc, const float* x, float* y, ptx_stream_t stream);
+/* adaptive_avg_pool3d(1): x [N][S][ld] (channels-last) or [N][C][S] (channels_first != 0)
+ * -> y [N][C]   (torchvision_models.py:461) */
+int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                       int32_t channels_first, ptx_stream_t stream);
+/* y[m][j] = act_out( sum_k act_in(x[m][k]) * w[j][k] + b[j] ), small M (GEMV-class, weight-
+ * bandwidth bound): last_linear (torchvision_models.py:463) and the TRN relation MLP at small
+ * batch (trn.py:39-45).  flags: PTX_PRO_RELU | PTX_EPI_RELU | PTX_EPI_ACCUM.  b may be NULL. */
+int ptx_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K,
+                   int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Non-local block pieces (nonlocalnet.py:143-166).
+ * ------------------------------------------------------------------------------------------ */
+/* Batched C[b] = op(A[b] x B[b]^T): A [batch][M][lda] (row-major, K contiguous),
+ * B [batch][Nn][ldb] (row-major, K contiguous), C [batch][M][ldc]; fp32 MFMA.
+ * Used for f = theta^T phi  (nonlocalnet.py:156) and y = softmax(f) g  (:160). */
+int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t batch, int32_t M, int32_t Nn,
+                 int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int64_t strideA, int64_t strideB,
+                 int64_t strideC, ptx_stream_t stream);
+/* in-place row softmax over the last dim: x [rows][ld], `cols` valid entries (nonlocalnet.py:157);
+ * scale_only != 0 -> x /= cols instead (dot_product mode, :204-205) */
+int ptx_softmax_rows(float* x, int64_t rows, int32_t cols, int32_t ld, int32_t scale_only,
+                     ptx_stream_t stream);
+/* y [N][S][ld] (channels-last) -> yt [N][ld_c][S_pad]: per-sample transpose used to present g as
+ * the K-contiguous B operand of y = f g */
+int ptx_transpose_last2(const float* x, float* y, int32_t batch, int32_t R, int32_t Cc, int32_t ldx,
+                        int32_t ldy, ptx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_AMD_H */

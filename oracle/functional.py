@@ -1,0 +1,257 @@
+"""TEST INFRASTRUCTURE ONLY -- functional CPU restatement of the reference forward pass.
+
+Everything here is a pure function of (state_dict, input): weights are looked up by the
+reference's own `state_dict` key names (the weight ABI), and the ATen ops
+are issued in the order the reference's nn.Modules issue them, so on the same machine the results
+are bit-identical to the imported reference (asserted by tests/test_oracle_vs_reference.py).
+
+Reference lines followed:
+  * stem / stages / head ............ pretorched/models/resnet3D.py:146-218,
+                                      pretorched/models/torchvision_models.py:443-469
+  * BasicBlock / Bottleneck ......... resnet3D.py:77-143
+  * shortcut A ...................... resnet3D.py:65-74, nonlocalnet.py:322-332
+  * shortcut B ...................... resnet3D.py:175-185
+  * (2+1)D factored conv ............ r2plus1d.py:29-88 (mid-channel formula :68-69)
+  * non-local block (4 modes) ....... nonlocalnet.py:51-243
+  * NL-ResNet3D placement rule ...... nonlocalnet.py:456-485
+  * TRN relation MLP ................ trn.py:20-56, multi-scale :59-113
+  * 2-D ResNet (torchvision shape) .. torchvision_models.py:443-492 + oracle/tv_standin.py
+"""
+import itertools
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm{2,3}d default, never overridden by the reference
+
+
+@dataclass
+class ArchCfg:
+    """Static description of one ResNet-style network of the reference zoo."""
+    block: str                      # 'basic' | 'bottleneck'
+    layers: Sequence[int]
+    shortcut: str = "B"            # 'A' zero-pad (resnet3D.py:65) | 'B' conv+bn (resnet3D.py:175)
+    conv: str = "3d"               # '3d' plain nn.Conv3d | '2p1d' SpatioTemporalConv everywhere
+    nonlocal_layers: Optional[Sequence[int]] = None   # NonLocalResNet3D only
+    nl_mode: str = "embedded_gaussian"
+    head: str = "last_linear"      # 'fc' for R2Plus1D (never passes through modify_resnets)
+    dims: int = 3                  # 2 for the torchvision-shaped resnet18 plumbing case
+    expansion: int = field(init=False)
+
+    def __post_init__(self):
+        self.expansion = 4 if self.block == "bottleneck" else 1
+
+
+ARCHS = {
+    "resnet3d10": ArchCfg("basic", [1, 1, 1, 1], "B"),
+    "resnet3d18": ArchCfg("basic", [2, 2, 2, 2], "A"),
+    "resnet3d34": ArchCfg("basic", [3, 4, 6, 3], "A"),
+    "resnet3d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B"),
+    "resneti3d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B"),
+    "resnet3d101": ArchCfg("bottleneck", [3, 4, 23, 3], "B"),
+    "resnet3d152": ArchCfg("bottleneck", [3, 8, 36, 3], "B"),
+    "resnet3d200": ArchCfg("bottleneck", [3, 24, 36, 3], "B"),
+    "nonlocalresnet3d50": ArchCfg("bottleneck", [3, 4, 6, 3], "A", nonlocal_layers=[0, 2, 3, 0]),
+    "r2plus1d10": ArchCfg("basic", [1, 1, 1, 1], "B", conv="2p1d", head="fc"),
+    "r2plus1d18": ArchCfg("basic", [2, 2, 2, 2], "B", conv="2p1d", head="fc"),
+    "r2plus1d34": ArchCfg("basic", [3, 4, 6, 3], "B", conv="2p1d", head="fc"),
+    "r2plus1d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", conv="2p1d", head="fc"),
+    # config-3 composite: (2+1)D bottlenecks + NL blocks, shortcut B
+    "nonlocal_r2plus1d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", conv="2p1d",
+                                   nonlocal_layers=[0, 2, 3, 0]),
+    "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
+}
+
+
+def _t3(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+# --------------------------------------------------------------------------------------------
+# primitive pieces
+# --------------------------------------------------------------------------------------------
+def _bn(sd, x, p):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.1, BN_EPS)
+
+
+def _conv(sd, x, p, stride, padding, dims=3):
+    w = sd[p + ".weight"]
+    b = sd.get(p + ".bias")
+    if dims == 2:
+        return F.conv2d(x, w, b, stride, padding)
+    return F.conv3d(x, w, b, _t3(stride), _t3(padding))
+
+
+def st_mid_channels(cin, cout, k):
+    """r2plus1d.py:68-69."""
+    kt, kh, kw = _t3(k)
+    return int(math.floor((kt * kh * kw * cin * cout) / (kh * kw * cin + kt * cout)))
+
+
+def _st_conv(sd, x, p, stride, padding):
+    """SpatioTemporalConv.forward, r2plus1d.py:85-88."""
+    st, sh, sw = _t3(stride)
+    pt, ph, pw = _t3(padding)
+    x = _conv(sd, x, p + ".spatial_conv", (1, sh, sw), (0, ph, pw))
+    x = F.relu(_bn(sd, x, p + ".bn"))
+    return _conv(sd, x, p + ".temporal_conv", (st, 1, 1), (pt, 0, 0))
+
+
+def _any_conv(cfg, sd, x, p, stride, padding):
+    if cfg.conv == "2p1d":
+        return _st_conv(sd, x, p, stride, padding)
+    return _conv(sd, x, p, stride, padding, cfg.dims)
+
+
+def shortcut_a(x, planes, stride):
+    """downsample_basic_block: strided subsample (avg_pool k=1) + zero channels."""
+    out = F.avg_pool3d(x, kernel_size=1, stride=stride)
+    pad = torch.zeros(out.size(0), planes - out.size(1), *out.shape[2:], dtype=out.dtype)
+    return torch.cat([out, pad], dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# non-local block
+# --------------------------------------------------------------------------------------------
+def nonlocal_block(sd, x, p, mode="embedded_gaussian", sub_sample=False, bn_layer=True):
+    """_NonLocalBlockND for dimension=3 (nonlocalnet.py:139-243)."""
+    b, c = x.shape[:2]
+    gk = p + ".g.0" if sub_sample else p + ".g"
+    ci = sd[gk + ".weight"].shape[0]
+
+    def pw(key, inp):
+        return F.conv3d(inp, sd[key + ".weight"], sd.get(key + ".bias"))
+
+    def pool(t):
+        return F.max_pool3d(t, 2) if sub_sample else t
+
+    g_x = pool(pw(gk, x)).reshape(b, ci, -1).permute(0, 2, 1)
+    if mode == "gaussian":
+        theta_x = x.reshape(b, c, -1).permute(0, 2, 1)
+        phi_x = pool(x).reshape(b, c, -1)
+        f = F.softmax(torch.matmul(theta_x, phi_x), dim=-1)
+    else:
+        pk = p + ".phi.0" if sub_sample else p + ".phi"
+        theta = pw(p + ".theta", x)
+        phi = pool(pw(pk, x))
+        if mode == "concatenation":
+            th = theta.reshape(b, ci, -1, 1)
+            ph = phi.reshape(b, ci, 1, -1)
+            h, w = th.size(2), ph.size(3)
+            cat = torch.cat([th.repeat(1, 1, 1, w), ph.repeat(1, 1, h, 1)], dim=1)
+            f = F.relu(F.conv2d(cat, sd[p + ".concat_project.0.weight"]))
+            f = f.reshape(b, h, w)
+            f = f / f.size(-1)
+        else:
+            f = torch.matmul(theta.reshape(b, ci, -1).permute(0, 2, 1), phi.reshape(b, ci, -1))
+            f = F.softmax(f, dim=-1) if mode == "embedded_gaussian" else f / f.size(-1)
+    y = torch.matmul(f, g_x).permute(0, 2, 1).contiguous().reshape(b, ci, *x.shape[2:])
+    if bn_layer:
+        w_y = _bn(sd, pw(p + ".W.0", y), p + ".W.1")
+    else:
+        w_y = pw(p + ".W", y)
+    return w_y + x
+
+
+# --------------------------------------------------------------------------------------------
+# residual stages
+# --------------------------------------------------------------------------------------------
+def _block(cfg, sd, x, p, planes, stride, has_down, nl):
+    residual = x
+    if cfg.block == "bottleneck":
+        out = F.relu(_bn(sd, _any_conv(cfg, sd, x, p + ".conv1", 1, 0), p + ".bn1"))
+        out = F.relu(_bn(sd, _any_conv(cfg, sd, out, p + ".conv2", stride, 1), p + ".bn2"))
+        out = _bn(sd, _any_conv(cfg, sd, out, p + ".conv3", 1, 0), p + ".bn3")
+    else:
+        out = F.relu(_bn(sd, _any_conv(cfg, sd, x, p + ".conv1", stride, 1), p + ".bn1"))
+        out = _bn(sd, _any_conv(cfg, sd, out, p + ".conv2", 1, 1), p + ".bn2")
+    if has_down:
+        if cfg.shortcut == "A":
+            residual = shortcut_a(x, planes * cfg.expansion, stride)
+        else:
+            residual = _bn(sd, _any_conv(cfg, sd, x, p + ".downsample.0", stride, 0),
+                           p + ".downsample.1")
+    out = F.relu(out + residual)
+    if nl:
+        out = nonlocal_block(sd, out, p + ".nonlocalblock", cfg.nl_mode)
+    return out
+
+
+def nl_flags(blocks, nonlocal_blocks):
+    """Which blocks of a stage carry an NL block (nonlocalnet.py:474-479)."""
+    freq = blocks // nonlocal_blocks if nonlocal_blocks != 0 else -1
+    return [(i % freq == 0 and freq > 0) for i in range(blocks)]
+
+
+def features(cfg: ArchCfg, sd, x):
+    """`model.features(x)`: stem + maxpool + layer1..4 (torchvision_models.py:448-458)."""
+    if cfg.dims == 2:
+        x = F.relu(_bn(sd, _conv(sd, x, "conv1", 2, 3, 2), "bn1"))
+        x = F.max_pool2d(x, 3, 2, 1)
+    else:
+        x = F.relu(_bn(sd, _any_conv(cfg, sd, x, "conv1", (1, 2, 2), (3, 3, 3)), "bn1"))
+        x = F.max_pool3d(x, 3, 2, 1)
+    inplanes = 64
+    for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), cfg.layers)):
+        stride = 1 if li == 0 else 2
+        flags = nl_flags(nblocks, cfg.nonlocal_layers[li]) if cfg.nonlocal_layers else [False] * nblocks
+        for bi in range(nblocks):
+            first = bi == 0
+            has_down = first and (stride != 1 or inplanes != planes * cfg.expansion)
+            x = _block(cfg, sd, x, "layer%d.%d" % (li + 1, bi), planes,
+                       stride if first else 1, has_down, flags[bi])
+            if first:
+                inplanes = planes * cfg.expansion
+    return x
+
+
+def logits(cfg: ArchCfg, sd, feat):
+    """`model.logits(features)`: global average pool + flatten + linear (:460-464)."""
+    x = F.adaptive_avg_pool2d(feat, 1) if cfg.dims == 2 else F.adaptive_avg_pool3d(feat, 1)
+    x = x.view(x.size(0), -1)
+    return F.linear(x, sd[cfg.head + ".weight"], sd[cfg.head + ".bias"])
+
+
+def forward(cfg: ArchCfg, sd, x):
+    with torch.no_grad():
+        return logits(cfg, sd, features(cfg, sd, x))
+
+
+# --------------------------------------------------------------------------------------------
+# TRN relation heads
+# --------------------------------------------------------------------------------------------
+def relation(sd, x, p, num_inputs):
+    """trn.Relation.forward: ReLU -> Linear -> ReLU -> Linear on concatenated frames (trn.py:39-56)."""
+    out_features = sd[p + "relate.3.weight"].shape[0]
+    h = x.contiguous().view(-1, num_inputs * x.size(-1))
+    h = F.linear(F.relu(h), sd[p + "relate.1.weight"], sd[p + "relate.1.bias"])
+    h = F.linear(F.relu(h), sd[p + "relate.3.weight"], sd[p + "relate.3.bias"])
+    return h.view(x.size(0), -1, out_features)
+
+
+def multiscale_relation(sd, x, num_input, num_relations=3, rng=np.random):
+    """trn.MultiScaleRelation.forward (trn.py:101-110): consumes the numpy RNG exactly as the
+    reference does (one `choice` per scale, in scale order)."""
+    scales = list(range(num_input, 1, -1))
+    outs = []
+    for si, scale in enumerate(scales):
+        combos = list(itertools.combinations(range(num_input), scale))
+        take = min(num_relations, len(combos))
+        for idx in rng.choice(len(combos), take, replace=False):
+            sub = x[..., combos[idx], :]
+            outs.append(relation(sd, sub, "relations.%d." % si, scale))
+    out_features = outs[0].shape[-1]
+    return torch.stack(outs).sum(0).view(x.size(0), -1, out_features)
+
+
+# --------------------------------------------------------------------------------------------
+# nominal work (GMAC) -- the figure roofline numbers are quoted against, SURVEY.md section 8d
+# --------------------------------------------------------------------------------------------
+def conv_macs(out_numel, cin, k):
+    kt, kh, kw = _t3(k)
+    return out_numel * cin * kt * kh * kw

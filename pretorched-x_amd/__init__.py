@@ -1,0 +1,212 @@
+"""pretorched-x_amd -- MI355X-native forward-pass engine behind pretorched-x's model API.
+
+Drop-in surface (reference README.md:11-15, 137-143; pretorched/__init__.py:56-83):
+
+    import pretorched_x_amd as pretorched            # see pretorched_x_amd.py at the repo root
+    model = pretorched.__dict__['resnet3d50'](num_classes=339, pretrained=None).cuda().eval()
+    feats = model.features(clips)      # [B, 2048, T/16, H/32, W/32]
+    out   = model.logits(feats)        # [B, 339]
+    out   = model(clips)               # == logits(features(clips))
+
+Only the video hot path of BASELINE.json is implemented: the 3-D ResNet family, (2+1)D ResNets,
+the non-local ResNet, the TRN relation heads and the 2-D resnet18 plumbing case.  Every FLOP of
+`features/logits/forward` runs in libptx_amd.so (hand-written gfx950 HIP); there is no fallback.
+"""
+import dataclasses
+from collections import defaultdict
+
+import torch
+
+from . import _lib
+from ._lib import PtxError
+from .engine import Engine, relation_mlp
+from .zoo import ARCHS, Arch, MultiScaleRelation, Relation, VideoResNet, factored_mid_channels
+
+__version__ = "0.1.0"
+
+# ---------------------------------------------------------------------------------------------
+# pretrained_settings: same keys/values the reference publishes (resnet3D.py:18-55,
+# nonlocalnet.py:11-47, torchvision_models.py:40-112).  URLs need network access, which this
+# image does not have; with a populated $TORCH_HOME cache they load exactly as in the reference.
+# ---------------------------------------------------------------------------------------------
+_IMAGENET_MEAN, _IMAGENET_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+_HOST = "http://pretorched-x.csail.mit.edu/models/"
+_URLS = {
+    "kinetics-400": {
+        "resnet3d18": _HOST + "resnet3d18_kinetics-e9f44270.pth",
+        "resnet3d34": _HOST + "resnet3d34_kinetics-7fed38dd.pth",
+        "resnet3d50": _HOST + "resnet3d50_kinetics-aad059c9.pth",
+        "resnet3d101": _HOST + "resnet3d101_kinetics-8d4c9d63.pth",
+        "resnet3d152": _HOST + "resnet3d152_kinetics-575c47e2.pth",
+        "nonlocalresnet3d50": _HOST + "resnet3d50_kinetics-aad059c9.pth",
+    },
+    "moments": {
+        "resnet3d50": _HOST + "resnet3d50_16seg_moments-6eb53860.pth",
+        "resnet50": "http://moments.csail.mit.edu/moments_models/resnet50_moments-fd0c4436.pth",
+    },
+    "imagenet": {"resnet18": "https://download.pytorch.org/models/resnet18-5c106cde.pth"},
+    "places365": {"resnet18": _HOST + "resnet18_places365-dbad67aa.pth"},
+}
+_NUM_CLASSES = {"kinetics-400": 400, "moments": 339, "imagenet": 1000, "places365": 365}
+
+pretrained_settings = defaultdict(dict)
+for _name in ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
+              "resnet3d200", "nonlocalresnet3d50"]:
+    for _ds in ("kinetics-400", "moments"):
+        pretrained_settings[_name][_ds] = {
+            "input_space": "RGB", "input_range": [0, 1], "url": _URLS[_ds].get(_name),
+            "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": _NUM_CLASSES[_ds],
+            "input_size": [3, 224, 224]}
+for _ds in ("imagenet", "places365"):
+    pretrained_settings["resnet18"][_ds] = {
+        "input_space": "RGB", "input_range": [0, 1], "url": _URLS[_ds]["resnet18"],
+        "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": _NUM_CLASSES[_ds],
+        "input_size": [3, 224, 224]}
+pretrained_settings["resnet50"]["moments"] = {
+    "input_space": "RGB", "input_range": [0, 1], "url": _URLS["moments"]["resnet50"],
+    "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": 339, "input_size": [3, 224, 224]}
+
+
+def _fetch(url):
+    if url is None:
+        raise PtxError("no pretrained weights are published for this model/dataset pair")
+    return torch.hub.load_state_dict_from_url(url, map_location="cpu")
+
+
+def _apply_settings(model, settings):
+    for k in ("input_space", "input_size", "input_range", "mean", "std"):
+        setattr(model, k, settings[k])
+
+
+def _rename_head(sd, model):
+    """Checkpoints carry `fc.*`; live models call the classifier `last_linear` (torchvision_models.py:445)."""
+    if model.arch.head == "last_linear":
+        sd = {("last_linear." + k[3:] if k.startswith("fc.") else k): v for k, v in sd.items()}
+    return sd
+
+
+def load_pretrained(model, num_classes, settings):
+    """reference torchvision_models.py:158-167"""
+    assert num_classes == settings["num_classes"], \
+        "num_classes should be {}, but is {}".format(settings["num_classes"], num_classes)
+    model.load_state_dict(_rename_head(_fetch(settings["url"]), model))
+    _apply_settings(model, settings)
+    return model
+
+
+def inflate_pretrained(model, num_classes, settings):
+    """reference torchvision_models.py:170-191: 2-D filters repeated along T (no 1/T scaling)."""
+    assert num_classes == settings["num_classes"], \
+        "num_classes should be {}, but is {}".format(settings["num_classes"], num_classes)
+    target = model.state_dict()
+    sd = _rename_head(_fetch(settings["url"]), model)
+    for k, v in list(sd.items()):
+        if k in target and v.shape != target[k].shape:
+            sd[k] = v.unsqueeze(2).expand_as(target[k]).contiguous()
+    model.load_state_dict(sd)
+    _apply_settings(model, settings)
+    return model
+
+
+def _build(arch_name, num_classes, shortcut_type=None):
+    if shortcut_type is not None and shortcut_type != ARCHS[arch_name].shortcut:
+        key = "%s@%s" % (arch_name, shortcut_type)
+        if key not in ARCHS:
+            ARCHS[key] = dataclasses.replace(ARCHS[arch_name], shortcut=shortcut_type)
+        arch_name = key
+    return VideoResNet(arch_name, num_classes)
+
+
+def _resnet3d_factory(name, default_shortcut, default_classes=400, default_pretrained="kinetics-400"):
+    def factory(num_classes=default_classes, pretrained=default_pretrained, shortcut_type=default_shortcut, **kwargs):
+        if kwargs:
+            raise TypeError("%s() got unexpected keyword arguments %s" % (name, sorted(kwargs)))
+        model = _build(name, num_classes, shortcut_type)
+        if pretrained is not None:
+            load_pretrained(model, num_classes, pretrained_settings[name][pretrained])
+        return model
+    factory.__name__ = name
+    factory.__doc__ = "Constructs a %s model (reference pretorched/models/resnet3D.py)." % name
+    return factory
+
+
+def resnet3d10(num_classes=339, shortcut_type="B"):
+    """reference resnet3D.py:242-246 (no pretrained weights exist)."""
+    return _build("resnet3d10", num_classes, shortcut_type)
+
+
+resnet3d18 = _resnet3d_factory("resnet3d18", "A")
+resnet3d34 = _resnet3d_factory("resnet3d34", "A")
+resnet3d50 = _resnet3d_factory("resnet3d50", "B")
+resnet3d101 = _resnet3d_factory("resnet3d101", "B")
+resnet3d152 = _resnet3d_factory("resnet3d152", "B")
+
+
+def resnet3d200(num_classes=400, pretrained="kinetics-400", **kwargs):
+    """reference resnet3D.py:301-308: `num_classes` is not forwarded to the constructor there
+    (the network is built with the class default, 339) -- mirrored."""
+    model = _build("resnet3d200", kwargs.pop("num_classes_override", 339), kwargs.pop("shortcut_type", "B"))
+    if pretrained is not None:
+        load_pretrained(model, num_classes, pretrained_settings["resnet3d200"][pretrained])
+    return model
+
+
+def resneti3d50(num_classes=400, pretrained="moments", shortcut_type="B"):
+    """ResNet3D-50 initialised by inflating the 2-D Moments ResNet-50 (resnet3D.py:311-318)."""
+    model = _build("resneti3d50", num_classes, shortcut_type)
+    if pretrained is not None:
+        inflate_pretrained(model, num_classes, pretrained_settings["resnet50"][pretrained])
+    return model
+
+
+def nonlocalresnet3d50(num_classes=339, num_nonlocal_blocks=5, pretrained="kinetics-400", shortcut_type="A"):
+    """reference nonlocalnet.py:553-570.  As there: `num_classes` is accepted but NOT forwarded
+    (always 339 logits); shortcut type 'A'; the checkpoint is loaded non-strictly."""
+    if num_nonlocal_blocks == 5:
+        nl = (0, 2, 3, 0)
+    elif num_nonlocal_blocks == 10:
+        nl = (0, 4, 6, 0)
+    else:
+        raise ValueError("num_nonlocal_blocks must be 5 or 10 (the reference fails with UnboundLocalError)")
+    key = "nonlocalresnet3d50/%d" % num_nonlocal_blocks
+    if key not in ARCHS:
+        ARCHS[key] = dataclasses.replace(ARCHS["nonlocalresnet3d50"], nonlocal_layers=nl)
+    model = _build(key, 339, shortcut_type)
+    if pretrained is not None:
+        settings = pretrained_settings["nonlocalresnet3d50"][pretrained]
+        model.load_state_dict(_fetch(settings["url"]), strict=False)
+        _apply_settings(model, settings)
+    return model
+
+
+def _r2plus1d_factory(name):
+    def factory(num_classes=339, shortcut_type="B"):
+        return _build(name, num_classes, shortcut_type)
+    factory.__name__ = name
+    factory.__doc__ = "Constructs a %s model (reference pretorched/models/r2plus1d.py:113-152)." % name
+    return factory
+
+
+r2plus1d10 = _r2plus1d_factory("r2plus1d10")
+r2plus1d18 = _r2plus1d_factory("r2plus1d18")
+r2plus1d34 = _r2plus1d_factory("r2plus1d34")
+r2plus1d50 = _r2plus1d_factory("r2plus1d50")
+
+
+def nonlocal_r2plus1d50(num_classes=339):
+    """BASELINE.json config 3 ("resnet2p1d50 + NLBlock"): no reference model combines (2+1)D convs
+    with NL blocks; this is the composition validated in SURVEY.md row A9 (shortcut 'B')."""
+    return _build("nonlocal_r2plus1d50", num_classes)
+
+
+def resnet18(num_classes=1000, pretrained="imagenet"):
+    """2-D ResNet-18 (reference torchvision_models.py:484-492), run as the T == 1 case."""
+    model = _build("resnet18", num_classes)
+    if pretrained is not None:
+        load_pretrained(model, num_classes, pretrained_settings["resnet18"][pretrained])
+    return model
+
+
+model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
+               "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
+               "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18"]

@@ -1,0 +1,109 @@
+"""ctypes binding of libptx_amd.so (the C ABI declared in include/ptx_amd.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol cannot be
+resolved this module raises, and every model in the package is unusable (SURVEY.md 8b:
+"the product path must fail loudly when the HIP extension is missing").
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptx_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ptx_amd.h")
+
+PTX_EPI_RELU = 1
+PTX_EPI_RES_ADD = 2
+PTX_EPI_RES_PADA = 4
+PTX_PRO_RELU = 8
+PTX_EPI_ACCUM = 16
+
+
+class PtxError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "Ti", "Hi", "Wi", "Ci", "ldx", "To", "Ho", "Wo", "Co", "ldy",
+                 "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "Kc", "Co_pad")] + \
+               [("flags", C.c_uint32)] + \
+               [(n, C.c_int32) for n in
+                ("ldr", "res_C", "res_T", "res_H", "res_W", "res_sT", "res_sH", "res_sW")]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class PackDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Co", "Ci", "kT", "kH", "kW", "Kc", "Co_pad", "fold_kw")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "Ti", "Hi", "Wi", "C", "ld", "To", "Ho", "Wo",
+                 "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW")]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_U = C.c_uint32
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/ptx_amd.h
+SIGNATURES = {
+    "ptx_version": (C.c_char_p, []),
+    "ptx_last_error": (C.c_char_p, []),
+    "ptx_conv3d_num_configs": (C.c_int, []),
+    "ptx_conv3d_config_name": (C.c_char_p, [C.c_int]),
+    "ptx_conv3d_config_supported": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "ptx_conv3d_pick_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+    "ptx_conv3d_workspace_bytes": (_Z, [C.POINTER(ConvDesc), C.c_int]),
+    "ptx_conv3d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
+    "ptx_packed_weight_elems": (_Z, [C.POINTER(PackDesc)]),
+    "ptx_pack_conv_weight": (C.c_int, [C.POINTER(PackDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "ptx_ncdhw_to_ndhwc": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
+    "ptx_ndhwc_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
+    "ptx_fold_kw_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ptx_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "ptx_global_avgpool": (C.c_int, [_P, _P, _I, _I, _L, _I, _I, _P]),
+    "ptx_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _U, _P]),
+    "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),
+    "ptx_softmax_rows": (C.c_int, [_P, _L, _I, _I, _I, _P]),
+    "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def header_symbols(path=HEADER_PATH):
+    """Every function name declared in include/ptx_amd.h (used by the no-GPU ABI test)."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptx_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library with typed entry points."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtxError(
+                "libptx_amd.so not found at %s -- build it with "
+                "`python pretorched-x_amd/csrc/build.py` (or __graft_entry__.build()); "
+                "this package has no CPU / eager fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().ptx_last_error().decode(errors="replace")
+        raise PtxError("%s failed (status %d): %s" % (what or "libptx_amd call", status, msg))

@@ -1,0 +1,65 @@
+"""Build libptx_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python pretorched-x_amd/csrc/build.py [--force] [--report]
+
+Objects and the shared library are written next to this file's parent package
+(`pretorched-x_amd/libptx_amd.so`), in-tree, so the built library travels with the repo
+snapshot to the GPU box.  `--report` adds -Rpass-analysis=kernel-resource-usage.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+SOURCES = ["conv_igemm.hip", "pack_layout.hip", "pool_head.hip"]
+HEADERS = ["ptx_common.h", os.path.join("..", "..", "include", "ptx_amd.h")]
+LIB = os.path.join(PKG, "libptx_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, report):
+    obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not _stale(obj, deps):
+        return obj, ""
+    cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
+          ["-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stdout))
+    return obj, r.stdout
+
+
+def build(force=False, report=False, verbose=True):
+    if force:
+        for s in SOURCES:
+            o = os.path.join(HERE, os.path.splitext(s)[0] + ".o")
+            if os.path.exists(o):
+                os.remove(o)
+    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        results = list(ex.map(lambda s: _compile(s, report), SOURCES))
+    objs = [o for o, _ in results]
+    log = "".join(l for _, l in results)
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stdout)
+    if verbose and log:
+        print(log)
+    return LIB
+
+
+if __name__ == "__main__":
+    lib = build(force="--force" in sys.argv, report="--report" in sys.argv)
+    print("built", lib, os.path.getsize(lib), "bytes")

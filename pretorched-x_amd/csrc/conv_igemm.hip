@@ -1,0 +1,549 @@
+// Implicit-GEMM 3-D convolution on the gfx950 fp32 matrix cores, with fused
+// bias(+folded BN) + residual + ReLU epilogue.  Channels-last activations (NDHWC), K-major
+// packed filters.  One kernel template serves every conv of the hot path:
+// the 7x7x7 stem (after the kW fold), 3x3x3 body, 1x1x1 pointwise / shortcut-B, the (1,k,k) and
+// (k,1,1) factored convs, and -- in batched mode -- the non-local block's NT matmuls.
+//
+// GEMM view:  M = N*To*Ho*Wo output positions, N = Co, K = taps * Ci.
+//   A[m][k]  gathered on the fly from x (zero outside the image): for one filter tap the BK
+//            channels of a row are contiguous in NDHWC, so every lane issues one 16-byte load.
+//   B[n][k]  = w_packed[tap][co][c]  (K contiguous).
+// Both operand tiles are staged global -> registers -> LDS ([rows][BK+4] floats: the +4 pad makes
+// the ds_read_b128 fragment reads of 32 distinct rows conflict-free) and double buffered: the
+// loads of k-step s+1 are issued before the MFMAs of step s and written to the other buffer
+// after them, one barrier per k-step.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (or 16x16x4): lane l supplies A[row = l % MT][k = l / MT] and
+// B[k = l / MT][col = l % MT].  A lane's ds_read_b128 returns 4 consecutive k of its row; the
+// r-th element of every lane forms one MFMA, i.e. the hardware k index is a fixed permutation of
+// the logical one -- harmless because A and B use the same permutation.
+// fp32 in, fp32 accumulate, bit-exact k-ordered fma chain (cdna_hip_programming.md section 3).
+#include "ptx_common.h"
+
+namespace ptx {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    float* partial;
+    int N, Ti, Hi, Wi, ldx, kA;
+    int To, Ho, Wo, Co, ldy;
+    int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+    int ldw, kB, w_rows, M;
+    long long w_tap_stride;
+    unsigned flags;
+    int ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
+    int m_tiles, n_tiles, split_k, kchunks, steps_total, steps_per_split;
+    long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
+};
+
+template <int MT> struct Mfma;
+template <> struct Mfma<32> {
+    using acc_t = f32x16;
+    static constexpr int NACC = 16;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lane) {
+        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+};
+template <> struct Mfma<16> {
+    using acc_t = f32x4;
+    static constexpr int NACC = 4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
+};
+
+// bias + residual + ReLU for one output element (shared with the split-K reduce kernel)
+__device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m, int co) {
+    if (p.bias) v += p.bias[co];
+    if (p.flags & PTX_EPI_RES_ADD) {
+        v += p.res[(size_t)m * p.ldr + co];
+    } else if (p.flags & PTX_EPI_RES_PADA) {
+        if (co < p.res_C) {
+            const int wo = m % p.Wo;
+            int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            t /= p.Ho;
+            const int to = t % p.To;
+            const int n = t / p.To;
+            const size_t pos = (((size_t)n * p.res_T + to * p.res_sT) * p.res_H + ho * p.res_sH) * p.res_W +
+                               wo * p.res_sW;
+            v += p.res[pos * p.ldr + co];
+        }
+    }
+    if (p.flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
+    return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int MT>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+    using MF = Mfma<MT>;
+    using acc_t = typename MF::acc_t;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int LDK = BK + 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / MT, TN = WTN / MT;
+    static_assert(TM * MT * WM == BM && TN * MT * WN == BN, "tile must split evenly");
+    constexpr int KG = 64 / MT;              // lane groups along k
+    constexpr int KSUB = BK / (4 * KG);      // ds_read_b128 sub-steps per k-step
+    static_assert(KSUB * 4 * KG == BK, "BK must be a multiple of 4*KG");
+    constexpr int F4R = BK / 4;              // float4 per tile row
+    constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
+    constexpr int A_IT = (A_F4 + 255) / 256, B_IT = (B_F4 + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int n_tile = tile % p.n_tiles;
+    const int m_tile = tile / p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int zb = blockIdx.y;
+    const int zs = blockIdx.z;
+
+    const float* __restrict__ xg = p.x + (size_t)zb * p.bs_x;
+    const float* __restrict__ wg = p.w + (size_t)zb * p.bs_w;
+
+    // ---- per-thread A rows: output position -> top-left input coordinate (tap independent) ----
+    int a_n[A_IT], a_t0[A_IT], a_h0[A_IT], a_w0[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / F4R;
+        const int m = m0 + row;
+        const bool ok = (idx < A_F4) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int wo = mm % p.Wo;
+        int t = mm / p.Wo;
+        const int ho = t % p.Ho;
+        t /= p.Ho;
+        const int to = t % p.To;
+        a_ok[i] = ok;
+        a_n[i] = t / p.To;
+        a_t0[i] = to * p.sT - p.pT;
+        a_h0[i] = ho * p.sH - p.pH;
+        a_w0[i] = wo * p.sW - p.pW;
+    }
+
+    // ---- block-uniform tap pruning: taps that only ever see zero padding are skipped ----
+    int kt_lo = 0, kt_hi = p.kT - 1, kh_lo = 0, kh_hi = p.kH - 1;
+    {
+        const int m_last = min(m0 + BM, p.M) - 1;
+        const int plane = p.Ho * p.Wo;
+        const int vol = p.To * plane;
+        if (m0 / vol == m_last / vol) {
+            const int to_a = (m0 % vol) / plane, to_b = (m_last % vol) / plane;
+            kt_lo = max(0, p.pT - to_b * p.sT);
+            kt_hi = min(p.kT - 1, p.Ti - 1 + p.pT - to_a * p.sT);
+            if (to_a == to_b) {
+                const int ho_a = (m0 % plane) / p.Wo, ho_b = (m_last % plane) / p.Wo;
+                kh_lo = max(0, p.pH - ho_b * p.sH);
+                kh_hi = min(p.kH - 1, p.Hi - 1 + p.pH - ho_a * p.sH);
+            }
+        }
+    }
+    const int khw = p.kH * p.kW;
+    const int s_end = min(p.steps_total, (zs + 1) * p.steps_per_split);
+    // first valid k-step at or after s (k-steps are numbered tap-major, channel-chunk-minor)
+    auto next_valid = [&](int s) -> int {
+        while (s < s_end) {
+            const int tap = s / p.kchunks;
+            const int kt = tap / khw;
+            const int kh = (tap - kt * khw) / p.kW;
+            if (kt < kt_lo) { s = kt_lo * khw * p.kchunks; continue; }
+            if (kt > kt_hi) { s = s_end; break; }
+            if (kh < kh_lo) { s = (kt * khw + kh_lo * p.kW) * p.kchunks; continue; }
+            if (kh > kh_hi) { s = (kt + 1) * khw * p.kchunks; continue; }
+            break;
+        }
+        return s;
+    };
+
+    f32x4 ra[A_IT], rb[B_IT];
+    const bool pro_relu = (p.flags & PTX_PRO_RELU) != 0;
+
+    auto load_tiles = [&](int s) {
+        const int tap = s / p.kchunks;
+        const int c0 = (s - tap * p.kchunks) * BK;
+        const int kt = tap / khw;
+        const int rem = tap - kt * khw;
+        const int kh = rem / p.kW;
+        const int kw = rem - kh * p.kW;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int col = (idx % F4R) * 4;
+            const int ti = a_t0[i] + kt, hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+            const bool ok = a_ok[i] && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+                            (unsigned)wi < (unsigned)p.Wi && (c0 + col) < p.kA;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const size_t pos = (((size_t)a_n[i] * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
+                v = *reinterpret_cast<const f32x4*>(xg + pos * p.ldx + c0 + col);
+                if (pro_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            ra[i] = v;
+        }
+        const float* wt = wg + (size_t)tap * p.w_tap_stride;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / F4R;
+            const int col = (idx % F4R) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < B_F4 && (n0 + row) < p.w_rows && (c0 + col) < p.kB)
+                v = *reinterpret_cast<const f32x4*>(wt + (size_t)(n0 + row) * p.ldw + c0 + col);
+            rb[i] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* Ab = As + buf * BM * LDK;
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < A_F4) *reinterpret_cast<f32x4*>(Ab + (idx / F4R) * LDK + (idx % F4R) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < B_F4) *reinterpret_cast<f32x4*>(Bb + (idx / F4R) * LDK + (idx % F4R) * 4) = rb[i];
+        }
+    };
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (lane / MT) * 4;
+    const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (lane / MT) * 4;
+
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * BM * LDK + frag_off_a;
+        const float* Bb = Bs + buf * BN * LDK + frag_off_b;
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + ks * 4 * KG);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + ks * 4 * KG);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i][r], b[j][r], acc[i][j]);
+        }
+    };
+
+    // ---- main loop: register-staged double buffering, one barrier per k-step ----
+    int s = next_valid(zs * p.steps_per_split);
+    if (s < s_end) {
+        load_tiles(s);
+        s = next_valid(s + 1);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            const bool more = s < s_end;
+            if (more) {
+                load_tiles(s);
+                s = next_valid(s + 1);
+            }
+            compute(buf);
+            if (!more) break;
+            store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue ----
+    float* __restrict__ yg = p.y + (size_t)zb * p.bs_y;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * WTN + j * MT + (lane % MT);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) {
+                const int m = m0 + wm * WTM + i * MT + MF::row(r, lane);
+                if (m < p.M && co < p.ldy) {
+                    if (p.split_k > 1)
+                        p.partial[((size_t)zs * p.M + m) * p.ldy + co] = acc[i][j][r];
+                    else
+                        yg[(size_t)m * p.ldy + co] = conv_epilogue(p, acc[i][j][r], m, co);
+                }
+            }
+        }
+    }
+}
+
+// y = epilogue(sum over splits of partial)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
+    const size_t total4 = (size_t)p.M * p.ldy / 4;
+    const size_t slab = (size_t)p.M * p.ldy;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + i * 4);
+        for (int z = 1; z < p.split_k; ++z) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(p.partial + z * slab + i * 4);
+            v += u;
+        }
+        const size_t e = i * 4;
+        const int m = (int)(e / p.ldy);
+        const int co = (int)(e - (size_t)m * p.ldy);
+        f32x4 o;
+        o.x = conv_epilogue(p, v.x, m, co);
+        o.y = conv_epilogue(p, v.y, m, co + 1);
+        o.z = conv_epilogue(p, v.z, m, co + 2);
+        o.w = conv_epilogue(p, v.w, m, co + 3);
+        *reinterpret_cast<f32x4*>(p.y + e) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile configurations
+// ------------------------------------------------------------------------------------------
+typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
+
+template <int BM, int BN, int BK, int WM, int WN, int MT>
+static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT>;
+    static bool attr_set = false;   // per process; benign race (idempotent call)
+    if (!attr_set) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return hip_check(hipGetLastError(), "conv_igemm launch");
+}
+
+struct ConvConfig {
+    int BM, BN, BK, WM, WN, MT;
+    const char* name;
+    launch_fn launch;
+};
+
+#define PTX_CFG(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT> }
+
+static const ConvConfig kConfigs[] = {
+    PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
+    PTX_CFG(128, 64, 32, 2, 2, 32),   // 1  Co == 64
+    PTX_CFG(64, 64, 32, 2, 2, 32),    // 2  small M
+    PTX_CFG(256, 64, 32, 4, 1, 32),   // 3  Co == 64, tall
+    PTX_CFG(64, 128, 32, 2, 2, 32),   // 4  small M, wide
+    PTX_CFG(112, 64, 32, 1, 4, 16),   // 5  M = 2^k * 49 (7 x 16 rows), Co == 64
+    PTX_CFG(128, 64, 24, 2, 2, 32),   // 6  kW-folded stem (K chunk = 24)
+    PTX_CFG(256, 64, 24, 4, 1, 32),   // 7  kW-folded stem, tall
+    PTX_CFG(112, 128, 32, 1, 4, 16),  // 8  M = 2^k * 49, Co >= 128
+    PTX_CFG(64, 64, 16, 2, 2, 32),    // 9  ragged channel counts ((2+1)D), small K chunk
+    PTX_CFG(128, 64, 16, 2, 2, 32),   // 10 ragged channel counts, larger M
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+static int validate_desc(const ptx_conv3d_desc* d) {
+    if (!d) return fail(PTX_ERR_INVALID, "conv3d: null descriptor");
+    if (d->N <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 ||
+        d->Ci <= 0 || d->Co <= 0)
+        return fail(PTX_ERR_INVALID, "conv3d: non-positive extent");
+    if (d->ldx < d->Ci || d->ldx % 4 || d->ldy < d->Co || d->ldy % 4)
+        return fail(PTX_ERR_INVALID, "conv3d: channel strides must be >= C and multiples of 4 (ldx=%d ldy=%d)",
+                    d->ldx, d->ldy);
+    if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 ||
+        d->pH < 0 || d->pW < 0)
+        return fail(PTX_ERR_INVALID, "conv3d: bad filter geometry");
+    if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < d->ldy)
+        return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d ldy=%d",
+                    d->Kc, d->Co_pad, d->Ci, d->ldy);
+    // output extent must match the conv arithmetic
+    const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
+    const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
+    const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
+    if (to != d->To || ho != d->Ho || wo != d->Wo)
+        return fail(PTX_ERR_INVALID, "conv3d: output extent (%d,%d,%d) != expected (%d,%d,%d)", d->To, d->Ho,
+                    d->Wo, to, ho, wo);
+    if ((int64_t)d->N * d->To * d->Ho * d->Wo > 0x7fffffffLL || (int64_t)d->N * d->Ti * d->Hi * d->Wi > 0x7fffffffLL)
+        return fail(PTX_ERR_INVALID, "conv3d: more than 2^31 positions");
+    if ((d->flags & PTX_EPI_RES_ADD) && (d->flags & PTX_EPI_RES_PADA))
+        return fail(PTX_ERR_INVALID, "conv3d: RES_ADD and RES_PADA are exclusive");
+    return PTX_OK;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_conv3d_num_configs(void) { return kNumConfigs; }
+
+extern "C" const char* ptx_conv3d_config_name(int config) {
+    if (config < 0 || config >= kNumConfigs) return "invalid";
+    return kConfigs[config].name;
+}
+
+extern "C" int ptx_conv3d_config_supported(const ptx_conv3d_desc* d, int config) {
+    if (validate_desc(d) != PTX_OK || config < 0 || config >= kNumConfigs) return 0;
+    return 1;   // K / M / N tails are all guarded inside the kernel
+}
+
+extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
+    if (split_k) *split_k = 1;
+    if (validate_desc(d) != PTX_OK) return 0;
+    const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
+    const int taps = d->kT * d->kH * d->kW;
+    int cfg;
+    if (d->Kc % 32 != 0 && d->Kc % 24 == 0) {
+        cfg = 6;
+    } else if (d->Kc % 32 != 0) {
+        cfg = (M >= 64 * 1024) ? 10 : 9;
+    } else {
+        const bool wide = d->ldy >= 128;
+        const int64_t big = cdiv64(M, 128) * cdiv(d->ldy, wide ? 128 : 64);
+        if (big >= 2 * kNumCU)
+            cfg = wide ? 0 : 1;
+        else
+            cfg = 2;
+    }
+    const ConvConfig& c = kConfigs[cfg];
+    const int64_t blocks = cdiv64(M, c.BM) * cdiv(d->ldy, c.BN);
+    const int steps = taps * cdiv(d->Kc, c.BK);
+    int sk = 1;
+    if (blocks < kNumCU) {
+        sk = (int)((kNumCU + blocks - 1) / blocks);
+        if (sk > 8) sk = 8;
+        while (sk > 1 && steps / sk < 8) --sk;
+    }
+    if (split_k) *split_k = sk;
+    return cfg;
+}
+
+extern "C" size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* d, int split_k) {
+    if (!d || split_k <= 1) return 0;
+    return (size_t)split_k * d->N * d->To * d->Ho * d->Wo * d->ldy * sizeof(float);
+}
+
+namespace ptx {
+int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
+                hipStream_t st) {
+    const ConvConfig& c = kConfigs[config];
+    a.m_tiles = cdiv(a.M, c.BM);
+    a.n_tiles = cdiv(a.ldy, c.BN);
+    a.kchunks = cdiv(max(a.kA, a.kB), c.BK);
+    a.steps_total = a.kT * a.kH * a.kW * a.kchunks;
+    if (split_k < 1) split_k = 1;
+    if (split_k > a.steps_total) split_k = a.steps_total;
+    if (batch > 1) split_k = 1;
+    a.split_k = split_k;
+    a.steps_per_split = cdiv(a.steps_total, split_k);
+    a.partial = nullptr;
+    if (split_k > 1) {
+        const size_t need = (size_t)split_k * a.M * a.ldy * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(PTX_ERR_WORKSPACE, "conv3d: split_k=%d needs %zu workspace bytes, got %zu", split_k, need,
+                        workspace_bytes);
+        a.partial = static_cast<float*>(workspace);
+    }
+    if ((int64_t)a.m_tiles * a.n_tiles > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "conv3d: grid too large");
+    dim3 grid((unsigned)(a.m_tiles * a.n_tiles), (unsigned)batch, (unsigned)split_k);
+    int s = c.launch(a, grid, st);
+    if (s != PTX_OK) return s;
+    if (split_k > 1) {
+        const size_t total4 = (size_t)a.M * a.ldy / 4;
+        unsigned blocks = (unsigned)std::min<size_t>((total4 + 255) / 256, (size_t)kNumCU * 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+        return hip_check(hipGetLastError(), "splitk_reduce launch");
+    }
+    return PTX_OK;
+}
+}  // namespace ptx
+
+extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const float* w_packed, const float* bias,
+                              const float* res, float* y, void* workspace, size_t workspace_bytes, int config,
+                              int split_k, ptx_stream_t stream) {
+    int s = validate_desc(d);
+    if (s != PTX_OK) return s;
+    if (!x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv3d: null tensor pointer");
+    if ((d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) && !res)
+        return fail(PTX_ERR_INVALID, "conv3d: residual flag set but res == NULL");
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)res | (uintptr_t)workspace) & 15)
+        return fail(PTX_ERR_INVALID, "conv3d: pointers must be 16-byte aligned");
+    if (config >= kNumConfigs) return fail(PTX_ERR_INVALID, "conv3d: config %d out of range", config);
+    if (config < 0) {
+        int sk = 1;
+        config = ptx_conv3d_pick_config(d, &sk);
+        if (split_k <= 0) split_k = sk;
+    }
+    if (split_k <= 0) split_k = 1;
+    if (d->flags & PTX_EPI_RES_ADD) {
+        if (d->ldr < d->ldy) return fail(PTX_ERR_INVALID, "conv3d: residual stride %d < ldy %d", d->ldr, d->ldy);
+    }
+    if (d->flags & PTX_EPI_RES_PADA) {
+        if (d->res_C > d->ldr || d->res_C > d->Co || (d->To - 1) * d->res_sT >= d->res_T ||
+            (d->Ho - 1) * d->res_sH >= d->res_H || (d->Wo - 1) * d->res_sW >= d->res_W)
+            return fail(PTX_ERR_INVALID, "conv3d: shortcut-A residual geometry out of range");
+    }
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.y = y;
+    a.N = d->N; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx; a.kA = d->ldx;
+    a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
+    a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW;
+    a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
+    a.ldw = d->Kc; a.kB = d->Kc; a.w_rows = d->Co_pad; a.w_tap_stride = (long long)d->Co_pad * d->Kc;
+    a.M = d->N * d->To * d->Ho * d->Wo;
+    a.flags = d->flags;
+    a.ldr = d->ldr; a.res_C = d->res_C; a.res_T = d->res_T; a.res_H = d->res_H; a.res_W = d->res_W;
+    a.res_sT = d->res_sT; a.res_sH = d->res_sH; a.res_sW = d->res_sW;
+    return launch_conv(a, config, split_k, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t batch, int32_t M, int32_t Nn,
+                            int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int64_t strideA, int64_t strideB,
+                            int64_t strideC, ptx_stream_t stream) {
+    if (!A || !B || !C) return fail(PTX_ERR_INVALID, "bgemm: null pointer");
+    if (batch <= 0 || M <= 0 || Nn <= 0 || K <= 0) return fail(PTX_ERR_INVALID, "bgemm: non-positive extent");
+    const int k4 = (K + 3) / 4 * 4;
+    if (lda % 4 || ldb % 4 || ldc % 4 || lda < k4 || ldb < k4 || ldc < Nn || strideA % 4 || strideB % 4 ||
+        strideC % 4)
+        return fail(PTX_ERR_INVALID, "bgemm: leading dims / strides must be multiples of 4 and cover the extents");
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return fail(PTX_ERR_INVALID, "bgemm: misaligned pointer");
+    if (batch > 65535) return fail(PTX_ERR_INVALID, "bgemm: batch > 65535");
+    ConvArgs a{};
+    a.x = A; a.w = B; a.bias = nullptr; a.res = nullptr; a.y = C;
+    a.N = 1; a.Ti = 1; a.Hi = 1; a.Wi = M; a.ldx = lda; a.kA = k4;
+    a.To = 1; a.Ho = 1; a.Wo = M; a.Co = Nn; a.ldy = ldc;
+    a.kT = a.kH = a.kW = 1; a.sT = a.sH = a.sW = 1; a.pT = a.pH = a.pW = 0;
+    a.ldw = ldb; a.kB = k4; a.w_rows = Nn; a.w_tap_stride = 0;
+    a.M = M; a.flags = 0;
+    a.bs_x = strideA; a.bs_w = strideB; a.bs_y = strideC;
+    // C columns [Nn, ldc) are written as zero (B rows >= Nn are read as zero)
+    const int64_t blocks128 = cdiv64(M, 128) * cdiv(ldc, 128) * batch;
+    const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 0 : 2;
+    return launch_conv(a, config, 1, batch, nullptr, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,263 @@
+// Load-time weight packing (BN fold + K-major relayout) and the layout transforms at the API edge.
+// All of these are HBM-bound byte movers: coalesced 16-byte accesses on the channels-last side,
+// LDS tile transposes where both sides cannot be contiguous at once.
+#include "ptx_common.h"
+
+namespace ptx {
+
+thread_local char g_last_error[512] = "";
+char* last_error_buf() { return g_last_error; }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bn_scale(const float* gamma, const float* var, float eps, int co) {
+    return gamma ? gamma[co] * (1.0f / sqrtf(var[co] + eps)) : 1.0f;
+}
+
+__global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const float* __restrict__ w,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ var, float eps,
+                                                          float* __restrict__ out, size_t total) {
+    const int taps_hw = d.kH * d.kW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % d.Kc);
+        size_t t = i / d.Kc;
+        const int co = (int)(t % d.Co_pad);
+        const int tap = (int)(t / d.Co_pad);
+        int kt, kh, kw, c;
+        bool valid = co < d.Co;
+        if (d.fold_kw) {
+            kt = tap / d.kH;
+            kh = tap % d.kH;
+            kw = k / d.Ci;
+            c = k % d.Ci;
+            valid = valid && k < d.kW * d.Ci;
+        } else {
+            kt = tap / taps_hw;
+            const int r = tap % taps_hw;
+            kh = r / d.kW;
+            kw = r % d.kW;
+            c = k;
+            valid = valid && k < d.Ci;
+        }
+        float v = 0.f;
+        if (valid) {
+            const size_t src = ((((size_t)co * d.Ci + c) * d.kT + kt) * d.kH + kh) * d.kW + kw;
+            v = w[src] * bn_scale(gamma, var, eps, co);
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void pack_bias_kernel(int Co, int Co_pad, const float* __restrict__ conv_bias,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                 float* __restrict__ out) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Co_pad) return;
+    float b = 0.f;
+    if (co < Co) {
+        const float s = bn_scale(gamma, var, eps, co);
+        const float cb = conv_bias ? conv_bias[co] : 0.f;
+        const float mu = mean ? mean[co] : 0.f;
+        b = (beta ? beta[co] : 0.f) + (cb - mu) * s;
+    }
+    out[co] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// [N][C][S] <-> [N][S][ld] tile transposes (32 x 32 floats through LDS, +1 pad)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ncs_to_nsc_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                         long long S, int ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float* xn = x + (size_t)n * C * S;
+    float* yn = y + (size_t)n * S * ld;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j;
+        const long long s = s0 + tx;
+        tile[ty + j][tx] = (c < C && s < S) ? xn[(size_t)c * S + s] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const long long s = s0 + ty + j;
+        const int c = c0 + tx;
+        if (s < S && c < ld) yn[(size_t)s * ld + c] = tile[tx][ty + j];   // zero beyond C by construction
+    }
+}
+
+__global__ void __launch_bounds__(256) nsc_to_ncs_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                         long long S, int ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xn = x + (size_t)n * S * ld;
+    float* yn = y + (size_t)n * C * S;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const long long s = s0 + ty + j;
+        const int c = c0 + tx;
+        tile[ty + j][tx] = (s < S && c < C) ? xn[(size_t)s * ld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j;
+        const long long s = s0 + tx;
+        if (c < C && s < S) yn[(size_t)c * S + s] = tile[tx][ty + j];
+    }
+}
+
+// y[b][c][r] = x[b][r][c]; rows r in [R, ldy) of y are zero-filled
+__global__ void __launch_bounds__(256) transpose_last2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int R, int Cc, int ldx, int ldy) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xb = x + (size_t)b * R * ldx;
+    float* yb = y + (size_t)b * Cc * ldy;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int r = r0 + ty + j, c = c0 + tx;
+        tile[ty + j][tx] = (r < R && c < Cc) ? xb[(size_t)r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j, r = r0 + tx;
+        if (c < Cc && r < ldy) yb[(size_t)c * ldy + r] = tile[tx][ty + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-Cin stem: NCDHW -> [N][T][H][Wo][ld] with the kW taps folded into the channel axis
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_kw_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                      int T, int H, int W, int kW, int sW, int pW, int Wo, int ld,
+                                                      size_t total4) {
+    const int f4r = ld / 4;
+    const int kvalid = kW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % f4r);
+        size_t row = i / f4r;
+        const int wo = (int)(row % Wo);
+        size_t t1 = row / Wo;
+        const int h = (int)(t1 % H);
+        t1 /= H;
+        const int t = (int)(t1 % T);
+        const int n = (int)(t1 / T);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;
+            const int kw = k / C, c = k - kw * C;
+            const int wi = wo * sW - pW + kw;
+            v[e] = (k < kvalid && wi >= 0 && wi < W) ? x[((((size_t)n * C + c) * T + t) * H + h) * W + wi] : 0.f;
+        }
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+static unsigned grid_for(size_t work_items) {
+    size_t b = (work_items + 255) / 256;
+    const size_t cap = (size_t)kNumCU * 8;
+    if (b > cap) b = cap;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" const char* ptx_version(void) { return "ptx_amd 0.1.0 (gfx950, fp32 MFMA)"; }
+extern "C" const char* ptx_last_error(void) { return last_error_buf(); }
+
+extern "C" size_t ptx_packed_weight_elems(const ptx_pack_desc* d) {
+    if (!d) return 0;
+    const size_t taps = d->fold_kw ? (size_t)d->kT * d->kH : (size_t)d->kT * d->kH * d->kW;
+    return taps * d->Co_pad * d->Kc;
+}
+
+extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, const float* conv_bias,
+                                    const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                    const float* bn_var, float bn_eps, float* w_packed, float* bias_out,
+                                    ptx_stream_t stream) {
+    if (!d || !w || !w_packed || !bias_out) return fail(PTX_ERR_INVALID, "pack: null pointer");
+    if (d->Co <= 0 || d->Ci <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0)
+        return fail(PTX_ERR_INVALID, "pack: non-positive extent");
+    const int keff = d->fold_kw ? d->kW * d->Ci : d->Ci;
+    if (d->Kc < keff || d->Kc % 4 || d->Co_pad < d->Co || d->Co_pad % 128)
+        return fail(PTX_ERR_INVALID, "pack: Kc=%d must cover K=%d (multiple of 4); Co_pad=%d must cover Co=%d (multiple of 128)",
+                    d->Kc, keff, d->Co_pad, d->Co);
+    if ((bn_gamma != nullptr) != (bn_var != nullptr))
+        return fail(PTX_ERR_INVALID, "pack: bn_gamma and bn_var must be given together");
+    const size_t total = ptx_packed_weight_elems(d);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, st, *d, w, bn_gamma, bn_var, bn_eps,
+                       w_packed, total);
+    PTX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(d->Co_pad, 256)), dim3(256), 0, st, d->Co, d->Co_pad, conv_bias,
+                       bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, bias_out);
+    return hip_check(hipGetLastError(), "pack launch");
+}
+
+static int check_layout_args(const void* x, const void* y, int N, int C, int64_t S, int ld) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "layout: null pointer");
+    if (N <= 0 || C <= 0 || S <= 0 || ld < C || ld % 4) return fail(PTX_ERR_INVALID, "layout: bad extents");
+    if (N > 65535 || cdiv(ld, 32) > 65535) return fail(PTX_ERR_INVALID, "layout: N or C too large for the grid");
+    return PTX_OK;
+}
+
+extern "C" int ptx_ncdhw_to_ndhwc(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                                  ptx_stream_t stream) {
+    int s = check_layout_args(x, y, N, C, S, ld);
+    if (s) return s;
+    dim3 grid((unsigned)cdiv64(S, 32), (unsigned)cdiv(ld, 32), (unsigned)N);
+    hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)S, ld);
+    return hip_check(hipGetLastError(), "ncdhw_to_ndhwc launch");
+}
+
+extern "C" int ptx_ndhwc_to_ncdhw(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                                  ptx_stream_t stream) {
+    int s = check_layout_args(x, y, N, C, S, ld);
+    if (s) return s;
+    dim3 grid((unsigned)cdiv64(S, 32), (unsigned)cdiv(C, 32), (unsigned)N);
+    hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)S, ld);
+    return hip_check(hipGetLastError(), "ndhwc_to_ncdhw launch");
+}
+
+extern "C" int ptx_transpose_last2(const float* x, float* y, int32_t batch, int32_t R, int32_t Cc, int32_t ldx,
+                                   int32_t ldy, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "transpose: null pointer");
+    if (batch <= 0 || batch > 65535 || R <= 0 || Cc <= 0 || ldx < Cc || ldy < R)
+        return fail(PTX_ERR_INVALID, "transpose: bad extents");
+    dim3 grid((unsigned)cdiv(ldy, 32), (unsigned)cdiv(Cc, 32), (unsigned)batch);
+    hipLaunchKernelGGL(transpose_last2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, R, Cc, ldx, ldy);
+    return hip_check(hipGetLastError(), "transpose_last2 launch");
+}
+
+extern "C" int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W,
+                                 int32_t kW, int32_t sW, int32_t pW, int32_t Wo, int32_t ld, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "fold_kw: null pointer");
+    if (N <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || kW <= 0 || sW <= 0 || pW < 0 || Wo <= 0)
+        return fail(PTX_ERR_INVALID, "fold_kw: non-positive extent");
+    if (ld < kW * C || ld % 4) return fail(PTX_ERR_INVALID, "fold_kw: ld=%d must cover kW*C=%d and be a multiple of 4", ld, kW * C);
+    if (Wo != (W + 2 * pW - kW) / sW + 1) return fail(PTX_ERR_INVALID, "fold_kw: Wo mismatch");
+    if ((uintptr_t)y & 15) return fail(PTX_ERR_INVALID, "fold_kw: misaligned output");
+    const size_t total4 = (size_t)N * T * H * Wo * (ld / 4);
+    hipLaunchKernelGGL(fold_kw_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, C, T, H, W, kW,
+                       sW, pW, Wo, ld, total4);
+    return hip_check(hipGetLastError(), "fold_kw launch");
+}

@@ -1,0 +1,268 @@
+// HBM-bound pieces of the path: 3-D max pooling, global average pooling, the small-M linear
+// layers (classifier head, TRN relation MLP) and the non-local block's row softmax.
+// Channels-last everywhere, so a wave's 64 lanes always touch 64 consecutive float4/float.
+#include "ptx_common.h"
+#include <cfloat>
+
+namespace ptx {
+
+// ---------------------------------------------------------------------------------------------
+// max_pool3d, -inf padding (every window of the reference's k3 s2 p1 pool has >= 1 valid tap)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
+                                                        float* __restrict__ y, size_t total4) {
+    const int f4r = d.ld / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % f4r);
+        size_t pos = i / f4r;
+        const int wo = (int)(pos % d.Wo);
+        size_t t1 = pos / d.Wo;
+        const int ho = (int)(t1 % d.Ho);
+        t1 /= d.Ho;
+        const int to = (int)(t1 % d.To);
+        const int n = (int)(t1 / d.To);
+        const int t_lo = max(0, to * d.sT - d.pT), t_hi = min(d.Ti, to * d.sT - d.pT + d.kT);
+        const int h_lo = max(0, ho * d.sH - d.pH), h_hi = min(d.Hi, ho * d.sH - d.pH + d.kH);
+        const int w_lo = max(0, wo * d.sW - d.pW), w_hi = min(d.Wi, wo * d.sW - d.pW + d.kW);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int t = t_lo; t < t_hi; ++t)
+            for (int h = h_lo; h < h_hi; ++h) {
+                const float* row = x + ((((size_t)n * d.Ti + t) * d.Hi + h) * d.Wi) * d.ld + q * 4;
+                for (int w = w_lo; w < w_hi; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)w * d.ld);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
+                    m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        // pad channels [C, ld) hold zeros on input, so they stay zero on output
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool
+// ---------------------------------------------------------------------------------------------
+// channels-last: x [N][S][ld] -> y [N][C]; block = 4 row-groups x 64 channels
+__global__ void __launch_bounds__(256) avgpool_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                         long long S, int ld) {
+    __shared__ float part[4][64];
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C) {
+        const float* xn = x + (size_t)n * S * ld + c;
+        for (long long s = g; s < S; s += 4) acc += xn[(size_t)s * ld];
+    }
+    part[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        y[(size_t)n * C + c] = (part[0][l] + part[1][l] + part[2][l] + part[3][l]) / (float)S;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// channels-first: x [N][C][S] -> y [N][C]; one wave per (n, c)
+__global__ void __launch_bounds__(256) avgpool_cf_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long long NC, long long S) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= NC) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * S;
+    float acc = 0.f;
+    for (long long s = lane; s < S; s += 64) acc += xr[s];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc / (float)S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-M linear: one wave per output feature, MR rows of x at a time (weight row read once)
+// ---------------------------------------------------------------------------------------------
+template <int MR>
+__global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            int M, int K, int Nout, int ldx, int ldy, unsigned flags) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= Nout) return;
+    const int lane = threadIdx.x & 63;
+    const int m0 = blockIdx.y * MR;
+    const bool relu_in = (flags & PTX_PRO_RELU) != 0;
+    const float* wr = w + (size_t)j * K;
+    float acc[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) acc[r] = 0.f;
+    const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
+    if (vec) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (m0 + r < M) {
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + r) * ldx + k);
+                    if (relu_in) {
+                        xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f);
+                        xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f);
+                    }
+                    acc[r] = fmaf(xv.x, wv.x, acc[r]);
+                    acc[r] = fmaf(xv.y, wv.y, acc[r]);
+                    acc[r] = fmaf(xv.z, wv.z, acc[r]);
+                    acc[r] = fmaf(xv.w, wv.w, acc[r]);
+                }
+            }
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (m0 + r < M) {
+                    float xv = x[(size_t)(m0 + r) * ldx + k];
+                    if (relu_in) xv = fmaxf(xv, 0.f);
+                    acc[r] = fmaf(xv, wv, acc[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const float s = wave_sum(acc[r]);
+        if (lane == 0 && m0 + r < M) {
+            float v = s + (b ? b[j] : 0.f);
+            if (flags & PTX_EPI_ACCUM) v += y[(size_t)(m0 + r) * ldy + j];
+            if (flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
+            y[(size_t)(m0 + r) * ldy + j] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-place row softmax (or 1/cols scaling); one workgroup per row, row held in registers
+// ---------------------------------------------------------------------------------------------
+constexpr int kSoftmaxMaxPerThread = 16;   // rows up to 4096 columns
+
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int cols, int ld, int scale_only) {
+    __shared__ float red[4];
+    __shared__ float red2[4];
+    float* row = x + (size_t)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[kSoftmaxMaxPerThread];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = (c < cols) ? row[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    if (scale_only) {
+        const float inv = 1.0f / (float)cols;
+#pragma unroll
+        for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
+            const int c = tid + 256 * i;
+            if (c < cols) row[c] = v[i] * inv;
+            else if (c < ld) row[c] = 0.f;
+        }
+        return;
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = (c < cols) ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red2[wave] = sum;
+    __syncthreads();
+    sum = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
+        const int c = tid + 256 * i;
+        if (c < cols) row[c] = v[i] * inv;
+        else if (c < ld) row[c] = 0.f;
+    }
+}
+
+static unsigned grid_for(size_t work_items) {
+    size_t b = (work_items + 255) / 256;
+    const size_t cap = (size_t)kNumCU * 8;
+    if (b > cap) b = cap;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float* y, ptx_stream_t stream) {
+    if (!d || !x || !y) return fail(PTX_ERR_INVALID, "maxpool3d: null pointer");
+    if (d->N <= 0 || d->C <= 0 || d->ld < d->C || d->ld % 4 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0 ||
+        d->sT <= 0 || d->sH <= 0 || d->sW <= 0)
+        return fail(PTX_ERR_INVALID, "maxpool3d: bad descriptor");
+    if (2 * d->pT > d->kT || 2 * d->pH > d->kH || 2 * d->pW > d->kW)
+        return fail(PTX_ERR_INVALID, "maxpool3d: padding larger than half the window");
+    const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
+    const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
+    const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
+    if (to != d->To || ho != d->Ho || wo != d->Wo) return fail(PTX_ERR_INVALID, "maxpool3d: output extent mismatch");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "maxpool3d: misaligned pointer");
+    const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (d->ld / 4);
+    hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, *d, x, y, total4);
+    return hip_check(hipGetLastError(), "maxpool3d launch");
+}
+
+extern "C" int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
+                                  int32_t channels_first, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "avgpool: null pointer");
+    if (N <= 0 || C <= 0 || S <= 0) return fail(PTX_ERR_INVALID, "avgpool: non-positive extent");
+    if (channels_first) {
+        const long long NC = (long long)N * C;
+        hipLaunchKernelGGL(avgpool_cf_kernel, dim3((unsigned)cdiv64(NC, 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                           NC, (long long)S);
+    } else {
+        if (ld < C || N > 65535) return fail(PTX_ERR_INVALID, "avgpool: bad ld / N");
+        hipLaunchKernelGGL(avgpool_cl_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)N), dim3(256), 0,
+                           (hipStream_t)stream, x, y, C, (long long)S, ld);
+    }
+    return hip_check(hipGetLastError(), "avgpool launch");
+}
+
+extern "C" int ptx_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K,
+                              int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream) {
+    if (!x || !w || !y) return fail(PTX_ERR_INVALID, "linear: null pointer");
+    if (M <= 0 || K <= 0 || Nout <= 0 || ldx < K || ldy < Nout) return fail(PTX_ERR_INVALID, "linear: bad extents");
+    constexpr int MR = 8;
+    if (cdiv(M, MR) > 65535) return fail(PTX_ERR_UNSUPPORTED, "linear: M too large for the small-M kernel");
+    dim3 grid((unsigned)cdiv(Nout, 4), (unsigned)cdiv(M, MR));
+    hipLaunchKernelGGL(linear_smallm_kernel<MR>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, M, K, Nout, ldx,
+                       ldy, flags);
+    return hip_check(hipGetLastError(), "linear launch");
+}
+
+extern "C" int ptx_softmax_rows(float* x, int64_t rows, int32_t cols, int32_t ld, int32_t scale_only,
+                                ptx_stream_t stream) {
+    if (!x) return fail(PTX_ERR_INVALID, "softmax: null pointer");
+    if (rows <= 0 || cols <= 0 || ld < cols) return fail(PTX_ERR_INVALID, "softmax: bad extents");
+    if (cols > 256 * kSoftmaxMaxPerThread || ld > 256 * kSoftmaxMaxPerThread)
+        return fail(PTX_ERR_UNSUPPORTED, "softmax: rows longer than %d are not supported", 256 * kSoftmaxMaxPerThread);
+    if (rows > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "softmax: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld,
+                       scale_only);
+    return hip_check(hipGetLastError(), "softmax launch");
+}

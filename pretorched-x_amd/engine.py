@@ -1,0 +1,639 @@
+"""Forward-pass engine: compiles a zoo model + input shape into a list of libptx_amd launches.
+
+Design (MI355X-first, not a translation of the reference's nn.Module graphs):
+  * one *plan* per (input shape, device): every activation buffer is allocated once
+    (channels-last NDHWC fp32, sized for 288 GB of HBM -- no reuse games), every conv descriptor,
+    tile configuration and split-K factor is fixed at compile time, weights are BN-folded and
+    re-laid-out K-major once (`ptx_pack_conv_weight`) and only re-packed when a parameter changes;
+  * running a plan is a straight sequence of asynchronous C-ABI calls on torch's current HIP
+    stream -- no synchronisation, no allocation except the returned tensor -- so it can be
+    captured into a hipGraph (`Engine.capture`) and replayed;
+  * there is no eager / CPU fallback: CPU tensors, training mode or a missing library raise.
+
+torch is used for device memory (torch.empty), streams and parameter storage only.
+"""
+import ctypes as C
+import json
+import os
+import threading
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import (ConvDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
+                   PTX_PRO_RELU, PTX_EPI_ACCUM, PtxError, check)
+
+_TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+_tuned = None
+_tuned_lock = threading.Lock()
+
+
+def _tuned_table():
+    global _tuned
+    with _tuned_lock:
+        if _tuned is None:
+            _tuned = {}
+            if os.path.exists(_TUNED_PATH):
+                try:
+                    _tuned = {k: tuple(v) for k, v in json.load(open(_TUNED_PATH)).items()}
+                except Exception:
+                    _tuned = {}
+        return _tuned
+
+
+def save_tuned_table(path=_TUNED_PATH):
+    with _tuned_lock:
+        json.dump({k: list(v) for k, v in sorted((_tuned or {}).items())}, open(path, "w"), indent=0)
+
+
+def _r4(v):
+    return (v + 3) // 4 * 4
+
+
+def _r128(v):
+    return (v + 127) // 128 * 128
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _device_ctx(dev):
+    """torch.cuda.device(dev) for real devices; a no-op for the 'meta' device used by dry-run
+    plan compilation (host-logic tests without a GPU)."""
+    return torch.cuda.device(dev) if torch.device(dev).type == "cuda" else _NullCtx()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, offset_elems=0):
+    return C.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+def _geom(conv):
+    """(kernel, stride, padding) as (T,H,W) triples for Conv3d, or Conv2d seen as T == 1."""
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    if isinstance(conv, nn.Conv2d):
+        return (1,) + tuple(k), (1,) + tuple(s), (0,) + tuple(p)
+    return tuple(k), tuple(s), tuple(p)
+
+
+class Act:
+    """A channels-last activation: tensor [N,T,H,W,ld], C valid channels."""
+    __slots__ = ("t", "N", "T", "H", "W", "C", "ld")
+
+    def __init__(self, dev, N, T, H, W, C_, ld=None):
+        self.N, self.T, self.H, self.W, self.C = N, T, H, W, C_
+        self.ld = _r4(C_) if ld is None else ld
+        self.t = torch.empty((N, T, H, W, self.ld), device=dev, dtype=torch.float32)
+        if self.ld != C_ and self.t.device.type != "meta":
+            self.t.zero_()
+
+    @property
+    def S(self):
+        return self.T * self.H * self.W
+
+
+class Packed:
+    """BN-folded, K-major filter + bias living on one device; refreshable in place."""
+
+    def __init__(self, dev, convs, bn, fold_kw=False):
+        self.convs = list(convs)     # >1: concatenated along Co (non-local g/theta/phi)
+        self.bn = bn
+        c0 = self.convs[0]
+        (kT, kH, kW), _, _ = _geom(c0)
+        self.Co = sum(c.out_channels for c in self.convs)
+        self.Ci = c0.in_channels
+        self.fold_kw = bool(fold_kw)
+        keff = kW * self.Ci if fold_kw else self.Ci
+        self.Kc = _r4(keff)
+        if fold_kw:
+            self.Kc = max(self.Kc, 24) if keff <= 24 else self.Kc
+        self.Co_pad = _r128(self.Co)
+        self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
+        self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw))
+        n = _lib.lib().ptx_packed_weight_elems(C.byref(self.d))
+        self.w = torch.empty(n, device=dev, dtype=torch.float32)
+        self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
+
+    def refresh(self):
+        convs, bn = self.convs, self.bn
+        if len(convs) == 1:
+            w = convs[0].weight.detach()
+            cb = convs[0].bias.detach() if convs[0].bias is not None else None
+        else:
+            w = torch.cat([c.weight.detach() for c in convs], 0)
+            cb = torch.cat([c.bias.detach() for c in convs], 0) if convs[0].bias is not None else None
+        w = w.contiguous()
+        if w.dtype != torch.float32 or not w.is_cuda:
+            raise PtxError("weights must be fp32 CUDA tensors on the plan's device")
+        null = C.c_void_p(0)
+        args = [null] * 4
+        eps = 0.0
+        keep = [w, cb]
+        if bn is not None:
+            ts = [bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var]
+            ts = [t.contiguous() for t in ts]
+            keep += ts
+            args = [_ptr(t) for t in ts]
+            eps = float(bn.eps)
+        check(_lib.lib().ptx_pack_conv_weight(C.byref(self.d), _ptr(w), _ptr(cb) if cb is not None else null,
+                                              args[0], args[1], args[2], args[3], C.c_float(eps),
+                                              _ptr(self.w), _ptr(self.b), _stream()), "ptx_pack_conv_weight")
+        return keep
+
+
+class ConvStep:
+    """One ptx_conv3d_fwd launch with everything but the stream frozen."""
+    __slots__ = ("d", "x", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs")
+
+    def __call__(self, st):
+        p = self.plan
+        check(_lib.lib().ptx_conv3d_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
+                                        p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
+
+
+class Plan:
+    def __init__(self, engine, model, shape, dev):
+        self.dev = dev
+        self.shape = tuple(shape)
+        self.lib = _lib.lib()
+        self.steps = []          # callables(stream)
+        self.conv_steps = []
+        self.packs = []
+        self._pack_cache = {}
+        self.ws_bytes = 0
+        self.ws = None
+        self.ws_ptr = C.c_void_p(0)
+        self.in_ptr = C.c_void_p(0)      # set per run
+        self.keepalive = []
+        self.graph = None
+        with _device_ctx(dev):
+            self._build(model)
+            if self.ws_bytes:
+                self.ws = torch.empty(self.ws_bytes // 4, device=dev, dtype=torch.float32)
+                self.ws_ptr = _ptr(self.ws)
+
+    # ---------------------------------------------------------------- building blocks
+    def pack(self, convs, bn, fold_kw=False):
+        if not isinstance(convs, (list, tuple)):
+            convs = [convs]
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw)
+        if key not in self._pack_cache:
+            p = Packed(self.dev, convs, bn, fold_kw)
+            self._pack_cache[key] = p
+            self.packs.append(p)
+        return self._pack_cache[key]
+
+    def act(self, N, T, H, W, C_, ld=None):
+        a = Act(self.dev, N, T, H, W, C_, ld)
+        return a
+
+    def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
+             pro_relu=False, label="conv", y=None):
+        kT, kH, kW = pk.k_eff
+        sT, sH, sW = stride
+        pT, pH, pW = padding
+        To = (x.T + 2 * pT - kT) // sT + 1
+        Ho = (x.H + 2 * pH - kH) // sH + 1
+        Wo = (x.W + 2 * pW - kW) // sW + 1
+        if y is None:
+            y = self.act(x.N, To, Ho, Wo, pk.Co)
+        flags = (PTX_EPI_RELU if relu else 0) | (PTX_PRO_RELU if pro_relu else 0)
+        d = ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, y.ld
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
+        d.Kc, d.Co_pad = pk.Kc, pk.Co_pad
+        resptr = C.c_void_p(0)
+        if res is not None:
+            resptr = _ptr(res.t)
+            d.ldr = res.ld
+            if res_kind == "padA":
+                flags |= PTX_EPI_RES_PADA
+                d.res_C, d.res_T, d.res_H, d.res_W = res.C, res.T, res.H, res.W
+                d.res_sT = d.res_sH = d.res_sW = int(res_stride)
+            else:
+                flags |= PTX_EPI_RES_ADD
+                assert (res.N, res.T, res.H, res.W, res.C) == (y.N, y.T, y.H, y.W, y.C), "residual shape"
+        d.flags = flags
+        st = ConvStep()
+        st.d, st.x, st.w, st.b, st.res, st.y = d, _ptr(x.t), _ptr(pk.w), _ptr(pk.b), resptr, _ptr(y.t)
+        st.plan, st.label = self, label
+        st.macs = x.N * To * Ho * Wo * pk.Co * pk.Ci * pk.d.kT * pk.d.kH * pk.d.kW
+        key = json.dumps(d.key())
+        tuned = _tuned_table().get(key)
+        if tuned is not None:
+            st.cfg, st.split = int(tuned[0]), int(tuned[1])
+        else:
+            sk = C.c_int(1)
+            st.cfg = self.lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))
+            st.split = sk.value
+        # split-K workspace: room for the tuner's widest split on small problems, else the chosen one
+        out_bytes = 4 * x.N * To * Ho * Wo * y.ld
+        want = 8 if out_bytes * 8 <= (128 << 20) else st.split
+        self.ws_bytes = max(self.ws_bytes, int(self.lib.ptx_conv3d_workspace_bytes(C.byref(d), want)))
+        self.steps.append(st)
+        self.conv_steps.append(st)
+        return y
+
+    def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv"):
+        """nn.Conv{2,3}d or a (2+1)D pair, followed by `bn`, with the epilogue fused."""
+        if hasattr(conv, "spatial_conv"):      # r2plus1d.py:85-88
+            ks, ss, ps = _geom(conv.spatial_conv)
+            fold = _foldable(conv.spatial_conv, x)
+            mid = self.conv(x if not fold else self.fold_input(x, conv.spatial_conv),
+                            self.pack(conv.spatial_conv, conv.bn, fold),
+                            (ss[0], ss[1], 1) if fold else ss, (ps[0], ps[1], 0) if fold else ps,
+                            relu=True, label=label + ".spatial")
+            kt, st_, pt = _geom(conv.temporal_conv)
+            return self.conv(mid, self.pack(conv.temporal_conv, bn), st_, pt, relu=relu, res=res,
+                             res_kind=res_kind, res_stride=res_stride, label=label + ".temporal")
+        k, s, p = _geom(conv)
+        fold = _foldable(conv, x)
+        if fold:
+            x = self.fold_input(x, conv)
+            s, p = (s[0], s[1], 1), (p[0], p[1], 0)
+        return self.conv(x, self.pack(conv, bn, fold), s, p, relu=relu, res=res, res_kind=res_kind,
+                         res_stride=res_stride, label=label)
+
+    def fold_input(self, raw, conv):
+        """raw: RawInput (NCDHW user tensor).  Emits ptx_fold_kw_ncdhw."""
+        (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
+        Wo = (raw.W + 2 * pW - kW) // sW + 1
+        ld = max(_r4(kW * raw.C), 24) if kW * raw.C <= 24 else _r4(kW * raw.C)
+        y = self.act(raw.N, raw.T, raw.H, Wo, ld, ld)
+        lib, yp = self.lib, _ptr(y.t)
+        N, C_, T, H, W = raw.N, raw.C, raw.T, raw.H, raw.W
+
+        def step(st, self=self):
+            check(lib.ptx_fold_kw_ncdhw(self.in_ptr, yp, N, C_, T, H, W, kW, sW, pW, Wo, ld, st), "ptx_fold_kw_ncdhw")
+        self.steps.append(step)
+        return y
+
+    def to_channels_last(self, raw):
+        y = self.act(raw.N, raw.T, raw.H, raw.W, raw.C)
+        lib, yp = self.lib, _ptr(y.t)
+        N, C_, S, ld = raw.N, raw.C, raw.T * raw.H * raw.W, y.ld
+
+        def step(st, self=self):
+            check(lib.ptx_ncdhw_to_ndhwc(self.in_ptr, yp, N, C_, S, ld, st), "ptx_ncdhw_to_ndhwc")
+        self.steps.append(step)
+        return y
+
+    def maxpool(self, x, k, s, p):
+        To = (x.T + 2 * p[0] - k[0]) // s[0] + 1
+        Ho = (x.H + 2 * p[1] - k[1]) // s[1] + 1
+        Wo = (x.W + 2 * p[2] - k[2]) // s[2] + 1
+        y = self.act(x.N, To, Ho, Wo, x.C, x.ld)
+        d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.ld, To, Ho, Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+        lib, xp, yp = self.lib, _ptr(x.t), _ptr(y.t)
+        self.keepalive.append(d)
+
+        def step(st):
+            check(lib.ptx_maxpool3d_fwd(C.byref(d), xp, yp, st), "ptx_maxpool3d_fwd")
+        self.steps.append(step)
+        return y
+
+    def nonlocal_block(self, x, nl, label):
+        """Embedded-gaussian non-local block (nonlocalnet.py:143-166): fused g/theta/phi projection,
+        f = theta^T phi, row softmax, y = f g, W projection + BN + residual."""
+        if getattr(nl, "mode", "embedded_gaussian") != "embedded_gaussian":
+            raise PtxError("only the embedded_gaussian non-local mode is implemented on the HIP path")
+        lib = self.lib
+        ci = nl.g.out_channels
+        S = x.S
+        one = (1, 1, 1)
+        zero = (0, 0, 0)
+        tpg = self.conv(x, self.pack([nl.theta, nl.phi, nl.g], None), one, zero, label=label + ".theta_phi_g")
+        ldf = _r4(S)
+        f = torch.empty((x.N, S, ldf), device=self.dev, dtype=torch.float32)
+        gT = torch.empty((x.N, ci, ldf), device=self.dev, dtype=torch.float32)
+        yatt = self.act(x.N, x.T, x.H, x.W, ci)
+        self.keepalive += [f, gT]
+        N, ld3 = x.N, tpg.ld
+        th, ph, gp = _ptr(tpg.t, 0), _ptr(tpg.t, ci), _ptr(tpg.t, 2 * ci)
+        fp, gtp, yp = _ptr(f), _ptr(gT), _ptr(yatt.t)
+        yld = yatt.ld
+
+        def step(st):
+            check(lib.ptx_bgemm_nt(th, ph, fp, N, S, S, ci, ld3, ld3, ldf, S * ld3, S * ld3, S * ldf, st), "bgemm f")
+            check(lib.ptx_softmax_rows(fp, N * S, S, ldf, 0, st), "softmax")
+            check(lib.ptx_transpose_last2(gp, gtp, N, S, ci, ld3, ldf, st), "transpose g")
+            check(lib.ptx_bgemm_nt(fp, gtp, yp, N, S, ci, S, ldf, ldf, yld, S * ldf, ci * ldf, S * yld, st), "bgemm y")
+        self.steps.append(step)
+        return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
+
+    # ---------------------------------------------------------------- network
+    def _build(self, model):
+        arch = model.arch
+        shp = self.shape
+        if arch.dims == 2:
+            N, Cin, H, W = shp
+            T = 1
+        else:
+            N, Cin, T, H, W = shp
+        raw = RawInput(N, Cin, T, H, W)
+        x = self.conv_bn(raw, model.conv1, model.bn1, relu=True, label="conv1")
+        if arch.dims == 2:
+            x = self.maxpool(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        else:
+            x = self.maxpool(x, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        for li in range(4):
+            for bi, blk in enumerate(getattr(model, "layer%d" % (li + 1))):
+                x = self._block(arch, blk, x, "layer%d.%d" % (li + 1, bi))
+        self.feat = x
+        # head buffers
+        self.pooled = torch.empty((x.N, x.C), device=self.dev, dtype=torch.float32)
+
+    def _block(self, arch, blk, x, name):
+        s = blk.stride
+        if blk.has_shortcut and arch.shortcut == "B":
+            res = self.conv_bn(x, blk.downsample[0], blk.downsample[1], label=name + ".downsample")
+            kind = None
+        elif blk.has_shortcut:
+            res, kind = x, "padA"
+        else:
+            res, kind = x, None
+        if arch.block == "bottleneck":
+            o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
+            o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
+            o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
+                             label=name + ".conv3")
+        else:
+            o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
+            o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, res=res, res_kind=kind, res_stride=s,
+                             label=name + ".conv2")
+        if blk.has_nl:
+            o = self.nonlocal_block(o, blk.nonlocalblock, name + ".nonlocalblock")
+        return o
+
+    # ---------------------------------------------------------------- running
+    def refresh_weights(self):
+        keep = []
+        for p in self.packs:
+            keep.append(p.refresh())
+        return keep
+
+    def run_features(self, x):
+        self.in_ptr = _ptr(x)
+        st = _stream()
+        for s in self.steps:
+            s(st)
+        return self.feat
+
+
+class RawInput:
+    """Shape of the user's NCDHW (or NCHW, T == 1) input; its pointer is bound at run time."""
+    __slots__ = ("N", "C", "T", "H", "W")
+
+    def __init__(self, N, C_, T, H, W):
+        self.N, self.C, self.T, self.H, self.W = N, C_, T, H, W
+
+
+def _foldable(conv, x):
+    """Small-Cin first conv reading the raw NCDHW input: fold kW into the channel axis."""
+    return isinstance(x, RawInput)
+
+
+class Engine:
+    """Per-model executor.  Stateless w.r.t. the model object (DataParallel replicas share it),
+    caches keyed by device."""
+
+    def __init__(self, model=None):
+        self._plans = {}
+        self._lock = threading.RLock()
+        self._sig = {}
+        self.check_weights = True
+
+    def __deepcopy__(self, memo):
+        return Engine()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, s):
+        self.__init__()
+
+    def invalidate(self):
+        with self._lock:
+            self._plans.clear()
+            self._sig.clear()
+
+    def dry_plan(self, model, shape):
+        """Compile a plan on the 'meta' device: every descriptor, tile choice and buffer shape is
+        produced, nothing is allocated or launched.  Host-logic tests use this without a GPU."""
+        return Plan(self, model, shape, torch.device("meta"))
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _validate(model, x, dims):
+        if model.training:
+            raise PtxError("pretorched-x_amd is a forward-only (inference) engine: call model.eval() first; "
+                           "there is no training-mode / autograd path")
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise PtxError("input must be a CUDA (ROCm) tensor -- there is no CPU fallback in this package")
+        if x.dtype != torch.float32:
+            raise PtxError("input must be float32 (got %s)" % x.dtype)
+        want = 4 if dims == 2 else 5
+        if x.dim() != want:
+            raise PtxError("expected a %d-D input, got shape %s" % (want, tuple(x.shape)))
+        p = next(model.parameters())
+        if p.device != x.device:
+            raise PtxError("input on %s but parameters on %s" % (x.device, p.device))
+
+    @staticmethod
+    def _signature(model):
+        return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+
+    def plan_for(self, model, x):
+        key = (tuple(x.shape), x.device.index, id(model))
+        with self._lock:
+            plan = self._plans.get(key)
+            fresh = plan is None
+            if fresh:
+                plan = Plan(self, model, x.shape, x.device)
+                self._plans[key] = plan
+            if fresh or self.check_weights:
+                sig = self._signature(model)
+                if fresh or self._sig.get(key) != sig:
+                    with torch.cuda.device(x.device):
+                        plan.refresh_weights()
+                    self._sig[key] = sig
+            return plan
+
+    # ------------------------------------------------------------------------------------
+    def features(self, model, x):
+        """NCDHW in -> NCDHW feature map out (contiguous), like the reference's `features`."""
+        self._validate(model, x, model.arch.dims)
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(model, x)
+            f = plan.run_features(x)
+            if model.arch.dims == 2:
+                out = torch.empty((f.N, f.C, f.H, f.W), device=x.device, dtype=torch.float32)
+            else:
+                out = torch.empty((f.N, f.C, f.T, f.H, f.W), device=x.device, dtype=torch.float32)
+            check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), f.N, f.C, f.S, f.ld, _stream()),
+                  "ptx_ndhwc_to_ncdhw")
+        return out
+
+    def _head(self, model, pooled_ptr, N, Cf, dev):
+        head = model.head_module
+        pooled = None
+        if isinstance(head, nn.Linear) and head.weight.is_cuda and head.weight.dtype == torch.float32:
+            out = torch.empty((N, head.out_features), device=dev, dtype=torch.float32)
+            w = head.weight.detach().contiguous()
+            b = head.bias.detach().contiguous() if head.bias is not None else None
+            check(_lib.lib().ptx_linear_fwd(pooled_ptr, _ptr(w), _ptr(b) if b is not None else C.c_void_p(0),
+                                            _ptr(out), N, Cf, head.out_features, Cf, head.out_features, 0,
+                                            _stream()), "ptx_linear_fwd")
+            return out
+        return None
+
+    def logits(self, model, feats):
+        """NCDHW feature map -> [N, classes]: global average pool + `last_linear` read at call time
+        (users replace it with another Linear or an Identity, reference README "last_linear")."""
+        self._validate(model, feats, model.arch.dims)
+        feats = feats.contiguous()
+        N, Cf = feats.shape[0], feats.shape[1]
+        S = feats.numel() // (N * Cf)
+        with torch.cuda.device(feats.device):
+            pooled = torch.empty((N, Cf), device=feats.device, dtype=torch.float32)
+            check(_lib.lib().ptx_global_avgpool(_ptr(feats), _ptr(pooled), N, Cf, S, Cf, 1, _stream()),
+                  "ptx_global_avgpool")
+            out = self._head(model, _ptr(pooled), N, Cf, feats.device)
+            if out is None:     # user-supplied head module (Identity, custom nn.Module): theirs to run
+                out = model.head_module(pooled)
+        return out
+
+    def forward(self, model, x):
+        """features -> logits without leaving channels-last."""
+        self._validate(model, x, model.arch.dims)
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(model, x)
+            f = plan.run_features(x)
+            check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
+                  "ptx_global_avgpool")
+            out = self._head(model, _ptr(plan.pooled), f.N, f.C, x.device)
+            if out is None:
+                out = model.head_module(plan.pooled.clone())
+        return out
+
+    # ------------------------------------------------------------------------------------
+    def autotune(self, model, x, iters=3, verbose=False, persist=False):
+        """Time every compiled tile configuration (x a few split-K factors) for each distinct conv
+        problem of the plan with HIP events and keep the fastest."""
+        self._validate(model, x, model.arch.dims)
+        lib = _lib.lib()
+        table = _tuned_table()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(model, x.contiguous())
+            plan.run_features(x.contiguous())      # make every buffer hold sane data
+            ncfg = lib.ptx_conv3d_num_configs()
+            seen = {}
+            for stp in plan.conv_steps:
+                key = json.dumps(stp.d.key())
+                if key in seen:
+                    stp.cfg, stp.split = seen[key]
+                    continue
+                best = None
+                steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
+                M = stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo
+                for cfg in range(ncfg):
+                    name = lib.ptx_conv3d_config_name(cfg).decode()
+                    bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
+                    if stp.d.Kc % 32 == 0:
+                        if bk != 32:
+                            continue
+                    elif stp.d.Kc % 24 == 0:
+                        if bk != 24:
+                            continue
+                    elif bk == 24:
+                        continue
+                    if bn_ > 64 and stp.d.ldy <= 64:
+                        continue
+                    blocks = ((M + bm - 1) // bm) * ((stp.d.ldy + bn_ - 1) // bn_)
+                    splits = [1]
+                    if blocks < 512:
+                        splits += [s for s in (2, 3, 4, 6, 8) if steps_k // s >= 4 and blocks * s <= 2048]
+                    for sk in splits:
+                        if sk > 1 and lib.ptx_conv3d_workspace_bytes(C.byref(stp.d), sk) > plan.ws_bytes:
+                            continue
+                        stp.cfg, stp.split = cfg, sk
+                        try:
+                            stp(_stream())      # warm-up + validity
+                        except PtxError:
+                            continue
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(iters):
+                            stp(_stream())
+                        e1.record()
+                        e1.synchronize()
+                        ms = e0.elapsed_time(e1) / iters
+                        if best is None or ms < best[0]:
+                            best = (ms, cfg, sk)
+                stp.cfg, stp.split = best[1], best[2]
+                seen[key] = (best[1], best[2])
+                table[key] = (best[1], best[2])
+                if verbose:
+                    print("tune %-34s M=%-8d N=%-5d K=%-6d -> %-20s split=%d  %.3f ms  %.1f TF" % (
+                        stp.label, M, stp.d.Co, stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW,
+                        lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
+                        2e-9 * stp.macs / best[0]))
+            plan.run_features(x.contiguous())
+        if persist:
+            save_tuned_table()
+        return plan
+
+    def profile_convs(self, model, x, iters=5):
+        """Per-conv-launch timing with HIP events on the current stream (for bench.py's roofline)."""
+        self._validate(model, x, model.arch.dims)
+        rows = []
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(model, x.contiguous())
+            plan.run_features(x.contiguous())
+            for stp in plan.conv_steps:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                stp(_stream())
+                e0.record()
+                for _ in range(iters):
+                    stp(_stream())
+                e1.record()
+                e1.synchronize()
+                rows.append((stp.label, stp.macs, e0.elapsed_time(e1) / iters,
+                             _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp.split))
+        return rows
+
+
+# ---------------------------------------------------------------------------------------------
+# TRN relation MLP (trn.py:39-45): ReLU -> Linear -> ReLU -> Linear
+# ---------------------------------------------------------------------------------------------
+def relation_mlp(flat, lin1, lin2, out=None, accumulate=False):
+    if not flat.is_cuda or flat.dtype != torch.float32:
+        raise PtxError("relation_mlp: input must be a float32 CUDA tensor (no CPU fallback)")
+    flat = flat.contiguous()
+    M, K = flat.shape
+    lib = _lib.lib()
+    with torch.cuda.device(flat.device):
+        hid = torch.empty((M, lin1.out_features), device=flat.device, dtype=torch.float32)
+        res = out if out is not None else torch.empty((M, lin2.out_features), device=flat.device,
+                                                      dtype=torch.float32)
+        w1, b1 = lin1.weight.detach().contiguous(), lin1.bias.detach().contiguous()
+        w2, b2 = lin2.weight.detach().contiguous(), lin2.bias.detach().contiguous()
+        # ReLU(in) -> Linear -> ReLU fused into launch 1; Linear into launch 2
+        check(lib.ptx_linear_fwd(_ptr(flat), _ptr(w1), _ptr(b1), _ptr(hid), M, K, lin1.out_features, K,
+                                 lin1.out_features, PTX_PRO_RELU | PTX_EPI_RELU, _stream()), "relation.linear1")
+        check(lib.ptx_linear_fwd(_ptr(hid), _ptr(w2), _ptr(b2), _ptr(res), M, lin1.out_features,
+                                 lin2.out_features, lin1.out_features, lin2.out_features,
+                                 PTX_EPI_ACCUM if accumulate else 0, _stream()), "relation.linear2")
+    return res

@@ -1,0 +1,75 @@
+"""Deterministic synthetic weights and inputs (there is no network for checkpoints/datasets).
+
+The recipe is the calibrated one of SURVEY.md section 8(d): default-initialised BatchNorms are the
+identity and the non-local block's output BN is all-zero (reference nonlocalnet.py:95-96), so a
+parity check on default-init weights would be vacuous for BN folding and for the whole NL branch.
+Every tensor is drawn from its own CPU generator seeded by (seed, crc32(key)), so the values
+depend only on the state_dict key and shape -- not on module construction order -- and the same
+function feeds the reference model (golden generation), the oracle and the HIP engine.
+"""
+import zlib
+from collections import OrderedDict
+
+import torch
+
+# gamma of the BN that closes a residual branch is damped so that logits stay O(10) deep into
+# the network (factor 0.8 -> max|logit| ~ 26 for resnet3d50).
+LAST_BN_DAMP = 0.8
+
+
+def _gen(seed, key):
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+    return g
+
+
+def _is_closing_bn(prefix, keys):
+    if prefix.endswith(".bn3") or prefix.endswith("downsample.1") or prefix.endswith(".W.1"):
+        return True
+    if prefix.endswith(".bn2"):
+        parent = prefix.rsplit(".", 1)[0]
+        return (parent + ".bn3.weight") not in keys
+    return False
+
+
+def synth_state_dict(template, seed=1234):
+    """template: mapping key -> tensor (only shape/dtype are used). Returns an OrderedDict of
+    fresh CPU fp32 tensors with the same keys/shapes."""
+    keys = set(template.keys())
+    out = OrderedDict()
+    for key, ref in template.items():
+        shape = tuple(ref.shape)
+        g = _gen(seed, key)
+        prefix, _, leaf = key.rpartition(".")
+        is_bn = (prefix + ".running_mean") in keys
+        if leaf == "num_batches_tracked":
+            out[key] = torch.zeros(shape, dtype=torch.long)
+        elif is_bn and leaf == "weight":
+            v = torch.rand(shape, generator=g) + 0.5
+            out[key] = v * LAST_BN_DAMP if _is_closing_bn(prefix, keys) else v
+        elif is_bn and leaf == "bias":
+            out[key] = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "running_mean":
+            out[key] = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "running_var":
+            out[key] = torch.rand(shape, generator=g) + 0.5
+        elif leaf == "weight" and len(shape) >= 3:          # conv: kaiming-normal, fan_out
+            fan_out = shape[0]
+            for k in shape[2:]:
+                fan_out *= k
+            out[key] = torch.randn(shape, generator=g) * (2.0 / fan_out) ** 0.5
+        elif leaf == "weight" and len(shape) == 2:          # linear
+            bound = 1.0 / shape[1] ** 0.5
+            out[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif leaf == "bias":                                # conv / linear bias
+            out[key] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+        else:
+            raise KeyError("synth_state_dict: unclassified key %r" % key)
+    return out
+
+
+def synth_clips(batch, frames, size, seed=99, channels=3):
+    """Synthetic normalised video clips, NCDHW fp32, from a seeded CPU generator."""
+    g = torch.Generator()
+    g.manual_seed(int(seed))
+    return torch.randn(batch, channels, frames, size, size, generator=g)

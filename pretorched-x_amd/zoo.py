@@ -1,0 +1,267 @@
+"""Model zoo: parameter trees with the reference's weight ABI, executed by the HIP engine.
+
+Each network is described by an `Arch` row and materialised as an `nn.Module` tree whose
+`state_dict()` keys, shapes and order are exactly the reference's (SURVEY.md 8b "Weight ABI"):
+`conv1.weight`, `bn1.*`, `layer{1-4}.{i}.conv{1,2,3}.weight`, `...bn{1,2,3}.*`,
+`...downsample.{0,1}.*`, `last_linear.*` (`fc.*` for R2Plus1D), `...nonlocalblock.{g,theta,phi}.*`,
+`...nonlocalblock.W.{0,1}.*`, `....spatial_conv/bn/temporal_conv.*` -- so reference checkpoints
+load unchanged.  torch.nn layers are used purely as parameter containers; no torch op computes
+anything on the forward path: `features` / `logits` / `forward` run hand-written gfx950 kernels
+through `engine.Engine` and raise if that is impossible (CPU tensors, training mode).
+
+Reference behaviour mirrored here (file:line in /root/reference/pretorched/models):
+  resnet3D.py:146-218, :242-318 (ResNet3D family + factories), torchvision_models.py:443-492
+  (features/logits/forward split, `last_linear`, 2-D resnet18), nonlocalnet.py:423-561
+  (NonLocalResNet3D, `num_classes` ignored by `nonlocalresnet3d50`, F8), r2plus1d.py:29-152.
+Unlike the reference, methods live on the class of the model itself -- nothing is monkey-patched
+onto a shared class.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+
+
+@dataclass(frozen=True)
+class Arch:
+    block: str                       # 'basic' | 'bottleneck'
+    layers: Sequence[int]
+    shortcut: str = "B"
+    conv: str = "3d"                 # '3d' | '2p1d'
+    nonlocal_layers: Optional[Sequence[int]] = None
+    head: str = "last_linear"
+    dims: int = 3
+
+    @property
+    def expansion(self):
+        return 4 if self.block == "bottleneck" else 1
+
+
+ARCHS = {
+    "resnet3d10": Arch("basic", (1, 1, 1, 1), "B"),
+    "resnet3d18": Arch("basic", (2, 2, 2, 2), "A"),
+    "resnet3d34": Arch("basic", (3, 4, 6, 3), "A"),
+    "resnet3d50": Arch("bottleneck", (3, 4, 6, 3), "B"),
+    "resneti3d50": Arch("bottleneck", (3, 4, 6, 3), "B"),
+    "resnet3d101": Arch("bottleneck", (3, 4, 23, 3), "B"),
+    "resnet3d152": Arch("bottleneck", (3, 8, 36, 3), "B"),
+    "resnet3d200": Arch("bottleneck", (3, 24, 36, 3), "B"),
+    "nonlocalresnet3d50": Arch("bottleneck", (3, 4, 6, 3), "A", nonlocal_layers=(0, 2, 3, 0)),
+    "r2plus1d10": Arch("basic", (1, 1, 1, 1), "B", conv="2p1d", head="fc"),
+    "r2plus1d18": Arch("basic", (2, 2, 2, 2), "B", conv="2p1d", head="fc"),
+    "r2plus1d34": Arch("basic", (3, 4, 6, 3), "B", conv="2p1d", head="fc"),
+    "r2plus1d50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="2p1d", head="fc"),
+    "nonlocal_r2plus1d50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="2p1d", nonlocal_layers=(0, 2, 3, 0)),
+    "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
+}
+
+
+class Bag(nn.Module):
+    """A named group of parameter-holding children; never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("Bag is a parameter container; the HIP engine executes the network")
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+def factored_mid_channels(cin, cout, k):
+    """Intermediate width of a (2+1)D pair (reference r2plus1d.py:68-69)."""
+    kt, kh, kw = _triple(k)
+    return int(math.floor((kt * kh * kw * cin * cout) / (kh * kw * cin + kt * cout)))
+
+
+def _conv(arch, cin, cout, k, stride=1, padding=0, bias=False):
+    if arch.dims == 2:
+        return nn.Conv2d(cin, cout, k, stride, padding, bias=bias)
+    if arch.conv == "2p1d":
+        (kt, kh, kw), (st, sh, sw), (pt, ph, pw) = _triple(k), _triple(stride), _triple(padding)
+        mid = factored_mid_channels(cin, cout, k)
+        pair = Bag()
+        pair.spatial_conv = nn.Conv3d(cin, mid, (1, kh, kw), (1, sh, sw), (0, ph, pw), bias=bias)
+        pair.bn = nn.BatchNorm3d(mid)
+        pair.temporal_conv = nn.Conv3d(mid, cout, (kt, 1, 1), (st, 1, 1), (pt, 0, 0), bias=bias)
+        return pair
+    return nn.Conv3d(cin, cout, k, stride, padding, bias=bias)
+
+
+def _bn(arch, c):
+    return nn.BatchNorm2d(c) if arch.dims == 2 else nn.BatchNorm3d(c)
+
+
+def _nonlocal(channels):
+    inter = max(channels // 2, 1)
+    nl = Bag()
+    nl.g = nn.Conv3d(channels, inter, 1)
+    nl.W = nn.ModuleList([nn.Conv3d(inter, channels, 1), nn.BatchNorm3d(channels)])
+    nl.theta = nn.Conv3d(channels, inter, 1)
+    nl.phi = nn.Conv3d(channels, inter, 1)
+    nl.mode = "embedded_gaussian"
+    return nl
+
+
+def _block(arch, cin, planes, stride, with_down, with_nl):
+    blk = Bag()
+    if arch.block == "bottleneck":
+        blk.conv1 = _conv(arch, cin, planes, 1)
+        blk.bn1 = _bn(arch, planes)
+        blk.conv2 = _conv(arch, planes, planes, 3, stride, 1)
+        blk.bn2 = _bn(arch, planes)
+        blk.conv3 = _conv(arch, planes, planes * 4, 1)
+        blk.bn3 = _bn(arch, planes * 4)
+    else:
+        blk.conv1 = _conv(arch, cin, planes, 3, stride, 1)
+        blk.bn1 = _bn(arch, planes)
+        blk.conv2 = _conv(arch, planes, planes, 3, 1, 1)
+        blk.bn2 = _bn(arch, planes)
+    cout = planes * arch.expansion
+    blk.downsample = None
+    if with_down and arch.shortcut == "B":
+        blk.downsample = nn.ModuleList([_conv(arch, cin, cout, 1, stride), _bn(arch, cout)])
+    blk.stride = stride
+    blk.has_shortcut = with_down
+    if with_nl:
+        blk.nonlocalblock = _nonlocal(cout)
+    blk.has_nl = with_nl
+    return blk
+
+
+def nl_placement(blocks, nonlocal_blocks):
+    freq = blocks // nonlocal_blocks if nonlocal_blocks != 0 else -1
+    return [(i % freq == 0 and freq > 0) for i in range(blocks)]
+
+
+class VideoResNet(nn.Module):
+    """ResNet3D / R2Plus1D / NonLocalResNet3D / 2-D ResNet, one class, table driven."""
+
+    def __init__(self, arch_name, num_classes):
+        super().__init__()
+        arch = ARCHS[arch_name]
+        self.arch_name = arch_name
+        self.arch = arch
+        if arch.dims == 2:
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        else:
+            self.conv1 = _conv(arch, 3, 64, 7, (1, 2, 2), (3, 3, 3))
+        self.bn1 = _bn(arch, 64)
+        # parameterless members of the reference trees, kept for structural familiarity only
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = (nn.MaxPool2d(3, 2, 1) if arch.dims == 2 else nn.MaxPool3d(3, 2, 1))
+        cin = 64
+        for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), arch.layers)):
+            stride = 1 if li == 0 else 2
+            nl = nl_placement(nblocks, arch.nonlocal_layers[li]) if arch.nonlocal_layers else [False] * nblocks
+            blocks = []
+            for bi in range(nblocks):
+                first = bi == 0
+                down = first and (stride != 1 or cin != planes * arch.expansion)
+                blocks.append(_block(arch, cin, planes, stride if first else 1, down, nl[bi]))
+                if first:
+                    cin = planes * arch.expansion
+            setattr(self, "layer%d" % (li + 1), nn.ModuleList(blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d(1) if arch.dims == 2 else nn.AdaptiveAvgPool3d(1)
+        if arch.head == "fc":
+            self.fc = nn.Linear(512 * arch.expansion, num_classes)
+        else:
+            self.fc = None                       # the reference sets fc=None after the rename
+            self.last_linear = nn.Linear(512 * arch.expansion, num_classes)
+        self._init_like_reference()
+        self.eval()
+        self._engine = Engine()
+
+    # -- initialisation with the reference's distributions (resnet3D.py:195-201, r2plus1d.py:103) --
+    def _init_like_reference(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv3d, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm2d)):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    @property
+    def head_module(self):
+        return self.fc if self.arch.head == "fc" else self.last_linear
+
+    # -- the reference Model API (README "Model API"; torchvision_models.py:448-469) --
+    def features(self, input):
+        return self._engine.features(self, input)
+
+    def logits(self, features):
+        return self._engine.logits(self, features)
+
+    def forward(self, input):
+        return self._engine.forward(self, input)
+
+    def engine(self):
+        return self._engine
+
+    # nn.Module plumbing that must invalidate packed weights
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._engine.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if "_engine" in self.__dict__:
+            self._engine.invalidate()
+        return r
+
+
+# ---------------------------------------------------------------------------------------------
+# TRN relation heads (reference trn.py:20-113): standalone modules, HIP-executed MLPs
+# ---------------------------------------------------------------------------------------------
+class Relation(nn.Module):
+    """input[..., num_inputs, in_features] -> output[B, -1, out_features]  (trn.py:20-56)."""
+
+    def __init__(self, num_inputs, in_features, out_features, bottleneck_dim=512):
+        super().__init__()
+        self.num_inputs, self.in_features = num_inputs, in_features
+        self.out_features, self.bottleneck_dim = out_features, bottleneck_dim
+        self.relate = nn.Sequential(nn.ReLU(), nn.Linear(num_inputs * in_features, bottleneck_dim),
+                                    nn.ReLU(), nn.Linear(bottleneck_dim, out_features))
+        self.eval()
+
+    def forward(self, input):
+        from .engine import relation_mlp
+        flat = input.contiguous().view(-1, self.num_inputs * self.in_features)
+        out = relation_mlp(flat, self.relate[1], self.relate[3])
+        return out.view(input.size(0), -1, self.out_features)
+
+
+class MultiScaleRelation(nn.Module):
+    """Sum of k-frame relations for k = n..2 over randomly drawn frame subsets (trn.py:59-113).
+    Subset sampling stays on the host and consumes numpy's global RNG exactly as the reference
+    does (one `np.random.choice` per scale, in scale order); only the MLPs run on the GPU."""
+
+    def __init__(self, num_input, in_features, out_features, bottleneck_dim=512, num_relations=3):
+        super().__init__()
+        import itertools
+        self.num_input, self.in_features, self.out_features = num_input, in_features, out_features
+        self.num_relations, self.bottleneck_dim = num_relations, bottleneck_dim
+        self.scales = list(range(num_input, 1, -1))
+        self.relations_scales = [list(itertools.combinations(range(num_input), s)) for s in self.scales]
+        self.subsample_scales = [min(num_relations, len(r)) for r in self.relations_scales]
+        self.relations = nn.ModuleList([Relation(s, in_features, out_features, bottleneck_dim)
+                                        for s in self.scales])
+        self.eval()
+
+    def forward(self, input):
+        import numpy as np
+        from .engine import relation_mlp
+        total = None
+        for si in range(len(self.scales)):
+            rel = self.relations[si]
+            picks = np.random.choice(len(self.relations_scales[si]), self.subsample_scales[si], replace=False)
+            for idx in picks:
+                sub = input[..., self.relations_scales[si][idx], :]          # frame gather: plumbing
+                flat = sub.contiguous().view(-1, rel.num_inputs * rel.in_features)
+                # the sum over relations (trn.py:110) is fused into the second Linear's epilogue
+                total = relation_mlp(flat, rel.relate[1], rel.relate[3], out=total, accumulate=total is not None)
+        return total.view(input.size(0), -1, self.out_features)
