@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): resnet3d50 (Moments-339) forward, 8x3x16x224x224 synthetic
+clips per GPU, clips/sec + max|dlogits| vs the CPU path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; a step = one forward of this rank's 8 clips (inputs resident in HBM) plus,
+for N > 1, the single all-gather of logits (RCCL).  Weak scaling: 8 clips per GPU.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIPS_PER_GPU, FRAMES, SIZE, CLASSES = 8, 16, 224, 339
+GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, padding taps counted
+PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import pretorched_x_amd as ptx
+    from pretorched_x_amd.parallel import gather_logits
+    from pretorched_x_amd.testing import synth_clips, synth_state_dict
+
+    model = ptx.__dict__["resnet3d50"](num_classes=CLASSES, pretrained=None)
+    sd = synth_state_dict(model.state_dict(), 1234)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    model.engine().check_weights = True
+    x_cpu = synth_clips(CLIPS_PER_GPU, FRAMES, SIZE, 99 + rank)       # per-rank clips
+    x = x_cpu.to(dev)
+
+    eng = model.engine()
+    if not args.no_autotune:
+        eng.autotune(model, x, iters=2, verbose=args.verbose and rank == 0)
+
+    def step():
+        out = model(x)
+        if world > 1:
+            out = gather_logits(out, total=CLIPS_PER_GPU * world)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    clips_per_s = CLIPS_PER_GPU * world * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel roofline: every conv launch timed with HIP events on the launch stream ----
+        rows = eng.profile_convs(model, x, iters=5)
+        by_kernel = {}
+        for label, macs, ms, cfg, split in rows:
+            k = by_kernel.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
+            k["ms"] += ms
+            k["flop"] += 2.0 * macs
+            k["launches"] += 1
+        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in by_kernel.values())
+        roofline = {
+            "bound": "mfma", "kernel": "conv_igemm_kernel<%s>" % dom_name,
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": None,
+            "launches_per_step": dom["launches"],
+            "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+            "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
+        }
+        net_tf = GFLOP_PER_CLIP * 1e9 * clips_per_s / world / 1e12
+        roofline_net = {"bound": "mfma", "achieved": round(net_tf, 2), "peak": PEAK_F32_MFMA_TF,
+                        "unit": "TFLOP/s", "frac": round(net_tf / PEAK_F32_MFMA_TF, 4),
+                        "conv_ms_sum": round(conv_ms, 3),
+                        "per_kernel": {k: {"ms": round(v["ms"], 3), "tflops": round(v["flop"] / v["ms"] / 1e9, 1),
+                                           "launches": v["launches"]} for k, v in sorted(by_kernel.items())}}
+
+        # ---- CPU baseline: the oracle restatement of the reference path on this box's host cores ----
+        cpu = None
+        parity = None
+        if not args.no_cpu_baseline:
+            from oracle import functional as OF
+            torch.set_num_threads(os.cpu_count() or 1)
+            cfg = OF.ARCHS["resnet3d50"]
+            want = OF.forward(cfg, sd, x_cpu)                 # warm-up + parity reference
+            times = []
+            budget = time.perf_counter() + 30.0
+            while len(times) < 3 and (not times or time.perf_counter() < budget):
+                t1 = time.perf_counter()
+                OF.forward(cfg, sd, x_cpu)
+                times.append(time.perf_counter() - t1)
+            med = sorted(times)[len(times) // 2]
+            cpu = {"value": round(CLIPS_PER_GPU / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(),
+                   "kind": "port", "sample": "%d timed forwards of the full 8x3x16x224x224 batch (median), "
+                   "oracle/functional.py on %d host threads" % (len(times), torch.get_num_threads())}
+            got = model(x).cpu()
+            parity = {"max_abs_dlogits": float((got - want).abs().max().item()),
+                      "max_abs_logit": float(want.abs().max().item()),
+                      "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))), "tolerance": 1e-3}
+
+        result = {
+            "metric": "clips/sec, resnet3d50 forward 8x3x16x224x224 per GPU (+ max|dlogits| vs CPU)",
+            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
+                                   "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE),
+                       "clips_per_gpu": CLIPS_PER_GPU, "global_batch": CLIPS_PER_GPU * world,
+                       "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
+            "roofline": roofline, "roofline_net": roofline_net, "cpu_baseline": cpu, "parity": parity,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

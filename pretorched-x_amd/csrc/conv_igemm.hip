@@ -19,6 +19,7 @@
 // the logical one -- harmless because A and B use the same permutation.
 // fp32 in, fp32 accumulate, bit-exact k-ordered fma chain (cdna_hip_programming.md section 3).
 #include "ptx_common.h"
+#include <algorithm>
 
 namespace ptx {
 
@@ -118,8 +119,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const float* __restrict__ wg = p.w + (size_t)zb * p.bs_w;
 
     // ---- per-thread A rows: output position -> top-left input coordinate (tap independent) ----
-    int a_n[A_IT], a_t0[A_IT], a_h0[A_IT], a_w0[A_IT];
-    bool a_ok[A_IT];
+    // a_pos = linear input position of the window origin; rows outside M get a_t0 = "minus infinity"
+    // so that every tap fails the bounds test.
+    int a_pos[A_IT], a_t0[A_IT], a_h0[A_IT], a_w0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + 256 * i;
@@ -132,11 +134,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         const int ho = t % p.Ho;
         t /= p.Ho;
         const int to = t % p.To;
-        a_ok[i] = ok;
-        a_n[i] = t / p.To;
-        a_t0[i] = to * p.sT - p.pT;
+        const int n = t / p.To;
+        a_t0[i] = ok ? to * p.sT - p.pT : -0x40000000;
         a_h0[i] = ho * p.sH - p.pH;
         a_w0[i] = wo * p.sW - p.pW;
+        a_pos[i] = ((n * p.Ti + (to * p.sT - p.pT)) * p.Hi + a_h0[i]) * p.Wi + a_w0[i];
     }
 
     // ---- block-uniform tap pruning: taps that only ever see zero padding are skipped ----
@@ -156,44 +158,62 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             }
         }
     }
-    const int khw = p.kH * p.kW;
+    // k-steps are numbered tap-major, channel-chunk-minor: s = ((kt*kH + kh)*kW + kw)*kchunks + ch.
+    // (kt, kh, kw, ch) is the next k-step to LOAD; it is advanced incrementally (no divisions in
+    // the loop) and `have` says whether it still lies inside this split's [s_begin, s_end).
     const int s_end = min(p.steps_total, (zs + 1) * p.steps_per_split);
-    // first valid k-step at or after s (k-steps are numbered tap-major, channel-chunk-minor)
-    auto next_valid = [&](int s) -> int {
-        while (s < s_end) {
-            const int tap = s / p.kchunks;
-            const int kt = tap / khw;
-            const int kh = (tap - kt * khw) / p.kW;
-            if (kt < kt_lo) { s = kt_lo * khw * p.kchunks; continue; }
-            if (kt > kt_hi) { s = s_end; break; }
-            if (kh < kh_lo) { s = (kt * khw + kh_lo * p.kW) * p.kchunks; continue; }
-            if (kh > kh_hi) { s = (kt + 1) * khw * p.kchunks; continue; }
+    int kt, kh, kw, ch;
+    bool have;
+    {
+        const int s0 = zs * p.steps_per_split;
+        const int tap = s0 / p.kchunks;
+        ch = s0 - tap * p.kchunks;
+        const int khw = p.kH * p.kW;
+        kt = tap / khw;
+        const int rem = tap - kt * khw;
+        kh = rem / p.kW;
+        kw = rem - kh * p.kW;
+    }
+    auto normalize = [&]() {
+        while (true) {
+            if (kt < kt_lo) { kt = kt_lo; kh = 0; kw = 0; ch = 0; }
+            if (kt > kt_hi) { have = false; return; }
+            if (kh < kh_lo) { kh = kh_lo; kw = 0; ch = 0; }
+            if (kh > kh_hi) { ++kt; kh = 0; kw = 0; ch = 0; continue; }
             break;
         }
-        return s;
+        have = (((kt * p.kH + kh) * p.kW + kw) * p.kchunks + ch) < s_end;
     };
+    auto advance = [&]() {
+        if (++ch == p.kchunks) {
+            ch = 0;
+            if (++kw == p.kW) {
+                kw = 0;
+                if (++kh == p.kH) { kh = 0; ++kt; }
+            }
+        }
+        normalize();
+    };
+    normalize();
 
     f32x4 ra[A_IT], rb[B_IT];
     const bool pro_relu = (p.flags & PTX_PRO_RELU) != 0;
 
-    auto load_tiles = [&](int s) {
-        const int tap = s / p.kchunks;
-        const int c0 = (s - tap * p.kchunks) * BK;
-        const int kt = tap / khw;
-        const int rem = tap - kt * khw;
-        const int kh = rem / p.kW;
-        const int kw = rem - kh * p.kW;
+    // issue the global loads of k-step (kt, kh, kw, ch) into registers
+    auto load_tiles = [&]() {
+        const int tap = (kt * p.kH + kh) * p.kW + kw;
+        const int c0 = ch * BK;
+        const int tap_off = (kt * p.Hi + kh) * p.Wi + kw;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int idx = tid + 256 * i;
             const int col = (idx % F4R) * 4;
             const int ti = a_t0[i] + kt, hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-            const bool ok = a_ok[i] && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+            const bool ok = (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
                             (unsigned)wi < (unsigned)p.Wi && (c0 + col) < p.kA;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                const size_t pos = (((size_t)a_n[i] * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
-                v = *reinterpret_cast<const f32x4*>(xg + pos * p.ldx + c0 + col);
+                v = *reinterpret_cast<const f32x4*>(xg + (size_t)(a_pos[i] + tap_off) * p.ldx + c0 + col);
                 if (pro_relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -262,18 +282,17 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ---- main loop: register-staged double buffering, one barrier per k-step ----
-    int s = next_valid(zs * p.steps_per_split);
-    if (s < s_end) {
-        load_tiles(s);
-        s = next_valid(s + 1);
+    if (have) {
+        load_tiles();
+        advance();
         store_tiles(0);
         __syncthreads();
         int buf = 0;
         while (true) {
-            const bool more = s < s_end;
+            const bool more = have;
             if (more) {
-                load_tiles(s);
-                s = next_valid(s + 1);
+                load_tiles();
+                advance();
             }
             compute(buf);
             if (!more) break;
@@ -335,11 +354,13 @@ template <int BM, int BN, int BK, int WM, int WN, int MT>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT>;
-    static bool attr_set = false;   // per process; benign race (idempotent call)
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device; benign race (idempotent call)
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     return hip_check(hipGetLastError(), "conv_igemm launch");
@@ -455,7 +476,7 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     const ConvConfig& c = kConfigs[config];
     a.m_tiles = cdiv(a.M, c.BM);
     a.n_tiles = cdiv(a.ldy, c.BN);
-    a.kchunks = cdiv(max(a.kA, a.kB), c.BK);
+    a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
     a.steps_total = a.kT * a.kH * a.kW * a.kchunks;
     if (split_k < 1) split_k = 1;
     if (split_k > a.steps_total) split_k = a.steps_total;

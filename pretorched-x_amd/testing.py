@@ -15,6 +15,9 @@ import torch
 # gamma of the BN that closes a residual branch is damped so that logits stay O(10) deep into
 # the network (factor 0.8 -> max|logit| ~ 26 for resnet3d50).
 LAST_BN_DAMP = 0.8
+# the non-local branch re-injects a full-width signal after the block's ReLU; its output BN
+# (`W.1`) is damped harder so NL networks stay in the same logit range (calibrated: ~10-30)
+NL_BN_DAMP = 0.2
 
 
 def _gen(seed, key):
@@ -24,7 +27,7 @@ def _gen(seed, key):
 
 
 def _is_closing_bn(prefix, keys):
-    if prefix.endswith(".bn3") or prefix.endswith("downsample.1") or prefix.endswith(".W.1"):
+    if prefix.endswith(".bn3") or prefix.endswith("downsample.1"):
         return True
     if prefix.endswith(".bn2"):
         parent = prefix.rsplit(".", 1)[0]
@@ -46,7 +49,11 @@ def synth_state_dict(template, seed=1234):
             out[key] = torch.zeros(shape, dtype=torch.long)
         elif is_bn and leaf == "weight":
             v = torch.rand(shape, generator=g) + 0.5
-            out[key] = v * LAST_BN_DAMP if _is_closing_bn(prefix, keys) else v
+            if prefix.endswith(".W.1"):
+                v = v * NL_BN_DAMP
+            elif _is_closing_bn(prefix, keys):
+                v = v * LAST_BN_DAMP
+            out[key] = v
         elif is_bn and leaf == "bias":
             out[key] = torch.randn(shape, generator=g) * 0.1
         elif leaf == "running_mean":

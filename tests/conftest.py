@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no device is visible and -m gpu was not requested
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def ptx():
+    import pretorched_x_amd
+    return pretorched_x_amd
+
+
+# golden case name -> (arch, factory kwargs); shapes/seeds live inside the fixture files
+GOLDEN_CASES = {
+    "resnet3d50_small": ("resnet3d50", dict(num_classes=339, pretrained=None)),
+    "resnet3d50_odd": ("resnet3d50", dict(num_classes=17, pretrained=None)),
+    "resnet3d10_small": ("resnet3d10", dict()),
+    "resnet3d18_small": ("resnet3d18", dict(num_classes=400, pretrained=None)),
+    "resnet3d34_small": ("resnet3d34", dict(num_classes=400, pretrained=None)),
+    "nonlocalresnet3d50_small": ("nonlocalresnet3d50", dict(pretrained=None)),
+    "r2plus1d18_small": ("r2plus1d18", dict(num_classes=174)),
+    "r2plus1d50_small": ("r2plus1d50", dict(num_classes=400)),
+    "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", dict(num_classes=339)),
+    "resnet18_cfg1": ("resnet18", dict(num_classes=1000, pretrained=None)),
+    "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
+}
+
+
+def golden_input(blob):
+    """Regenerate the fixture's input from its recorded shape and seed (CPU generator)."""
+    shape = tuple(int(v) for v in blob["shape"])
+    g = torch.Generator().manual_seed(int(blob["x_seed"]))
+    return torch.randn(*shape, generator=g)

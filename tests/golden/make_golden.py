@@ -1,0 +1,150 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference, via oracle.ref_shim)
+on CPU with the deterministic synthetic weights/inputs of pretorched_x_amd.testing.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference tree does not exist on the GPU box, so these small fixtures (logits, small feature
+maps, state_dict key lists) are committed; the GPU parity tests compare the HIP engine against
+them and, in the same run, against the oracle restatement (oracle/functional.py).
+
+Recipe per case: weights = synth_state_dict(reference_model.state_dict(), seed=W_SEED),
+input = synth_clips(..., seed=X_SEED); outputs from `model.features` / `model(x)` in eval mode.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import ref_shim, tv_standin  # noqa: E402
+import pretorched_x_amd as ptx  # noqa: E402
+from pretorched_x_amd.testing import synth_clips, synth_state_dict  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+W_SEED, X_SEED = 1234, 99
+
+# name -> (input shape, factory kwargs)
+CASES = {
+    "resnet3d50_cfg2": ("resnet3d50", (8, 3, 16, 224, 224), dict(num_classes=339, pretrained=None)),
+    "resnet3d50_small": ("resnet3d50", (2, 3, 8, 64, 64), dict(num_classes=339, pretrained=None)),
+    "resnet3d50_odd": ("resnet3d50", (3, 3, 5, 50, 70), dict(num_classes=17, pretrained=None)),
+    "resnet3d10_small": ("resnet3d10", (2, 3, 8, 64, 64), dict()),
+    "resnet3d18_small": ("resnet3d18", (2, 3, 8, 64, 64), dict(num_classes=400, pretrained=None)),
+    "resnet3d34_small": ("resnet3d34", (1, 3, 4, 48, 48), dict(num_classes=400, pretrained=None)),
+    "nonlocalresnet3d50_small": ("nonlocalresnet3d50", (2, 3, 8, 64, 64), dict(pretrained=None)),
+    "r2plus1d18_small": ("r2plus1d18", (2, 3, 8, 64, 64), dict(num_classes=174)),
+    "r2plus1d50_small": ("r2plus1d50", (2, 3, 8, 64, 64), dict(num_classes=400)),
+    "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", (2, 3, 8, 64, 64), dict(num_classes=339)),
+    "resnet18_cfg1": ("resnet18", (1, 3, 224, 224), dict(num_classes=1000, pretrained=None)),
+}
+
+
+def build_composite(ref, r2):
+    """(2+1)D bottlenecks + NL blocks inside NonLocalResNet3D, shortcut 'B'."""
+    nl = ref.models.nonlocalnet
+
+    class NLBottleneck2p1d(nl.NonLocalBottleneck):
+        Conv3d = r2.SpatioTemporalConv
+
+    class NLR2Plus1D(nl.NonLocalResNet3D):
+        Conv3d = r2.SpatioTemporalConv
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.conv1 = r2.SpatioTemporalConv(3, 64, 7, stride=(1, 2, 2), padding=(3, 3, 3), bias=False)
+
+        def init_weights(self):
+            r2.R2Plus1D.init_weights(self)
+
+    return lambda num_classes=339: NLR2Plus1D(NLBottleneck2p1d, [3, 4, 6, 3], [0, 2, 3, 0],
+                                              shortcut_type="B", num_classes=num_classes)
+
+
+def main():
+    torch.manual_seed(0)
+    ref = ref_shim.import_reference({"resnet18": tv_standin.resnet18})
+    r2 = ref_shim.import_r2plus1d()
+    trn = ref_shim.import_trn()
+    composite = build_composite(ref, r2)
+    keys_out = {}
+
+    # (2+1)D reference models must be *built and run* before any resnet3d* factory patches
+    # ResNet3D.forward at class level -- so handle them first.
+    order = sorted(CASES, key=lambda n: 0 if "r2plus1d" in n else 1)
+    for case in order:
+        arch, shape, kw = CASES[case]
+        if arch == "nonlocal_r2plus1d50":
+            model = composite(**kw)
+        elif arch.startswith("r2plus1d"):
+            model = getattr(r2, arch)(**kw)
+        else:
+            model = ref.__dict__[arch](**kw)
+        model.eval()
+        sd = synth_state_dict(model.state_dict(), W_SEED)
+        model.load_state_dict(sd)
+        keys_out[case] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        x = synth_clips(shape[0], shape[2], shape[3], X_SEED) if len(shape) == 5 else None
+        if len(shape) == 5 and shape[3] != shape[4]:
+            g = torch.Generator().manual_seed(X_SEED)
+            x = torch.randn(*shape, generator=g)
+        if len(shape) == 4:
+            g = torch.Generator().manual_seed(X_SEED)
+            x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            if hasattr(model, "features") and not arch.startswith("r2plus1d"):
+                feat = model.features(x)
+                logits = model.logits(feat)
+            else:   # R2Plus1D keeps ResNet3D.forward / fc (r2plus1d.py:99-110)
+                feat = None
+                logits = _r2_forward(model, x)
+        blob = dict(logits=logits.numpy(), shape=np.array(shape), w_seed=W_SEED, x_seed=X_SEED)
+        if feat is not None:
+            f = feat.numpy()
+            blob["feat_shape"] = np.array(f.shape)
+            blob["feat_sum"] = np.float64(f.astype(np.float64).sum())
+            blob["feat_abs_sum"] = np.float64(np.abs(f.astype(np.float64)).sum())
+            if f.size <= 300000:
+                blob["features"] = f
+        np.savez_compressed(os.path.join(OUT, case + ".npz"), **blob)
+        print("%-28s logits %s max|.|=%.3f argmax=%s" % (case, tuple(logits.shape), logits.abs().max().item(),
+                                                        logits.argmax(1).tolist()))
+
+    # TRN relation heads (standalone nn.Modules)
+    g = torch.Generator().manual_seed(X_SEED)
+    xr = torch.randn(4, 1, 8, 256, generator=g)
+    rel = trn.Relation(8, 256, 96, 128).eval()
+    sd = synth_state_dict(rel.state_dict(), W_SEED)
+    rel.load_state_dict(sd)
+    keys_out["relation"] = [[k, list(v.shape)] for k, v in rel.state_dict().items()]
+    with torch.no_grad():
+        yr = rel(xr)
+    msr = trn.MultiScaleRelation(8, 256, 96, 128, 3).eval()
+    sd = synth_state_dict(msr.state_dict(), W_SEED)
+    msr.load_state_dict(sd)
+    keys_out["multiscale_relation"] = [[k, list(v.shape)] for k, v in msr.state_dict().items()]
+    np.random.seed(7)
+    with torch.no_grad():
+        ym = msr(xr)
+    np.savez_compressed(os.path.join(OUT, "trn_relation.npz"), relation=yr.numpy(), multiscale=ym.numpy(),
+                        np_seed=7, w_seed=W_SEED, x_seed=X_SEED)
+    print("trn relation", tuple(yr.shape), "multiscale", tuple(ym.shape))
+    json.dump(keys_out, open(os.path.join(OUT, "state_keys.json"), "w"))
+
+
+def _r2_forward(model, x):
+    """ResNet3D.forward as written at resnet3D.py:203-218 (the class attribute may have been
+    replaced by modify_resnets in this process, F7): stem, pool, stages, avgpool, fc."""
+    h = model.maxpool(model.relu(model.bn1(model.conv1(x))))
+    h = model.layer4(model.layer3(model.layer2(model.layer1(h))))
+    h = model.avgpool(h)
+    head = model.fc if getattr(model, "fc", None) is not None else model.last_linear
+    return head(h.view(h.size(0), -1))
+
+
+if __name__ == "__main__":
+    main()

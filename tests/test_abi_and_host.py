@@ -1,0 +1,152 @@
+"""No-GPU tests: the C-ABI library loads and exports exactly what include/ptx_amd.h declares,
+host-side argument validation works without a device, and the plan compiler / registry / weight
+ABI behave like the reference's."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_header_and_bindings_agree(ptx):
+    L = ptx._lib
+    declared = set(L.header_symbols())
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.ptx_version()
+
+
+def test_struct_layouts_match_header(ptx):
+    """ctypes mirrors of the POD descriptors must have the header's field order and size."""
+    L = ptx._lib
+    text = open(L.HEADER_PATH).read()
+
+    def fields_of(struct):
+        body = text.split("typedef struct %s {" % struct)[1].split("}")[0]
+        body = "\n".join(line.split("/*")[0] for line in body.splitlines())
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.replace("uint32_t", "").replace("int32_t", "")
+            out += [n.strip() for n in names.split(",") if n.strip()]
+        return out
+
+    assert fields_of("ptx_conv3d_desc") == [f for f, _ in L.ConvDesc._fields_]
+    assert fields_of("ptx_pack_desc") == [f for f, _ in L.PackDesc._fields_]
+    assert fields_of("ptx_pool3d_desc") == [f for f, _ in L.PoolDesc._fields_]
+    assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
+
+
+def test_host_side_validation_without_gpu(ptx):
+    L = ptx._lib
+    lib = L.lib()
+    n = lib.ptx_conv3d_num_configs()
+    assert n >= 8
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(n)]
+    assert len(set(names)) == n and all("/" in s for s in names)
+    # null descriptor -> PTX_ERR_INVALID with a message, no device touched
+    st = lib.ptx_conv3d_fwd(None, None, None, None, None, None, None, 0, -1, 1, None)
+    assert st == 1 and b"null" in lib.ptx_last_error()
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = 8, 8, 56, 56, 64, 64
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 8, 56, 56, 64, 64
+    d.kT = d.kH = d.kW = 3
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = 1
+    d.Kc, d.Co_pad = 64, 128
+    sk = C.c_int(0)
+    cfg = lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))
+    assert 0 <= cfg < n and sk.value == 1
+    assert lib.ptx_conv3d_workspace_bytes(C.byref(d), 1) == 0
+    assert lib.ptx_conv3d_workspace_bytes(C.byref(d), 2) == 2 * 8 * 8 * 56 * 56 * 64 * 4
+    d.Wo = 55    # inconsistent output extent must be rejected before any launch
+    st = lib.ptx_conv3d_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, 0, -1, 1, None)
+    assert st == 1 and b"output extent" in lib.ptx_last_error()
+    pd = L.PackDesc(64, 3, 7, 7, 7, 24, 128, 1)
+    assert lib.ptx_packed_weight_elems(C.byref(pd)) == 49 * 128 * 24
+    pd = L.PackDesc(64, 64, 3, 3, 3, 64, 128, 0)
+    assert lib.ptx_packed_weight_elems(C.byref(pd)) == 27 * 128 * 64
+
+
+def test_registry_and_weight_abi(ptx):
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    from conftest import GOLDEN_CASES
+    for case, (name, kw) in GOLDEN_CASES.items():
+        assert name in ptx.model_names
+        model = ptx.__dict__[name](**kw)        # the documented `pretorched.__dict__[name](...)` entry
+        got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        assert got == keys[case], case            # names, shapes AND order of the reference
+        assert not model.training
+    m = ptx.resnet3d50(num_classes=339, pretrained=None)
+    assert m.fc is None and isinstance(m.last_linear, torch.nn.Linear)
+    assert not hasattr(m, "input_size")           # only set when pretrained (torchvision_models.py:162)
+    # reference quirk F8: nonlocalresnet3d50 ignores num_classes
+    assert ptx.nonlocalresnet3d50(num_classes=400, pretrained=None).last_linear.out_features == 339
+    with pytest.raises(ValueError):
+        ptx.nonlocalresnet3d50(num_nonlocal_blocks=7, pretrained=None)
+    assert ptx.pretrained_settings["resnet3d50"]["moments"]["num_classes"] == 339
+    assert ptx.factored_mid_channels(64, 64, 3) == 144 and ptx.factored_mid_channels(3, 64, 7) == 110
+
+
+def test_no_cpu_fallback(ptx):
+    m = ptx.resnet3d10()
+    with pytest.raises(ptx.PtxError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 4, 32, 32))
+    with pytest.raises(ptx.PtxError, match="no CPU fallback"):
+        m.features(torch.randn(1, 3, 4, 32, 32))
+    with pytest.raises(ptx.PtxError):
+        ptx.Relation(2, 8, 4, 4)(torch.randn(1, 1, 2, 8))
+    m.train()
+    with pytest.raises(ptx.PtxError, match="forward-only"):
+        m(torch.randn(1, 3, 4, 32, 32))
+
+
+def test_plan_compiler_matches_survey_worklist(ptx):
+    """config 2 = 53 convs, 318.763 GMAC, 23 distinct problems."""
+    m = ptx.resnet3d50(num_classes=339, pretrained=None)
+    plan = m.engine().dry_plan(m, (8, 3, 16, 224, 224))
+    assert len(plan.conv_steps) == 53
+    gmac = sum(s.macs for s in plan.conv_steps) / 1e9
+    assert abs(gmac - 318.763) < 0.01
+    geom = {s.d.key()[:22] for s in plan.conv_steps}              # geometry only (no epilogue flags):
+    assert len(geom) == 23                                        # C4 covers conv3 and the shortcut
+    assert tuple(plan.feat.t.shape) == (8, 1, 7, 7, 2048)
+    stem = plan.conv_steps[0].d
+    assert (stem.Ci, stem.kT, stem.kH, stem.kW, stem.Kc) == (24, 7, 7, 1, 24)   # kW folded into channels
+    for name, shape, gm in [("r2plus1d50", (1, 3, 32, 112, 112), 21.158), ("nonlocalresnet3d50", (1, 3, 32, 112, 112), 22.433),
+                            ("nonlocal_r2plus1d50", (1, 3, 32, 112, 112), 24.035), ("resnet18", (1, 3, 224, 224), 1.8136)]:
+        kw = dict(pretrained=None) if name in ("nonlocalresnet3d50", "resnet18") else {}
+        mm = ptx.__dict__[name](**kw)
+        pl = mm.engine().dry_plan(mm, shape)
+        assert abs(sum(s.macs for s in pl.conv_steps) / 1e9 - gm) < 0.01, name
+
+
+def test_synth_recipe_is_deterministic(ptx):
+    from pretorched_x_amd.testing import synth_clips, synth_state_dict
+    m = ptx.resnet3d10()
+    a = synth_state_dict(m.state_dict(), 7)
+    b = synth_state_dict(m.state_dict(), 7)
+    c = synth_state_dict(m.state_dict(), 8)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert any(not torch.equal(a[k], c[k]) for k in a)
+    assert torch.equal(synth_clips(2, 4, 16, 5), synth_clips(2, 4, 16, 5))
+    assert (a["layer1.0.bn2.weight"].mean() < a["layer1.0.bn1.weight"].mean())   # closing BN damped
+
+
+def test_shard_bounds():
+    from pretorched_x_amd.parallel import shard_bounds
+    for total in (1, 7, 8, 16, 17):
+        for world in (1, 2, 3, 8):
+            chunks = [shard_bounds(total, world, r) for r in range(world)]
+            want = [c.shape[0] for c in torch.arange(total).chunk(world)] + [0] * world
+            assert [b - a for a, b in chunks] == want[:world]
+            assert chunks[0][0] == 0 and chunks[-1][1] == total
+            assert all(chunks[i][1] == chunks[i + 1][0] for i in range(world - 1))

@@ -1,0 +1,350 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the ATen CPU op the reference
+calls at the cited site, on seeded inputs, through ctypes (no torch GPU math in the path under
+test -- torch only moves bytes).  Tolerances: fp32 with a different summation order."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib(ptx):
+    return ptx._lib.lib()
+
+
+def _p(t, off=0):
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _r4(v):
+    return (v + 3) // 4 * 4
+
+
+def to_cl(x, ld=None):
+    """NCDHW cpu -> channels-last [N,T,H,W,ld] on the GPU (zero pad channels)."""
+    n, c = x.shape[:2]
+    ld = _r4(c) if ld is None else ld
+    y = torch.zeros(n, *x.shape[2:], ld)
+    y[..., :c] = x.permute(0, 2, 3, 4, 1)
+    return y.to(DEV)
+
+
+def from_cl(y, c):
+    return y[..., :c].permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def hip_conv(ptx, x, w, stride, padding, bias=None, bn=None, relu=False, res=None, res_pad=None, res_stride=1,
+             cfg=-1, split=0, pro_relu=False):
+    """x NCDHW cpu, w [Co,Ci,kT,kH,kW] cpu.  Returns NCDHW cpu output of ptx_conv3d_fwd."""
+    L, lib = ptx._lib, _lib(ptx)
+    Co, Ci, kT, kH, kW = w.shape
+    N, _, T, H, W = x.shape
+    sT, sH, sW = stride
+    pT, pH, pW = padding
+    To, Ho, Wo = (T + 2 * pT - kT) // sT + 1, (H + 2 * pH - kH) // sH + 1, (W + 2 * pW - kW) // sW + 1
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd = w.contiguous().to(DEV)
+    null = C.c_void_p(0)
+    keep = [wd]
+    bnargs, eps = [null] * 4, 0.0
+    if bn is not None:
+        ts = [t.contiguous().to(DEV) for t in bn[:4]]
+        keep += ts
+        bnargs, eps = [_p(t) for t in ts], bn[4]
+    bd = bias.to(DEV) if bias is not None else None
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd) if bd is not None else null, *bnargs,
+                                     C.c_float(eps), _p(wp), _p(bp), _st()), "pack")
+    xd = to_cl(x)
+    ldy = _r4(Co)
+    yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, xd.shape[-1]
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, ldy
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
+    d.Kc, d.Co_pad = pd.Kc, pd.Co_pad
+    flags = (L.PTX_EPI_RELU if relu else 0) | (L.PTX_PRO_RELU if pro_relu else 0)
+    rd = None
+    if res is not None:
+        rd = to_cl(res)
+        d.ldr = rd.shape[-1]
+        flags |= L.PTX_EPI_RES_ADD
+    if res_pad is not None:
+        rd = to_cl(res_pad)
+        d.ldr = rd.shape[-1]
+        d.res_C, d.res_T, d.res_H, d.res_W = res_pad.shape[1], res_pad.shape[2], res_pad.shape[3], res_pad.shape[4]
+        d.res_sT = d.res_sH = d.res_sW = res_stride
+        flags |= L.PTX_EPI_RES_PADA
+    d.flags = flags
+    ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
+    ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
+    L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), _p(rd) if rd is not None else null, _p(yd),
+                               _p(ws), ws_bytes, cfg, split, _st()), "conv")
+    torch.cuda.synchronize()
+    pad = yd[..., Co:]
+    assert pad.numel() == 0 or bool((pad == 0).all()), "pad channels must be written as zero"
+    return from_cl(yd, Co)
+
+
+def ref_conv(x, w, stride, padding, bias=None, bn=None, relu=False, res=None, res_pad=None, res_stride=1,
+             pro_relu=False):
+    if pro_relu:
+        x = F.relu(x)
+    y = F.conv3d(x, w, bias, stride, padding)
+    if bn is not None:
+        g, b, m, v, eps = bn
+        y = F.batch_norm(y, m, v, g, b, False, 0.1, eps)
+    if res is not None:
+        y = y + res
+    if res_pad is not None:
+        r = F.avg_pool3d(res_pad, kernel_size=1, stride=res_stride)
+        y = y + torch.cat([r, torch.zeros(r.size(0), y.size(1) - r.size(1), *r.shape[2:])], 1)
+    return F.relu(y) if relu else y
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def make_bn(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+            torch.rand(c, generator=g) + 0.5, 1e-5)
+
+
+def close(got, want, tol=2e-4):
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert got.shape == want.shape
+    assert err <= tol * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+GEOMS = [
+    # name, N,T,H,W, Ci,Co, k, s, p
+    ("pw64_256", 2, 3, 10, 11, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("c3s1_64", 2, 3, 10, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("c3s2_128", 1, 6, 14, 14, 128, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ("pw_s2", 2, 4, 14, 14, 256, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ("c3_T1", 3, 1, 7, 7, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("c3_T2_s2", 2, 2, 14, 14, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ("spatial_odd", 2, 4, 9, 9, 51, 85, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("temporal_odd", 2, 5, 6, 6, 85, 34, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ("temporal7", 1, 8, 6, 6, 110, 64, (7, 1, 1), (1, 1, 1), (3, 0, 0)),
+    ("c5_generic", 1, 5, 9, 10, 12, 20, (3, 5, 2), (1, 2, 1), (1, 2, 1)),
+]
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv_geometries_auto_config(ptx, g):
+    name, N, T, H, W, Ci, Co, k, s, p = g
+    x, w = rnd(N, Ci, T, H, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+    bn = make_bn(Co, 3)
+    close(hip_conv(ptx, x, w, s, p, bn=bn, relu=True), ref_conv(x, w, s, p, bn=bn, relu=True))
+
+
+def test_conv_every_config_and_split(ptx):
+    lib = _lib(ptx)
+    N, T, H, W, Ci, Co = 2, 3, 9, 10, 64, 160
+    x, w = rnd(N, Ci, T, H, W, seed=4), rnd(Co, Ci, 3, 3, 3, seed=5, scale=0.03)
+    bn = make_bn(Co, 6)
+    res = rnd(N, Co, T, H, W, seed=7)
+    want = ref_conv(x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res)
+    errs = {}
+    for cfg in range(lib.ptx_conv3d_num_configs()):
+        for split in (1, 2, 5):
+            got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res, cfg=cfg, split=split)
+            errs[(lib.ptx_conv3d_config_name(cfg).decode(), split)] = (got - want).abs().max().item()
+    bad = {k: v for k, v in errs.items() if not v <= 2e-4 * max(1.0, want.abs().max().item())}
+    assert not bad, bad
+
+
+def test_conv_ragged_channels_every_config(ptx):
+    lib = _lib(ptx)
+    x, w = rnd(2, 51, 3, 7, 6, seed=8), rnd(85, 51, 1, 3, 3, seed=9, scale=0.05)
+    bias = rnd(85, seed=10)
+    want = ref_conv(x, w, (1, 1, 1), (0, 1, 1), bias=bias)
+    for cfg in range(lib.ptx_conv3d_num_configs()):
+        close(hip_conv(ptx, x, w, (1, 1, 1), (0, 1, 1), bias=bias, cfg=cfg, split=1), want)
+
+
+def test_conv_epilogues(ptx):
+    x, w = rnd(2, 64, 4, 8, 8, seed=11), rnd(128, 64, 1, 1, 1, seed=12, scale=0.1)
+    bn = make_bn(128, 13)
+    bias = rnd(128, seed=14)
+    one, zero = (1, 1, 1), (0, 0, 0)
+    close(hip_conv(ptx, x, w, one, zero), ref_conv(x, w, one, zero))                                # plain
+    close(hip_conv(ptx, x, w, one, zero, bias=bias, bn=bn), ref_conv(x, w, one, zero, bias=bias, bn=bn))  # conv bias + BN
+    close(hip_conv(ptx, x, w, one, zero, pro_relu=True, relu=True), ref_conv(x, w, one, zero, pro_relu=True, relu=True))
+    # shortcut A, stride 1 (channel zero-pad only) and stride 2 (subsample + zero-pad)
+    rp = rnd(2, 64, 4, 8, 8, seed=15)
+    close(hip_conv(ptx, x, w, one, zero, bn=bn, relu=True, res_pad=rp, res_stride=1),
+          ref_conv(x, w, one, zero, bn=bn, relu=True, res_pad=rp, res_stride=1))
+    w3 = rnd(128, 64, 3, 3, 3, seed=16, scale=0.03)
+    rp2 = rnd(2, 48, 4, 8, 8, seed=17)
+    close(hip_conv(ptx, x, w3, (2, 2, 2), one, bn=bn, relu=True, res_pad=rp2, res_stride=2, split=3),
+          ref_conv(x, w3, (2, 2, 2), one, bn=bn, relu=True, res_pad=rp2, res_stride=2))
+
+
+def test_stem_fold_path(ptx):
+    """ptx_fold_kw_ncdhw + fold_kw weight pack + (7,7,1) conv == Conv3d(3,64,7,s(1,2,2),p3) + BN + ReLU
+    (resnet3D.py:153-155)."""
+    L, lib = ptx._lib, _lib(ptx)
+    N, T, H, W = 2, 5, 30, 26
+    x, w = rnd(N, 3, T, H, W, seed=20), rnd(64, 3, 7, 7, 7, seed=21, scale=0.03)
+    bn = make_bn(64, 22)
+    want = ref_conv(x, w, (1, 2, 2), (3, 3, 3), bn=bn, relu=True)
+    Wo = (W + 6 - 7) // 2 + 1
+    Ho = (H + 6 - 7) // 2 + 1
+    xd = x.to(DEV)
+    x2 = torch.full((N, T, H, Wo, 24), float("nan"), device=DEV)
+    L.check(lib.ptx_fold_kw_ncdhw(_p(xd), _p(x2), N, 3, T, H, W, 7, 2, 3, Wo, 24, _st()), "fold")
+    pd = L.PackDesc(64, 3, 7, 7, 7, 24, 128, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(128, device=DEV)
+    ts = [t.to(DEV) for t in bn[:4]]
+    wd = w.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                     C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack")
+    for cfg in (-1, 6, 7, 1, 9):
+        yd = torch.full((N, T, Ho, Wo, 64), float("nan"), device=DEV)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, Wo, 24, 24
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = T, Ho, Wo, 64, 64
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 7, 7, 1, 1, 2, 1, 3, 3, 0
+        d.Kc, d.Co_pad, d.flags = 24, 128, L.PTX_EPI_RELU
+        L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(x2), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st()), "conv")
+        torch.cuda.synchronize()
+        close(from_cl(yd, 64), want)
+
+
+def test_maxpool(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    for (N, T, H, W, Cc, k, s, p) in [(2, 6, 13, 12, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                      (1, 1, 15, 15, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                      (2, 5, 8, 8, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1))]:
+        x = rnd(N, Cc, T, H, W, seed=30)
+        want = F.max_pool3d(x, k, s, p)
+        xd = to_cl(x)
+        To, Ho, Wo = want.shape[2:]
+        yd = torch.full((N, To, Ho, Wo, xd.shape[-1]), float("nan"), device=DEV)
+        d = L.PoolDesc(N, T, H, W, Cc, xd.shape[-1], To, Ho, Wo, *k, *s, *p)
+        L.check(lib.ptx_maxpool3d_fwd(C.byref(d), _p(xd), _p(yd), _st()), "maxpool")
+        torch.cuda.synchronize()
+        assert torch.equal(from_cl(yd, Cc), want)      # max is exact
+
+
+def test_avgpool_and_linear(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    x = rnd(3, 100, 2, 7, 7, seed=31)
+    want = F.adaptive_avg_pool3d(x, 1).flatten(1)
+    xd = to_cl(x)
+    out = torch.empty(3, 100, device=DEV)
+    L.check(lib.ptx_global_avgpool(_p(xd), _p(out), 3, 100, 98, xd.shape[-1], 0, _st()), "avgpool cl")
+    close(out.cpu(), want, 1e-5)
+    xcf = x.to(DEV)
+    out2 = torch.empty(3, 100, device=DEV)
+    L.check(lib.ptx_global_avgpool(_p(xcf), _p(out2), 3, 100, 98, 100, 1, _st()), "avgpool cf")
+    close(out2.cpu(), want, 1e-5)
+    for (M, K, Nout, flags) in [(8, 2048, 339, 0), (1, 2048, 17, 0), (9, 100, 33, L.PTX_EPI_RELU),
+                                (5, 62, 7, L.PTX_PRO_RELU | L.PTX_EPI_RELU), (3, 16384, 64, L.PTX_PRO_RELU)]:
+        a, w, b = rnd(M, K, seed=32), rnd(Nout, K, seed=33, scale=K ** -0.5), rnd(Nout, seed=34)
+        ain = F.relu(a) if flags & L.PTX_PRO_RELU else a
+        want = F.linear(ain, w, b)
+        want = F.relu(want) if flags & L.PTX_EPI_RELU else want
+        ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+        yd = torch.full((M, Nout), float("nan"), device=DEV)
+        L.check(lib.ptx_linear_fwd(_p(ad), _p(wd), _p(bd), _p(yd), M, K, Nout, K, Nout, flags, _st()), "linear")
+        close(yd.cpu(), want, 1e-5)
+        L.check(lib.ptx_linear_fwd(_p(ad), _p(wd), None, _p(yd), M, K, Nout, K, Nout, flags | L.PTX_EPI_ACCUM, _st()),
+                "linear accum")
+        extra = F.linear(ain, w)
+        # accumulate: y_new = act(y_old + xW) -- with RELU flags y_old >= 0 already
+        want2 = want + extra
+        want2 = F.relu(want2) if flags & L.PTX_EPI_RELU else want2
+        close(yd.cpu(), want2, 1e-5)
+
+
+def test_layout_transforms(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    for (N, Cc, S) in [(2, 3, 1000), (1, 70, 37), (3, 2048, 49)]:
+        x = rnd(N, Cc, S, seed=40)
+        ld = _r4(Cc)
+        xd = x.to(DEV)
+        y = torch.full((N, S, ld), float("nan"), device=DEV)
+        L.check(lib.ptx_ncdhw_to_ndhwc(_p(xd), _p(y), N, Cc, S, ld, _st()), "to cl")
+        torch.cuda.synchronize()
+        assert torch.equal(y[..., :Cc].cpu(), x.permute(0, 2, 1))
+        assert bool((y[..., Cc:] == 0).all())
+        z = torch.full((N, Cc, S), float("nan"), device=DEV)
+        L.check(lib.ptx_ndhwc_to_ncdhw(_p(y), _p(z), N, Cc, S, ld, _st()), "to cf")
+        torch.cuda.synchronize()
+        assert torch.equal(z.cpu(), x)
+    x = rnd(2, 50, 24, seed=41)      # [batch][R=50][ldx=24], Cc=22 valid
+    xd = x.to(DEV)
+    y = torch.full((2, 22, 52), float("nan"), device=DEV)
+    L.check(lib.ptx_transpose_last2(_p(xd), _p(y), 2, 50, 22, 24, 52, _st()), "transpose")
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, :, :50].cpu(), x[:, :, :22].permute(0, 2, 1))
+    assert bool((y[:, :, 50:] == 0).all())
+
+
+def test_softmax_and_bgemm(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    for cols in (196, 1568, 37):
+        ld = _r4(cols)
+        x = rnd(5, ld, seed=42, scale=3.0)
+        xd = x.clone().to(DEV)
+        L.check(lib.ptx_softmax_rows(_p(xd), 5, cols, ld, 0, _st()), "softmax")
+        torch.cuda.synchronize()
+        close(xd[:, :cols].cpu(), F.softmax(x[:, :cols], -1), 1e-6)
+        assert bool((xd[:, cols:] == 0).all())
+        xs = x.clone().to(DEV)
+        L.check(lib.ptx_softmax_rows(_p(xs), 5, cols, ld, 1, _st()), "scale")
+        close(xs[:, :cols].cpu(), x[:, :cols] / cols, 1e-6)
+    for (B, M, Nn, K) in [(3, 196, 196, 64), (2, 200, 100, 52), (2, 300, 256, 1568), (1, 70, 33, 10)]:
+        lda, ldb, ldc = _r4(K) + 4, _r4(K), _r4(Nn)
+        a = torch.zeros(B, M, lda)
+        b = torch.zeros(B, Nn, ldb)
+        a[..., :K] = rnd(B, M, K, seed=43)
+        b[..., :K] = rnd(B, Nn, K, seed=44)
+        ad, bd = a.to(DEV), b.to(DEV)
+        cd = torch.full((B, M, ldc), float("nan"), device=DEV)
+        L.check(lib.ptx_bgemm_nt(_p(ad), _p(bd), _p(cd), B, M, Nn, K, lda, ldb, ldc, M * lda, Nn * ldb, M * ldc, _st()),
+                "bgemm")
+        torch.cuda.synchronize()
+        close(cd[..., :Nn].cpu(), torch.matmul(a[..., :K], b[..., :K].transpose(1, 2)), 1e-4)
+        assert bool((cd[..., Nn:] == 0).all())
+
+
+def test_error_paths_on_device(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    x = torch.zeros(128 * 64, device=DEV)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = 1, 1, 4, 4, 64, 64
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, 4, 4, 4, 4
+    d.kT = d.kH = d.kW = 1
+    d.sT = d.sH = d.sW = 1
+    d.Kc, d.Co_pad = 64, 128
+    assert lib.ptx_conv3d_fwd(C.byref(d), _p(x), _p(x), None, None, _p(x, 4096), None, 0, 2, 1, _st()) == 0
+    # split-K without workspace must be refused, not crash
+    st = lib.ptx_conv3d_fwd(C.byref(d), _p(x), _p(x), None, None, _p(x, 4096), None, 0, 2, 2, _st())
+    assert st == 4 and b"workspace" in lib.ptx_last_error()
+    d.flags = L.PTX_EPI_RES_ADD
+    st = lib.ptx_conv3d_fwd(C.byref(d), _p(x), _p(x), None, None, _p(x, 4096), None, 0, 2, 1, _st())
+    assert st == 1 and b"residual" in lib.ptx_last_error()
+    with pytest.raises(L.PtxError):
+        L.check(st, "conv")
+    # misaligned pointer
+    d.flags = 0
+    st = lib.ptx_conv3d_fwd(C.byref(d), _p(x, 1), _p(x), None, None, _p(x, 4096), None, 0, 2, 1, _st())
+    assert st == 1 and b"aligned" in lib.ptx_last_error()
+    torch.cuda.synchronize()
