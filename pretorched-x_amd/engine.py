@@ -168,6 +168,7 @@ class Plan:
         self.steps = []          # callables(stream)
         self.conv_steps = []
         self.packs = []
+        self.acts = []
         self._pack_cache = {}
         self.ws_bytes = 0
         self.ws = None
@@ -194,6 +195,7 @@ class Plan:
 
     def act(self, N, T, H, W, C_, ld=None):
         a = Act(self.dev, N, T, H, W, C_, ld)
+        self.acts.append(a)      # steps hold raw pointers: the plan owns every buffer
         return a
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
