@@ -37,8 +37,9 @@ struct ConvArgs {
     long long w_tap_stride;
     unsigned flags;
     int ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
-    int m_tiles, n_tiles, split_k, kchunks, steps_total, steps_per_split;
+    int m_tiles, n_tiles, split_k, kchunks;
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
+    unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
 template <int MT> struct Mfma;
@@ -158,49 +159,51 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             }
         }
     }
-    // k-steps are numbered tap-major, channel-chunk-minor: s = ((kt*kH + kh)*kW + kw)*kchunks + ch.
-    // (kt, kh, kw, ch) is the next k-step to LOAD; it is advanced incrementally (no divisions in
-    // the loop) and `have` says whether it still lies inside this split's [s_begin, s_end).
-    const int s_end = min(p.steps_total, (zs + 1) * p.steps_per_split);
+    // The block iterates the PRUNED k-space {kt_lo..kt_hi} x {kh_lo..kh_hi} x kW x kchunks, tap-major,
+    // channel-chunk-minor; split-K slices that space evenly.  (kt, kh, kw, ch) is the next k-step to
+    // LOAD and is advanced with a few scalar compares -- no divisions, no data-dependent branches.
+    const int nkt = max(kt_hi - kt_lo + 1, 0), nkh = max(kh_hi - kh_lo + 1, 0);
+    const int total_steps = nkt * nkh * p.kW * p.kchunks;
+    const int per_split = (total_steps + p.split_k - 1) / p.split_k;
+    const int s_begin = min(zs * per_split, total_steps);
+    const int my_steps = min(s_begin + per_split, total_steps) - s_begin;
     int kt, kh, kw, ch;
-    bool have;
     {
-        const int s0 = zs * p.steps_per_split;
-        const int tap = s0 / p.kchunks;
-        ch = s0 - tap * p.kchunks;
-        const int khw = p.kH * p.kW;
-        kt = tap / khw;
-        const int rem = tap - kt * khw;
-        kh = rem / p.kW;
-        kw = rem - kh * p.kW;
+        ch = s_begin % p.kchunks;
+        int t = s_begin / p.kchunks;
+        kw = t % p.kW;
+        t /= p.kW;
+        const int d = max(nkh, 1);
+        kh = kh_lo + t % d;
+        kt = kt_lo + t / d;
     }
-    auto normalize = [&]() {
-        while (true) {
-            if (kt < kt_lo) { kt = kt_lo; kh = 0; kw = 0; ch = 0; }
-            if (kt > kt_hi) { have = false; return; }
-            if (kh < kh_lo) { kh = kh_lo; kw = 0; ch = 0; }
-            if (kh > kh_hi) { ++kt; kh = 0; kw = 0; ch = 0; continue; }
-            break;
-        }
-        have = (((kt * p.kH + kh) * p.kW + kw) * p.kchunks + ch) < s_end;
-    };
     auto advance = [&]() {
-        if (++ch == p.kchunks) {
-            ch = 0;
-            if (++kw == p.kW) {
-                kw = 0;
-                if (++kh == p.kH) { kh = 0; ++kt; }
-            }
-        }
-        normalize();
+        ++ch;
+        const bool c1 = ch == p.kchunks;
+        ch = c1 ? 0 : ch;
+        kw += c1 ? 1 : 0;
+        const bool c2 = kw == p.kW;
+        kw = c2 ? 0 : kw;
+        kh += c2 ? 1 : 0;
+        const bool c3 = kh > kh_hi;
+        kh = c3 ? kh_lo : kh;
+        kt += c3 ? 1 : 0;
     };
-    normalize();
 
     f32x4 ra[A_IT], rb[B_IT];
     const bool pro_relu = (p.flags & PTX_PRO_RELU) != 0;
 
+    // Branch-free operand loads through buffer resources: an element that must read as zero
+    // (tap outside the image, row >= M, channel tail) gets byte offset kOOB >= num_records, for
+    // which the hardware returns 0 without touching memory.  (Extents are validated < 2 GiB.)
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, p.w_bytes, 0x00020000);
+
     // issue the global loads of k-step (kt, kh, kw, ch) into registers
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](bool valid) {
         const int tap = (kt * p.kH + kh) * p.kW + kw;
         const int c0 = ch * BK;
         const int tap_off = (kt * p.Hi + kh) * p.Wi + kw;
@@ -209,28 +212,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             const int idx = tid + 256 * i;
             const int col = (idx % F4R) * 4;
             const int ti = a_t0[i] + kt, hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-            const bool ok = (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+            const bool ok = valid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
                             (unsigned)wi < (unsigned)p.Wi && (c0 + col) < p.kA;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *reinterpret_cast<const f32x4*>(xg + (size_t)(a_pos[i] + tap_off) * p.ldx + c0 + col);
-                if (pro_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            ra[i] = v;
+            const unsigned off = ((unsigned)(a_pos[i] + tap_off) * (unsigned)p.ldx + (unsigned)(c0 + col)) * 4u;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0));
         }
-        const float* wt = wg + (size_t)tap * p.w_tap_stride;
+        const unsigned wbase = (unsigned)((size_t)tap * p.w_tap_stride) + (unsigned)c0;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / F4R;
             const int col = (idx % F4R) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < B_F4 && (n0 + row) < p.w_rows && (c0 + col) < p.kB)
-                v = *reinterpret_cast<const f32x4*>(wt + (size_t)(n0 + row) * p.ldw + c0 + col);
-            rb[i] = v;
+            const bool ok = valid && idx < B_F4 && (n0 + row) < p.w_rows && (c0 + col) < p.kB;
+            const unsigned off = (wbase + (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)col) * 4u;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, ok ? off : kOOB, 0, 0));
         }
     };
 
@@ -240,7 +235,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < A_F4) *reinterpret_cast<f32x4*>(Ab + (idx / F4R) * LDK + (idx % F4R) * 4) = ra[i];
+            if (idx < A_F4) {
+                f32x4 v = ra[i];
+                if (pro_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<f32x4*>(Ab + (idx / F4R) * LDK + (idx % F4R) * 4) = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -263,61 +265,97 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * LDK + frag_off_a;
         const float* Bb = Bs + buf * BN * LDK + frag_off_b;
+        // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks are issued
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
 #pragma unroll
         for (int ks = 0; ks < KSUB; ++ks) {
-            f32x4 a[TM], b[TN];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KSUB) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + ks * 4 * KG);
+                for (int i = 0; i < TM; ++i)
+                    a[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + (ks + 1) * 4 * KG);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + ks * 4 * KG);
+                for (int j = 0; j < TN; ++j)
+                    b[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + (ks + 1) * 4 * KG);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i][r], b[j][r], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[cur][i][r], b[cur][j][r], acc[i][j]);
         }
     };
 
-    // ---- main loop: register-staged double buffering, one barrier per k-step ----
-    if (have) {
-        load_tiles();
+    // ---- main loop: register-staged double buffering, one barrier per k-step.  The body is one
+    // basic block: the loads of step s+1 are issued unconditionally (all-OOB on the last step, which
+    // costs no memory traffic) so the scheduler can interleave them with the MFMAs of step s. ----
+    if (my_steps > 0) {
+        load_tiles(true);
         advance();
         store_tiles(0);
         __syncthreads();
         int buf = 0;
-        while (true) {
-            const bool more = have;
-            if (more) {
-                load_tiles();
-                advance();
-            }
+        for (int it = 1; it <= my_steps; ++it) {
+            load_tiles(it < my_steps);
+            advance();
             compute(buf);
-            if (!more) break;
             store_tiles(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
 
-    // ---- epilogue ----
-    float* __restrict__ yg = p.y + (size_t)zb * p.bs_y;
+    // ---- epilogue: bias + residual + ReLU, branch-free through buffer resources (out-of-range
+    // stores are dropped, out-of-range loads read 0); residual values of a tile are requested in
+    // one batch before they are consumed. ----
+    const bool to_partial = p.split_k > 1;
+    float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ldy : p.y + (size_t)zb * p.bs_y;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);
+    const bool res_add = !to_partial && (p.flags & PTX_EPI_RES_ADD);
+    const bool res_pada = !to_partial && (p.flags & PTX_EPI_RES_PADA);
+    const bool relu = !to_partial && (p.flags & PTX_EPI_RELU);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, res_add ? p.r_bytes : 0u, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * WTN + j * MT + (lane % MT);
+        const bool co_ok = co < p.ldy;
+        const float bv = (!to_partial && p.bias && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn * WTN + j * MT + (lane % MT);
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m0 + wm * WTM + i * MT;
+            float rv[MF::NACC];
 #pragma unroll
             for (int r = 0; r < MF::NACC; ++r) {
-                const int m = m0 + wm * WTM + i * MT + MF::row(r, lane);
-                if (m < p.M && co < p.ldy) {
-                    if (p.split_k > 1)
-                        p.partial[((size_t)zs * p.M + m) * p.ldy + co] = acc[i][j][r];
-                    else
-                        yg[(size_t)m * p.ldy + co] = conv_epilogue(p, acc[i][j][r], m, co);
+                const int m = mrow + MF::row(r, lane);
+                const unsigned off = ((unsigned)m * (unsigned)p.ldr + (unsigned)co) * 4u;
+                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rsrc_r, (res_add && co_ok && m < p.M) ? off : kOOB, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) {
+                const int m = mrow + MF::row(r, lane);
+                float v = acc[i][j][r] + bv + rv[r];
+                if (res_pada && co < p.res_C && m < p.M) {     // shortcut A (BasicBlock / NL nets only)
+                    const int wo = m % p.Wo;
+                    int t = m / p.Wo;
+                    const int ho = t % p.Ho;
+                    t /= p.Ho;
+                    const int to = t % p.To;
+                    const int n = t / p.To;
+                    const size_t pos = (((size_t)n * p.res_T + to * p.res_sT) * p.res_H + ho * p.res_sH) * p.res_W +
+                                       wo * p.res_sW;
+                    v += p.res[pos * p.ldr + co];
                 }
+                v = relu ? fmaxf(v, 0.f) : v;
+                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y,
+                                                      (co_ok && m < p.M) ? off : kOOB, 0, 0);
             }
         }
     }
@@ -477,12 +515,20 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     a.m_tiles = cdiv(a.M, c.BM);
     a.n_tiles = cdiv(a.ldy, c.BN);
     a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
-    a.steps_total = a.kT * a.kH * a.kW * a.kchunks;
+    const int steps_total = a.kT * a.kH * a.kW * a.kchunks;
     if (split_k < 1) split_k = 1;
-    if (split_k > a.steps_total) split_k = a.steps_total;
+    if (split_k > steps_total) split_k = steps_total;
     if (batch > 1) split_k = 1;
     a.split_k = split_k;
-    a.steps_per_split = cdiv(a.steps_total, split_k);
+    {
+        const uint64_t yb = (uint64_t)a.M * a.ldy * 4ull;
+        uint64_t rb = 0;
+        if (a.flags & PTX_EPI_RES_ADD) rb = (uint64_t)a.M * a.ldr * 4ull;
+        if (yb >= 0x80000000ull || rb >= 0x80000000ull)
+            return fail(PTX_ERR_UNSUPPORTED, "conv3d: output / residual of one launch must be < 2 GiB; split the batch");
+        a.y_bytes = (unsigned)yb;
+        a.r_bytes = (unsigned)rb;
+    }
     a.partial = nullptr;
     if (split_k > 1) {
         const size_t need = (size_t)split_k * a.M * a.ldy * sizeof(float);
@@ -539,6 +585,15 @@ extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const fl
     a.ldw = d->Kc; a.kB = d->Kc; a.w_rows = d->Co_pad; a.w_tap_stride = (long long)d->Co_pad * d->Kc;
     a.M = d->N * d->To * d->Ho * d->Wo;
     a.flags = d->flags;
+    {
+        const uint64_t xb = (uint64_t)d->N * d->Ti * d->Hi * d->Wi * d->ldx * 4ull;
+        const uint64_t wb = (uint64_t)d->kT * d->kH * d->kW * d->Co_pad * d->Kc * 4ull;
+        if (xb >= 0x80000000ull || wb >= 0x80000000ull)
+            return fail(PTX_ERR_UNSUPPORTED, "conv3d: input (%llu B) and packed filter (%llu B) must each be < 2 GiB "
+                        "(32-bit buffer offsets); split the batch", (unsigned long long)xb, (unsigned long long)wb);
+        a.x_bytes = (unsigned)xb;
+        a.w_bytes = (unsigned)wb;
+    }
     a.ldr = d->ldr; a.res_C = d->res_C; a.res_T = d->res_T; a.res_H = d->res_H; a.res_W = d->res_W;
     a.res_sT = d->res_sT; a.res_sH = d->res_sH; a.res_sW = d->res_sW;
     return launch_conv(a, config, split_k, 1, workspace, workspace_bytes, (hipStream_t)stream);
@@ -563,6 +618,13 @@ extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t ba
     a.ldw = ldb; a.kB = k4; a.w_rows = Nn; a.w_tap_stride = 0;
     a.M = M; a.flags = 0;
     a.bs_x = strideA; a.bs_w = strideB; a.bs_y = strideC;
+    {
+        const uint64_t xb = (uint64_t)M * lda * 4ull, wb = (uint64_t)Nn * ldb * 4ull;
+        if (xb >= 0x80000000ull || wb >= 0x80000000ull)
+            return fail(PTX_ERR_UNSUPPORTED, "bgemm: one batch item of A / B must be < 2 GiB");
+        a.x_bytes = (unsigned)xb;
+        a.w_bytes = (unsigned)wb;
+    }
     // C columns [Nn, ldc) are written as zero (B rows >= Nn are read as zero)
     const int64_t blocks128 = cdiv64(M, 128) * cdiv(ldc, 128) * batch;
     const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 0 : 2;

@@ -542,6 +542,7 @@ class Engine:
             plan.run_features(x.contiguous())      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
             seen = {}
+            log = open(os.environ["PTX_TUNE_LOG"], "w") if os.environ.get("PTX_TUNE_LOG") else None
             for stp in plan.conv_steps:
                 key = json.dumps(stp.d.key())
                 if key in seen:
@@ -582,6 +583,10 @@ class Engine:
                         e1.record()
                         e1.synchronize()
                         ms = e0.elapsed_time(e1) / iters
+                        if log is not None:
+                            log.write("%s\tM=%d\tN=%d\tK=%d\t%s\tsplit=%d\t%.4f ms\t%.1f TF\n" % (
+                                stp.label, M, stp.d.Co, stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, name, sk, ms,
+                                2e-9 * stp.macs / ms))
                         if best is None or ms < best[0]:
                             best = (ms, cfg, sk)
                 stp.cfg, stp.split = best[1], best[2]
@@ -593,6 +598,8 @@ class Engine:
                         lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
                         2e-9 * stp.macs / best[0]))
             plan.run_features(x.contiguous())
+            if log is not None:
+                log.close()
         if persist:
             save_tuned_table()
         return plan
