@@ -43,7 +43,7 @@ typedef void* ptx_stream_t; /* hipStream_t */
 #define PTX_EPI_RES_ADD 2u   /* + residual, same shape as y   (resnet3D.py:141 `out += residual`) */
 #define PTX_EPI_RES_PADA 4u  /* + shortcut-A residual: strided subsample of `res`, zero channels
                                 above res_C              (resnet3D.py:65-74, nonlocalnet.py:322) */
-#define PTX_PRO_RELU 8u      /* ReLU on the input operand while loading (trn.py:39-45)           */
+#define PTX_PRO_RELU 8u      /* ptx_linear_fwd only: ReLU on the input while loading (trn.py:39-45) */
 #define PTX_EPI_ACCUM 16u    /* ptx_linear_fwd only: y += result (trn.py:110 stack(...).sum(0))   */
 
 const char* ptx_version(void);
@@ -66,7 +66,7 @@ typedef struct ptx_conv3d_desc {
     int32_t pT, pH, pW;      /* zero padding                                      */
     int32_t Kc;              /* packed-weight K extent per tap  (>= Ci, multiple of the pack granule) */
     int32_t Co_pad;          /* packed-weight row count per tap (>= Co, multiple of 128)              */
-    uint32_t flags;          /* PTX_EPI_* | PTX_PRO_*                             */
+    uint32_t flags;          /* PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_EPI_RES_PADA */
     /* residual operand (PTX_EPI_RES_ADD: ldr only; PTX_EPI_RES_PADA: all fields) */
     int32_t ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
 } ptx_conv3d_desc;

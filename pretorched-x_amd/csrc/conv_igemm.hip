@@ -20,6 +20,7 @@
 // fp32 in, fp32 accumulate, bit-exact k-ordered fma chain (cdna_hip_programming.md section 3).
 #include "ptx_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ptx {
 
@@ -39,6 +40,7 @@ struct ConvArgs {
     int ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
     int m_tiles, n_tiles, split_k, kchunks;
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
+    int ablate;   // diagnostics only (PTX_ABLATE env): 1 no global loads, 2 no LDS stores/barrier, 4 no LDS reads
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -84,11 +86,12 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL>
+__global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NT = 64 * WM * WN;         // threads per workgroup (4 or 8 waves)
+    static_assert(NT >= 256 && NT <= 512, "4 to 8 waves per workgroup");
     constexpr int LDK = BK + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     static_assert(KSUB * 4 * KG == BK, "BK must be a multiple of 4*KG");
     constexpr int F4R = BK / 4;              // float4 per tile row
     constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
-    constexpr int A_IT = (A_F4 + 255) / 256, B_IT = (B_F4 + 255) / 256;
+    constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][LDK]
@@ -119,14 +122,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const float* __restrict__ xg = p.x + (size_t)zb * p.bs_x;
     const float* __restrict__ wg = p.w + (size_t)zb * p.bs_w;
 
-    // ---- per-thread A rows: output position -> top-left input coordinate (tap independent) ----
-    // a_pos = linear input position of the window origin; rows outside M get a_t0 = "minus infinity"
-    // so that every tap fails the bounds test.
-    int a_pos[A_IT], a_t0[A_IT], a_h0[A_IT], a_w0[A_IT];
+    // ---- per-thread operand rows (tap independent, computed once) ----
+    // fp32 MFMA shares the FP32 datapath with VALU, so VALU work in the k-loop costs MFMA cycles:
+    // everything per-lane is hoisted here.  For each A row this thread stages:
+    //   a_off  = byte offset of the row's CENTRE tap (kt,kh,kw) = (pT,pH,pW) -- always inside the
+    //            image for a valid row -- plus this thread's channel column; kOOB for rows >= M;
+    //   a_mask = separable validity bitmasks: bit kt | bit 8+kh | bit 16+kw set iff that tap
+    //            coordinate lands inside the image.
+    // A k-step then needs 4 VALU per load: and, cmp (mask test), add (uniform tap offset), cndmask.
+    constexpr unsigned kOOB = 0x80000000u;
+    unsigned a_off[A_IT], a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         const int row = idx / F4R;
+        const int col = (idx % F4R) * 4;
         const int m = m0 + row;
         const bool ok = (idx < A_F4) && (m < p.M);
         const int mm = ok ? m : 0;
@@ -136,10 +146,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         t /= p.Ho;
         const int to = t % p.To;
         const int n = t / p.To;
-        a_t0[i] = ok ? to * p.sT - p.pT : -0x40000000;
-        a_h0[i] = ho * p.sH - p.pH;
-        a_w0[i] = wo * p.sW - p.pW;
-        a_pos[i] = ((n * p.Ti + (to * p.sT - p.pT)) * p.Hi + a_h0[i]) * p.Wi + a_w0[i];
+        const int tc = to * p.sT, hc = ho * p.sH, wc = wo * p.sW;      // centre-tap input coordinate
+        unsigned mask = 0;
+        for (int k = 0; k < p.kT; ++k) mask |= ((unsigned)(tc - p.pT + k) < (unsigned)p.Ti ? 1u : 0u) << k;
+        for (int k = 0; k < p.kH; ++k) mask |= ((unsigned)(hc - p.pH + k) < (unsigned)p.Hi ? 1u : 0u) << (8 + k);
+        for (int k = 0; k < p.kW; ++k) mask |= ((unsigned)(wc - p.pW + k) < (unsigned)p.Wi ? 1u : 0u) << (16 + k);
+        const unsigned cpos = (unsigned)(((n * p.Ti + tc) * p.Hi + hc) * p.Wi + wc);
+        a_off[i] = ok ? (cpos * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
+        a_mask[i] = ok ? mask : 0u;
+    }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + NT * i;
+        const int row = idx / F4R;
+        const int col = (idx % F4R) * 4;
+        const bool ok = idx < B_F4 && (n0 + row) < p.w_rows;
+        b_off[i] = ok ? ((unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)col) * 4u : kOOB;
     }
 
     // ---- block-uniform tap pruning: taps that only ever see zero padding are skipped ----
@@ -191,41 +214,36 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     };
 
     f32x4 ra[A_IT], rb[B_IT];
-    const bool pro_relu = (p.flags & PTX_PRO_RELU) != 0;
-
     // Branch-free operand loads through buffer resources: an element that must read as zero
-    // (tap outside the image, row >= M, channel tail) gets byte offset kOOB >= num_records, for
-    // which the hardware returns 0 without touching memory.  (Extents are validated < 2 GiB.)
-    constexpr unsigned kOOB = 0x80000000u;
+    // (tap outside the image, row >= M, channel tail) gets a byte offset >= kOOB >= num_records,
+    // for which the hardware returns 0 without touching memory.  (Extents are validated < 2 GiB.)
     const __amdgpu_buffer_rsrc_t rsrc_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, p.w_bytes, 0x00020000);
 
-    // issue the global loads of k-step (kt, kh, kw, ch) into registers
+    // issue the global loads of k-step (kt, kh, kw, ch) into registers; `valid` == false turns
+    // every load into an OOB (zero, no traffic) access
     auto load_tiles = [&](bool valid) {
         const int tap = (kt * p.kH + kh) * p.kW + kw;
         const int c0 = ch * BK;
-        const int tap_off = (kt * p.Hi + kh) * p.Wi + kw;
+        // uniform: tap selector for the mask test, signed byte offset of the tap from the centre
+        const unsigned sel = valid ? ((1u << kt) | (1u << (8 + kh)) | (1u << (16 + kw))) : 0xFFFFFFFFu;
+        const unsigned s_off =
+            (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.ldx + c0) * 4);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + 256 * i;
-            const int col = (idx % F4R) * 4;
-            const int ti = a_t0[i] + kt, hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-            const bool ok = valid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
-                            (unsigned)wi < (unsigned)p.Wi && (c0 + col) < p.kA;
-            const unsigned off = ((unsigned)(a_pos[i] + tap_off) * (unsigned)p.ldx + (unsigned)(c0 + col)) * 4u;
+            bool ok = (a_mask[i] & sel) == sel;
+            if (KTAIL) ok = ok && (c0 + (int)(((tid + NT * i) % F4R) * 4)) < p.kA;
+            const unsigned off = a_off[i] + s_off;
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0));
         }
-        const unsigned wbase = (unsigned)((size_t)tap * p.w_tap_stride) + (unsigned)c0;
+        const unsigned s_woff = valid ? (unsigned)(((size_t)tap * p.w_tap_stride + c0) * 4) : kOOB;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / F4R;
-            const int col = (idx % F4R) * 4;
-            const bool ok = valid && idx < B_F4 && (n0 + row) < p.w_rows && (c0 + col) < p.kB;
-            const unsigned off = (wbase + (unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)col) * 4u;
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, ok ? off : kOOB, 0, 0));
+            unsigned off = b_off[i] + s_woff;
+            if (KTAIL) off = (c0 + (int)(((tid + NT * i) % F4R) * 4)) < p.kB ? off : kOOB;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
         }
     };
 
@@ -234,19 +252,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < A_F4) {
-                f32x4 v = ra[i];
-                if (pro_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *reinterpret_cast<f32x4*>(Ab + (idx / F4R) * LDK + (idx % F4R) * 4) = v;
-            }
+            const int idx = tid + NT * i;
+            if (idx < A_F4) *reinterpret_cast<f32x4*>(Ab + (idx / F4R) * LDK + (idx % F4R) * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NT * i;
             if (idx < B_F4) *reinterpret_cast<f32x4*>(Bb + (idx / F4R) * LDK + (idx % F4R) * 4) = rb[i];
         }
     };
@@ -300,13 +311,26 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         store_tiles(0);
         __syncthreads();
         int buf = 0;
-        for (int it = 1; it <= my_steps; ++it) {
-            load_tiles(it < my_steps);
-            advance();
-            compute(buf);
-            store_tiles(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+        if (p.ablate == 0) {
+            for (int it = 1; it <= my_steps; ++it) {
+                load_tiles(it < my_steps);
+                advance();
+                compute(buf);
+                store_tiles(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {   // diagnostics: timing with pieces of the pipeline removed (results are garbage)
+            for (int it = 1; it <= my_steps; ++it) {
+                if (!(p.ablate & 1)) load_tiles(it < my_steps);
+                advance();
+                compute(buf);
+                if (!(p.ablate & 2)) {
+                    store_tiles(buf ^ 1);
+                    __syncthreads();
+                }
+                buf ^= 1;
+            }
         }
     }
 
@@ -388,10 +412,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT>
-static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL>
+static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -400,8 +424,15 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, a);
     return hip_check(hipGetLastError(), "conv_igemm launch");
+}
+
+// KTAIL instantiation only when the K extent of either operand is not a multiple of BK
+template <int BM, int BN, int BK, int WM, int WN, int MT>
+static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false>(a, grid, st);
 }
 
 struct ConvConfig {
@@ -425,6 +456,15 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG(112, 128, 32, 1, 4, 16),  // 8  M = 2^k * 49, Co >= 128
     PTX_CFG(64, 64, 16, 2, 2, 32),    // 9  ragged channel counts ((2+1)D), small K chunk
     PTX_CFG(128, 64, 16, 2, 2, 32),   // 10 ragged channel counts, larger M
+    // 8-wave workgroups: big tiles (fewer bytes moved per MFMA) at 4 waves per SIMD
+    PTX_CFG(128, 128, 32, 2, 4, 32),  // 11
+    PTX_CFG(128, 128, 32, 4, 2, 32),  // 12
+    PTX_CFG(128, 64, 32, 4, 2, 32),   // 13
+    PTX_CFG(256, 64, 32, 8, 1, 32),   // 14
+    PTX_CFG(256, 128, 32, 4, 2, 32),  // 15
+    PTX_CFG(256, 64, 24, 8, 1, 32),   // 16 stem
+    PTX_CFG(128, 64, 24, 4, 2, 32),   // 17 stem
+    PTX_CFG(224, 64, 32, 7, 1, 32),   // 18 M = 2^k * 49 (7 x 32 rows), 7 waves
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -439,6 +479,8 @@ static int validate_desc(const ptx_conv3d_desc* d) {
     if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 ||
         d->pH < 0 || d->pW < 0)
         return fail(PTX_ERR_INVALID, "conv3d: bad filter geometry");
+    if (d->kT > 8 || d->kH > 8 || d->kW > 8)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: filter extents above 8 are not supported (%d,%d,%d)", d->kT, d->kH, d->kW);
     if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < d->ldy)
         return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d ldy=%d",
                     d->Kc, d->Co_pad, d->Ci, d->ldy);
@@ -530,6 +572,11 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         a.r_bytes = (unsigned)rb;
     }
     a.partial = nullptr;
+    {
+        static int ablate = -1;
+        if (ablate < 0) { const char* e = getenv("PTX_ABLATE"); ablate = e ? atoi(e) : 0; }
+        a.ablate = ablate;
+    }
     if (split_k > 1) {
         const size_t need = (size_t)split_k * a.M * a.ldy * sizeof(float);
         if (!workspace || workspace_bytes < need)
@@ -568,6 +615,8 @@ extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const fl
         if (split_k <= 0) split_k = sk;
     }
     if (split_k <= 0) split_k = 1;
+    if (d->flags & PTX_PRO_RELU)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: PTX_PRO_RELU is only implemented by ptx_linear_fwd");
     if (d->flags & PTX_EPI_RES_ADD) {
         if (d->ldr < d->ldy) return fail(PTX_ERR_INVALID, "conv3d: residual stride %d < ldy %d", d->ldr, d->ldy);
     }
