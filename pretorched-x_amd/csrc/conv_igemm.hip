@@ -273,63 +273,63 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (lane / MT) * 4;
     const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (lane / MT) * 4;
 
-    auto compute = [&](int buf) {
-        const float* Ab = As + buf * BM * LDK + frag_off_a;
-        const float* Bb = Bs + buf * BN * LDK + frag_off_b;
-        // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks are issued
-        f32x4 a[2][TM], b[2][TN];
+    // fragment registers, rotated across sub-steps.  The slot sequence must close on itself at the
+    // step boundary with compile-time indices: 2 slots for an even sub-step count, KSUB for odd.
+    static_assert(KSUB >= 2, "at least two sub-steps per k-step");
+    constexpr int NSLOT = (KSUB % 2) ? KSUB : 2;
+    f32x4 fa[NSLOT][TM], fb[NSLOT][TN];
+    auto read_frags = [&](int buf, int ks, int slot) {
+        const float* Ab = As + buf * BM * LDK + frag_off_a + ks * 4 * KG;
+        const float* Bb = Bs + buf * BN * LDK + frag_off_b + ks * 4 * KG;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
+    };
+    auto mma_frags = [&](int slot) {
 #pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KSUB) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + (ks + 1) * 4 * KG);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + (ks + 1) * 4 * KG);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[cur][i][r], b[cur][j][r], acc[i][j]);
-        }
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[slot][i][r], fb[slot][j][r], acc[i][j]);
     };
 
-    // ---- main loop: register-staged double buffering, one barrier per k-step.  The body is one
-    // basic block: the loads of step s+1 are issued unconditionally (all-OOB on the last step, which
-    // costs no memory traffic) so the scheduler can interleave them with the MFMAs of step s. ----
+    // ---- main loop.  Register-staged double buffering with the k-step software-pipelined inside
+    // the wave so the MFMA stream never drains at the step boundary:
+    //   sub-step 0        : MFMAs on fragments already in registers, next fragments requested
+    //   sub-step STORE_KS : tile s+1 (loaded during step s-1) is written to the other LDS buffer and
+    //                       the global loads of tile s+2 are issued -- under this step's MFMAs
+    //   last sub-step     : lgkmcnt(0) + barrier, first fragments of step s+1 requested, then the
+    //                       last MFMAs of step s (their fragments were fetched before the barrier)
+    // Safety with 2 LDS buffers: after the barrier of step s-1 nobody reads buffer (s-1)&1 again
+    // (its last fragments were completed before that barrier), so step s may overwrite it; those
+    // writes complete (lgkmcnt(0)) before the barrier of step s, after which step s+1 reads them.
+    constexpr int STORE_KS = KSUB >= 3 ? 1 : 0;
     if (my_steps > 0) {
         load_tiles(true);
         advance();
         store_tiles(0);
+        load_tiles(my_steps > 1);
+        advance();
         __syncthreads();
-        int buf = 0;
-        if (p.ablate == 0) {
-            for (int it = 1; it <= my_steps; ++it) {
-                load_tiles(it < my_steps);
-                advance();
-                compute(buf);
-                store_tiles(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
-        } else {   // diagnostics: timing with pieces of the pipeline removed (results are garbage)
-            for (int it = 1; it <= my_steps; ++it) {
-                if (!(p.ablate & 1)) load_tiles(it < my_steps);
-                advance();
-                compute(buf);
-                if (!(p.ablate & 2)) {
-                    store_tiles(buf ^ 1);
+        read_frags(0, 0, 0);
+        for (int it = 0; it < my_steps; ++it) {
+            const int buf = it & 1;
+#pragma unroll
+            for (int ks = 0; ks < KSUB; ++ks) {
+                if (ks == KSUB - 1) {
                     __syncthreads();
+                    read_frags(buf ^ 1, 0, (ks + 1) % NSLOT);
+                } else {
+                    read_frags(buf, ks + 1, (ks + 1) % NSLOT);
                 }
-                buf ^= 1;
+                if (ks == STORE_KS) {
+                    store_tiles(buf ^ 1);
+                    load_tiles(it + 2 < my_steps);
+                    advance();
+                }
+                mma_frags(ks % NSLOT);
             }
         }
     }
