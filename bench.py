@@ -64,6 +64,9 @@ def main():
     eng = model.engine()
     if not args.no_autotune:
         eng.autotune(model, x, iters=2, verbose=args.verbose and rank == 0)
+        if rank == 0 and os.environ.get("PTX_TUNED_OUT"):
+            from pretorched_x_amd.engine import save_tuned_table
+            save_tuned_table(os.environ["PTX_TUNED_OUT"])
 
     def step():
         out = model(x)

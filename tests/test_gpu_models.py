@@ -87,9 +87,10 @@ def test_config2_full_size_parity(ptx):
 
 
 def test_full_size_properties(ptx):
-    """Size-independent properties at the full config-2 shape: determinism, batch-permutation
-    equivariance (bit-exact: every output's k-order is position independent) and agreement of
-    B=8 with B=1 plans (different tiles / split-K -> fp32 reorder noise only)."""
+    """Size-independent properties at the full config-2 shape: determinism (bit-exact),
+    batch-permutation equivariance (split-K slices the tile's *pruned* k-space, so the grouping of
+    partial sums depends on where a clip's rows fall in a tile: fp32 reorder noise only) and
+    agreement of B=8 with B=1 plans (different tiles / split-K)."""
     model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), 77)
     x = synth_clips(8, 16, 224, 5).to(DEV)
     a = model(x)
@@ -97,7 +98,8 @@ def test_full_size_properties(ptx):
     assert torch.equal(a, b)
     perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
     c = model(x[perm].contiguous())
-    assert torch.equal(c, a[perm])
+    assert (c - a[perm]).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
+    assert torch.equal(c.argmax(1), a[perm].argmax(1))
     one = model(x[2:3].contiguous())
     assert (one - a[2:3]).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
 
