@@ -40,7 +40,7 @@ struct ConvArgs {
     int ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
     int m_tiles, n_tiles, split_k, kchunks;
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
-    int ablate;   // diagnostics only (PTX_ABLATE env): 1 no global loads, 2 no LDS stores/barrier, 4 no LDS reads
+    int unit_pointwise;   // 1x1x1 / stride 1 / pad 0: skip the position decode
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -139,6 +139,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const int col = (idx % F4R) * 4;
         const int m = m0 + row;
         const bool ok = (idx < A_F4) && (m < p.M);
+        if (p.unit_pointwise) {      // 1x1x1, stride 1, no padding: input position == output position
+            a_off[i] = ok ? ((unsigned)m * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
+            a_mask[i] = ok ? 0x00010101u : 0u;
+            continue;
+        }
         const int mm = ok ? m : 0;
         const int wo = mm % p.Wo;
         int t = mm / p.Wo;
@@ -273,6 +278,32 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (lane / MT) * 4;
     const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (lane / MT) * 4;
 
+    // ---- residual prefetch: for same-shape residual adds with few accumulator tiles per wave the
+    // residual values are requested BEFORE the k-loop, so their HBM latency hides under it ----
+    const bool to_partial = p.split_k > 1;
+    const bool res_add = !to_partial && (p.flags & PTX_EPI_RES_ADD);
+    constexpr bool kResEarly = (TM * TN * MF::NACC) <= 16;   // keeps multi-tile waves (stem) under 128 regs
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, res_add ? p.r_bytes : 0u, 0x00020000);
+    float rv[TM][TN][MF::NACC];
+    auto load_residual = [&](int i, int j) {
+        const int co = n0 + wn * WTN + j * MT + (lane % MT);
+        const int mrow = m0 + wm * WTM + i * MT;
+#pragma unroll
+        for (int r = 0; r < MF::NACC; ++r) {
+            const int m = mrow + MF::row(r, lane);
+            const unsigned off = ((unsigned)m * (unsigned)p.ldr + (unsigned)co) * 4u;
+            rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                        rsrc_r, (res_add && co < p.ldy && m < p.M) ? off : kOOB, 0, 0));
+        }
+    };
+    if (kResEarly) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_residual(i, j);
+    }
+
     // fragment registers, rotated across sub-steps.  The slot sequence must close on itself at the
     // step boundary with compile-time indices: 2 slots for an even sub-step count, KSUB for odd.
     static_assert(KSUB >= 2, "at least two sub-steps per k-step");
@@ -337,14 +368,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // ---- epilogue: bias + residual + ReLU, branch-free through buffer resources (out-of-range
     // stores are dropped, out-of-range loads read 0); residual values of a tile are requested in
     // one batch before they are consumed. ----
-    const bool to_partial = p.split_k > 1;
     float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ldy : p.y + (size_t)zb * p.bs_y;
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);
-    const bool res_add = !to_partial && (p.flags & PTX_EPI_RES_ADD);
     const bool res_pada = !to_partial && (p.flags & PTX_EPI_RES_PADA);
     const bool relu = !to_partial && (p.flags & PTX_EPI_RELU);
-    const __amdgpu_buffer_rsrc_t rsrc_r =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, res_add ? p.r_bytes : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn * WTN + j * MT + (lane % MT);
@@ -353,18 +380,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mrow = m0 + wm * WTM + i * MT;
-            float rv[MF::NACC];
+            if (!kResEarly) load_residual(i, j);
 #pragma unroll
             for (int r = 0; r < MF::NACC; ++r) {
                 const int m = mrow + MF::row(r, lane);
-                const unsigned off = ((unsigned)m * (unsigned)p.ldr + (unsigned)co) * 4u;
-                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rsrc_r, (res_add && co_ok && m < p.M) ? off : kOOB, 0, 0));
-            }
-#pragma unroll
-            for (int r = 0; r < MF::NACC; ++r) {
-                const int m = mrow + MF::row(r, lane);
-                float v = acc[i][j][r] + bv + rv[r];
+                float v = acc[i][j][r] + bv + rv[i][j][r];
                 if (res_pada && co < p.res_C && m < p.M) {     // shortcut A (BasicBlock / NL nets only)
                     const int wo = m % p.Wo;
                     int t = m / p.Wo;
@@ -465,6 +485,11 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG(256, 64, 24, 8, 1, 32),   // 16 stem
     PTX_CFG(128, 64, 24, 4, 2, 32),   // 17 stem
     PTX_CFG(224, 64, 32, 7, 1, 32),   // 18 M = 2^k * 49 (7 x 32 rows), 7 waves
+    PTX_CFG(32, 64, 32, 2, 2, 16),    // 19 small M: 32-row tiles (wave 16x32 on 16x16x4 MFMA)
+    PTX_CFG(32, 128, 32, 2, 2, 16),   // 20 small M, wide
+    PTX_CFG(128, 64, 16, 4, 2, 32),   // 21 short K, 8 waves
+    PTX_CFG(128, 128, 16, 4, 2, 32),  // 22 short K, 8 waves, wide
+    PTX_CFG(64, 128, 16, 2, 2, 32),   // 23 short K, wide
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -515,31 +540,34 @@ extern "C" int ptx_conv3d_config_supported(const ptx_conv3d_desc* d, int config)
 }
 
 extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
+    // Defaults distilled from Engine.autotune runs on MI355X (profiles/r01_*): 64x64 tiles at 4
+    // workgroups per CU win almost everywhere; the folded stem wants the 8-wave 256x64x24 tile; wide
+    // outputs with a large M take the 8-wave 128x128 tile; short K prefers BK = 16 (more workgroups
+    // in flight); small grids are widened with split-K.
     if (split_k) *split_k = 1;
     if (validate_desc(d) != PTX_OK) return 0;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     const int taps = d->kT * d->kH * d->kW;
     int cfg;
     if (d->Kc % 32 != 0 && d->Kc % 24 == 0) {
-        cfg = 6;
+        cfg = M >= 256 * 1024 ? 16 : 6;
     } else if (d->Kc % 32 != 0) {
         cfg = (M >= 64 * 1024) ? 10 : 9;
+    } else if (taps * d->Kc <= 128) {
+        cfg = 9;                                   // K <= 128: one or two k-steps of 32
+    } else if (d->ldy >= 128 && cdiv64(M, 128) * cdiv(d->ldy, 128) >= 4 * kNumCU) {
+        cfg = 12;
     } else {
-        const bool wide = d->ldy >= 128;
-        const int64_t big = cdiv64(M, 128) * cdiv(d->ldy, wide ? 128 : 64);
-        if (big >= 2 * kNumCU)
-            cfg = wide ? 0 : 1;
-        else
-            cfg = 2;
+        cfg = 2;
     }
     const ConvConfig& c = kConfigs[cfg];
     const int64_t blocks = cdiv64(M, c.BM) * cdiv(d->ldy, c.BN);
     const int steps = taps * cdiv(d->Kc, c.BK);
     int sk = 1;
-    if (blocks < kNumCU) {
-        sk = (int)((kNumCU + blocks - 1) / blocks);
+    if (blocks < 2 * kNumCU) {
+        sk = (int)((3 * kNumCU + blocks - 1) / blocks);
         if (sk > 8) sk = 8;
-        while (sk > 1 && steps / sk < 8) --sk;
+        while (sk > 1 && steps / sk < 12) --sk;
     }
     if (split_k) *split_k = sk;
     return cfg;
@@ -572,11 +600,8 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         a.r_bytes = (unsigned)rb;
     }
     a.partial = nullptr;
-    {
-        static int ablate = -1;
-        if (ablate < 0) { const char* e = getenv("PTX_ABLATE"); ablate = e ? atoi(e) : 0; }
-        a.ablate = ablate;
-    }
+    a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
+                        a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo) ? 1 : 0;
     if (split_k > 1) {
         const size_t need = (size_t)split_k * a.M * a.ldy * sizeof(float);
         if (!workspace || workspace_bytes < need)

@@ -555,7 +555,7 @@ class Engine:
                     name = lib.ptx_conv3d_config_name(cfg).decode()
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
                     if stp.d.Kc % 32 == 0:
-                        if bk != 32:
+                        if bk == 24:
                             continue
                     elif stp.d.Kc % 24 == 0:
                         if bk != 24:
@@ -563,6 +563,8 @@ class Engine:
                     elif bk == 24:
                         continue
                     if bn_ > 64 and stp.d.ldy <= 64:
+                        continue
+                    if bm >= 128 and M < 8192:
                         continue
                     blocks = ((M + bm - 1) // bm) * ((stp.d.ldy + bn_ - 1) // bn_)
                     splits = [1]
