@@ -41,6 +41,7 @@ struct ConvArgs {
     int m_tiles, n_tiles, split_k, kchunks;
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
     int unit_pointwise;   // 1x1x1 / stride 1 / pad 0: skip the position decode
+    int k_live;           // live (possibly non-zero) K columns per tap = desc.Ci
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
@@ -309,7 +310,32 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     static_assert(KSUB >= 2, "at least two sub-steps per k-step");
     constexpr int NSLOT = (KSUB % 2) ? KSUB : 2;
     f32x4 fa[NSLOT][TM], fb[NSLOT][TN];
+    // K22 (kW-folded stem: only 21 of the 24 k of a chunk carry data): the last sub-step covers
+    // k = 16..21 with two 8-byte reads per row -- lane group g gets (16+2g, 17+2g) and (20+2g, 21+2g)
+    // -- and 3 MFMAs pairing (16,18) (17,19) (20,22); the pair (21,23) is all padding and is dropped:
+    // 11 instead of 12 MFMAs per tap.
+    static_assert(!K22 || (BK == 24 && MT == 32), "K22 is the BK = 24 / 32x32x2 stem path");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int frag22_a = (wm * WTM + (lane % MT)) * LDK + 16 + (lane / MT) * 2;
+    const int frag22_b = (wn * WTN + (lane % MT)) * LDK + 16 + (lane / MT) * 2;
     auto read_frags = [&](int buf, int ks, int slot) {
+        if (K22 && ks == KSUB - 1) {
+            const float* Ab = As + buf * BM * LDK + frag22_a;
+            const float* Bb = Bs + buf * BN * LDK + frag22_b;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + 4);
+                fa[slot][i] = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + 4);
+                fb[slot][j] = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+            return;
+        }
         const float* Ab = As + buf * BM * LDK + frag_off_a + ks * 4 * KG;
         const float* Bb = Bs + buf * BN * LDK + frag_off_b + ks * 4 * KG;
 #pragma unroll
@@ -317,13 +343,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
     };
-    auto mma_frags = [&](int slot) {
+    auto mma_frags = [&](int slot, int nr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            if (r < nr) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[slot][i][r], fb[slot][j][r], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[slot][i][r], fb[slot][j][r], acc[i][j]);
+            }
+        }
     };
 
     // ---- main loop.  Register-staged double buffering with the k-step software-pipelined inside
@@ -360,7 +389,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     load_tiles(it + 2 < my_steps);
                     advance();
                 }
-                mma_frags(ks % NSLOT);
+                mma_frags(ks % NSLOT, (K22 && ks == KSUB - 1) ? 3 : 4);
             }
         }
     }
@@ -432,10 +461,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -451,8 +480,12 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
 template <int BM, int BN, int BK, int WM, int WN, int MT>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true>(a, grid, st);
-    return launch_one<BM, BN, BK, WM, WN, MT, false>(a, grid, st);
+    if constexpr (BK == 24 && MT == 32) {
+        // kW-folded stem: one 24-wide chunk per tap of which at most 22 columns are live
+        if (a.k_live <= 22 && a.kA == 24 && a.kB == 24) return launch_one<BM, BN, BK, WM, WN, MT, false, true>(a, grid, st);
+    }
+    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false>(a, grid, st);
 }
 
 struct ConvConfig {
@@ -653,7 +686,7 @@ extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const fl
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.y = y;
     a.N = d->N; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx; a.kA = d->ldx;
-    a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
+    a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy; a.k_live = d->Ci;
     a.kT = d->kT; a.kH = d->kH; a.kW = d->kW; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW;
     a.pT = d->pT; a.pH = d->pH; a.pW = d->pW;
     a.ldw = d->Kc; a.kB = d->Kc; a.w_rows = d->Co_pad; a.w_tap_stride = (long long)d->Co_pad * d->Kc;
@@ -687,7 +720,7 @@ extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t ba
     ConvArgs a{};
     a.x = A; a.w = B; a.bias = nullptr; a.res = nullptr; a.y = C;
     a.N = 1; a.Ti = 1; a.Hi = 1; a.Wi = M; a.ldx = lda; a.kA = k4;
-    a.To = 1; a.Ho = 1; a.Wo = M; a.Co = Nn; a.ldy = ldc;
+    a.To = 1; a.Ho = 1; a.Wo = M; a.Co = Nn; a.ldy = ldc; a.k_live = K;
     a.kT = a.kH = a.kW = 1; a.sT = a.sH = a.sW = 1; a.pT = a.pH = a.pW = 0;
     a.ldw = ldb; a.kB = k4; a.w_rows = Nn; a.w_tap_stride = 0;
     a.M = M; a.flags = 0;

@@ -271,7 +271,9 @@ class Plan:
         (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
         Wo = (raw.W + 2 * pW - kW) // sW + 1
         ld = max(_r4(kW * raw.C), 24) if kW * raw.C <= 24 else _r4(kW * raw.C)
-        y = self.act(raw.N, raw.T, raw.H, Wo, ld, ld)
+        # C = live folded columns (kW * Cin = 21 for the RGB stem); the kernel drops the MFMAs that
+        # would only multiply the zero pad columns [C, ld)
+        y = self.act(raw.N, raw.T, raw.H, Wo, kW * raw.C, ld)
         lib, yp = self.lib, _ptr(y.t)
         N, C_, T, H, W = raw.N, raw.C, raw.T, raw.H, raw.W
 

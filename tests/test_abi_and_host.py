@@ -120,7 +120,7 @@ def test_plan_compiler_matches_survey_worklist(ptx):
     assert len(geom) == 23                                        # C4 covers conv3 and the shortcut
     assert tuple(plan.feat.t.shape) == (8, 1, 7, 7, 2048)
     stem = plan.conv_steps[0].d
-    assert (stem.Ci, stem.kT, stem.kH, stem.kW, stem.Kc) == (24, 7, 7, 1, 24)   # kW folded into channels
+    assert (stem.Ci, stem.ldx, stem.kT, stem.kH, stem.kW, stem.Kc) == (21, 24, 7, 7, 1, 24)   # kW folded into channels
     for name, shape, gm in [("r2plus1d50", (1, 3, 32, 112, 112), 21.158), ("nonlocalresnet3d50", (1, 3, 32, 112, 112), 22.433),
                             ("nonlocal_r2plus1d50", (1, 3, 32, 112, 112), 24.035), ("resnet18", (1, 3, 224, 224), 1.8136)]:
         kw = dict(pretrained=None) if name in ("nonlocalresnet3d50", "resnet18") else {}

@@ -213,10 +213,11 @@ def test_stem_fold_path(ptx):
     wd = w.to(DEV)
     L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
                                      C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack")
-    for cfg in (-1, 6, 7, 1, 9):
+    # live = 21 selects the 11-MFMA-per-tap stem path on BK = 24 tiles; 24 the generic one
+    for cfg, live in ((-1, 21), (6, 21), (7, 24), (16, 21), (17, 21), (17, 24), (1, 21), (9, 24)):
         yd = torch.full((N, T, Ho, Wo, 64), float("nan"), device=DEV)
         d = L.ConvDesc()
-        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, Wo, 24, 24
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, Wo, live, 24
         d.To, d.Ho, d.Wo, d.Co, d.ldy = T, Ho, Wo, 64, 64
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 7, 7, 1, 1, 2, 1, 3, 3, 0
         d.Kc, d.Co_pad, d.flags = 24, 128, L.PTX_EPI_RELU
