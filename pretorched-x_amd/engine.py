@@ -175,7 +175,7 @@ class Plan:
         self.ws_ptr = C.c_void_p(0)
         self.in_ptr = C.c_void_p(0)      # set per run
         self.keepalive = []
-        self.graph = None
+        self.tuned = False
         with _device_ctx(dev):
             self._build(model)
             if self.ws_bytes:
@@ -416,6 +416,9 @@ class Engine:
         self._lock = threading.RLock()
         self._sig = {}
         self.check_weights = True
+        # tile configurations of conv problems that are not in the tuned table are timed (HIP events,
+        # < 1 s per network) the first time a plan runs; PTX_AUTOTUNE=0 keeps the heuristic defaults
+        self.auto_tune = os.environ.get("PTX_AUTOTUNE", "1") != "0"
 
     def __deepcopy__(self, memo):
         return Engine()
@@ -480,6 +483,7 @@ class Engine:
         x = x.contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
+            self._maybe_tune(model, plan, x)
             f = plan.run_features(x)
             if model.arch.dims == 2:
                 out = torch.empty((f.N, f.C, f.H, f.W), device=x.device, dtype=torch.float32)
@@ -518,12 +522,19 @@ class Engine:
                 out = model.head_module(pooled)
         return out
 
+    def _maybe_tune(self, model, plan, x):
+        if self.auto_tune and not plan.tuned:
+            plan.tuned = True
+            if any(json.dumps(s.d.key()) not in _tuned_table() for s in plan.conv_steps):
+                self.autotune(model, x, iters=2, only_untuned=True)
+
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""
         self._validate(model, x, model.arch.dims)
         x = x.contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
+            self._maybe_tune(model, plan, x)
             f = plan.run_features(x)
             check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
                   "ptx_global_avgpool")
@@ -533,7 +544,7 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------
-    def autotune(self, model, x, iters=3, verbose=False, persist=False):
+    def autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False):
         """Time every compiled tile configuration (x a few split-K factors) for each distinct conv
         problem of the plan with HIP events and keep the fastest."""
         self._validate(model, x, model.arch.dims)
@@ -541,6 +552,7 @@ class Engine:
         table = _tuned_table()
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x.contiguous())
+            plan.tuned = True
             plan.run_features(x.contiguous())      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
             seen = {}
@@ -549,6 +561,8 @@ class Engine:
                 key = json.dumps(stp.d.key())
                 if key in seen:
                     stp.cfg, stp.split = seen[key]
+                    continue
+                if only_untuned and key in table:
                     continue
                 best = None
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)

@@ -35,9 +35,15 @@ def _is_closing_bn(prefix, keys):
     return False
 
 
-def synth_state_dict(template, seed=1234):
+def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=NL_BN_DAMP, inner_bn_damp=1.0):
     """template: mapping key -> tensor (only shape/dtype are used). Returns an OrderedDict of
-    fresh CPU fp32 tensors with the same keys/shapes."""
+    fresh CPU fp32 tensors with the same keys/shapes.
+
+    The damping factors scale BN gammas so that logits of deep random-weight networks stay in the
+    calibrated 10-30 range (SURVEY.md 8d "re-calibrate per model"): `last_bn_damp` for the BN that
+    closes a residual branch, `nl_bn_damp` for the non-local block's output BN (`W.1`),
+    `inner_bn_damp` for the BN inside a (2+1)D factored conv pair (`*.bn`).  Fixtures record the
+    values they were generated with."""
     keys = set(template.keys())
     out = OrderedDict()
     for key, ref in template.items():
@@ -50,9 +56,11 @@ def synth_state_dict(template, seed=1234):
         elif is_bn and leaf == "weight":
             v = torch.rand(shape, generator=g) + 0.5
             if prefix.endswith(".W.1"):
-                v = v * NL_BN_DAMP
+                v = v * nl_bn_damp
+            elif prefix.endswith(".bn") and (prefix[:-3] + ".spatial_conv.weight") in keys:
+                v = v * inner_bn_damp
             elif _is_closing_bn(prefix, keys):
-                v = v * LAST_BN_DAMP
+                v = v * last_bn_damp
             out[key] = v
         elif is_bn and leaf == "bias":
             out[key] = torch.randn(shape, generator=g) * 0.1

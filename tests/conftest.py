@@ -50,7 +50,18 @@ GOLDEN_CASES = {
     "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "resnet18_cfg1": ("resnet18", dict(num_classes=1000, pretrained=None)),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
+    "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
+    "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),
+    "nonlocalresnet3d50_cfg3": ("nonlocalresnet3d50", dict(pretrained=None)),
 }
+FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3")
+
+
+def golden_recipe(blob):
+    """kwargs of synth_state_dict the fixture was generated with (seed + BN damping)."""
+    import json
+    kw = json.loads(str(blob["recipe"])) if "recipe" in blob.files else {}
+    return dict(seed=int(blob["w_seed"]), **kw)
 
 
 def golden_input(blob):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, golden_input, load_golden
+from conftest import GOLDEN_CASES, golden_input, golden_recipe, load_golden
 from oracle import functional as OF
 from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
@@ -19,9 +19,9 @@ DEV = "cuda:0"
 TOL = 1e-3
 
 
-def _build(ptx, arch, kw, seed):
+def _build(ptx, arch, kw, seed, **recipe):
     model = ptx.__dict__[arch](**kw)
-    sd = synth_state_dict(model.state_dict(), seed)
+    sd = synth_state_dict(model.state_dict(), seed, **recipe)
     model.load_state_dict(sd)
     return model.to(DEV).eval(), sd
 
@@ -35,7 +35,8 @@ def _check(got, want, what, tol=TOL):
     return err
 
 
-SMALL = [c for c in GOLDEN_CASES if c != "resnet3d50_cfg2"]
+from conftest import FULL_SIZE
+SMALL = [c for c in GOLDEN_CASES if c not in FULL_SIZE]
 
 
 @pytest.mark.parametrize("case", SMALL)
@@ -84,6 +85,22 @@ def test_config2_full_size_parity(ptx):
     assert abs(f.sum().item() - float(blob["feat_sum"])) <= 1e-4 * float(blob["feat_abs_sum"])
     assert abs(f.abs().sum().item() - float(blob["feat_abs_sum"])) <= 1e-4 * float(blob["feat_abs_sum"])
     print("cfg2 max|dlogits| = %.3e (max|logit| %.2f)" % (err, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("case", [c for c in FULL_SIZE if c != "resnet3d50_cfg2"])
+def test_config3_full_size_parity(ptx, case):
+    """BASELINE.json config 3 (8x3x32x112x112): (2+1)D + non-local composite and its two parents,
+    against the real reference's logits (golden) at full size."""
+    arch, kw = GOLDEN_CASES[case]
+    blob = load_golden(case)
+    model, _ = _build(ptx, arch, kw, **golden_recipe(blob))
+    x = golden_input(blob)
+    out = model(x.to(DEV))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(blob["logits"])
+    err = _check(out, ref, case + " logits vs golden")
+    assert torch.equal(out.cpu().argmax(1), ref.argmax(1))
+    print("%s max|dlogits| = %.3e (max|logit| %.2f)" % (case, err, ref.abs().max().item()))
 
 
 def test_full_size_properties(ptx):

@@ -21,7 +21,10 @@ def _arch_sd(ptx, arch, kw, seed):
     return model.arch, synth_state_dict(model.state_dict(), seed)
 
 
-@pytest.mark.parametrize("case", [c for c in GOLDEN_CASES if c != "resnet3d50_cfg2"])
+from conftest import FULL_SIZE
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN_CASES if c not in FULL_SIZE])
 def test_oracle_matches_golden(ptx, case):
     arch, kw = GOLDEN_CASES[case]
     blob = load_golden(case)
