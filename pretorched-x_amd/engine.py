@@ -570,13 +570,7 @@ class Engine:
                 for cfg in range(ncfg):
                     name = lib.ptx_conv3d_config_name(cfg).decode()
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
-                    if stp.d.Kc % 32 == 0:
-                        if bk == 24:
-                            continue
-                    elif stp.d.Kc % 24 == 0:
-                        if bk != 24:
-                            continue
-                    elif bk == 24:
+                    if (bk == 24) != (stp.d.Kc == 24):      # BK = 24 tiles are for the kW-folded stem only
                         continue
                     if bn_ > 64 and stp.d.ldy <= 64:
                         continue
@@ -607,6 +601,9 @@ class Engine:
                                 2e-9 * stp.macs / ms))
                         if best is None or ms < best[0]:
                             best = (ms, cfg, sk)
+                if best is None:                 # nothing admissible was timed: keep the heuristic default
+                    sk = C.c_int(1)
+                    best = (float("nan"), lib.ptx_conv3d_pick_config(C.byref(stp.d), C.byref(sk)), sk.value)
                 stp.cfg, stp.split = best[1], best[2]
                 seen[key] = (best[1], best[2])
                 table[key] = (best[1], best[2])
