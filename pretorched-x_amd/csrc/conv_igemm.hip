@@ -87,13 +87,18 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
     constexpr int NT = 64 * WM * WN;         // threads per workgroup (4 or 8 waves)
     static_assert(NT >= 256 && NT <= 512, "4 to 8 waves per workgroup");
-    constexpr int LDK = BK + 4;
+    // Register-staged tiles are padded by 4 floats per row (conflict-free ds_read_b128).  DMA tiles
+    // (buffer_load ... lds) must be lane-linear, i.e. unpadded: the bank-conflict fix moves into an
+    // XOR swizzle of the 16-byte slot index that is applied to the per-lane SOURCE address when
+    // loading and to the fragment read address (cdna_hip_programming.md rule 21).
+    constexpr int LDK = DMA ? BK : BK + 4;
+    static_assert(!DMA || (!K22 && (BK == 32 || BK == 16)), "DMA staging: BK 32 or 16");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
     static_assert(TM * MT * WM == BM && TN * MT * WN == BN, "tile must split evenly");
@@ -103,6 +108,14 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     constexpr int F4R = BK / 4;              // float4 per tile row
     constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
     constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
+    // swizzle: physical 16-B slot = logical slot ^ ((row >> SWS) & (F4R - 1)); with 128-B rows (F4R 8)
+    // SWS = 1, with 64-B rows (F4R 4) SWS = 2 -- any 16 distinct rows of a ds_read_b128 lane group
+    // then cover all 16 slots of the 256-B bank row.
+    constexpr int SWS = (F4R == 8) ? 1 : 2;
+    auto swz_col = [&](int idx) -> int {       // logical channel column fetched by staging slot idx
+        const int row = idx / F4R, ps = idx % F4R;
+        return (DMA ? (ps ^ ((row >> SWS) & (F4R - 1))) : ps) * 4;
+    };
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][LDK]
@@ -137,7 +150,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + NT * i;
         const int row = idx / F4R;
-        const int col = (idx % F4R) * 4;
+        const int col = swz_col(idx);
         const int m = m0 + row;
         const bool ok = (idx < A_F4) && (m < p.M);
         if (p.unit_pointwise) {      // 1x1x1, stride 1, no padding: input position == output position
@@ -166,7 +179,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + NT * i;
         const int row = idx / F4R;
-        const int col = (idx % F4R) * 4;
+        const int col = swz_col(idx);
         const bool ok = idx < B_F4 && (n0 + row) < p.w_rows;
         b_off[i] = ok ? ((unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)col) * 4u : kOOB;
     }
@@ -219,7 +232,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         kt += c3 ? 1 : 0;
     };
 
-    f32x4 ra[A_IT], rb[B_IT];
+    f32x4 ra[DMA ? 1 : A_IT], rb[DMA ? 1 : B_IT];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     // Branch-free operand loads through buffer resources: an element that must read as zero
     // (tap outside the image, row >= M, channel tail) gets a byte offset >= kOOB >= num_records,
     // for which the hardware returns 0 without touching memory.  (Extents are validated < 2 GiB.)
@@ -230,7 +245,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 
     // issue the global loads of k-step (kt, kh, kw, ch) into registers; `valid` == false turns
     // every load into an OOB (zero, no traffic) access
-    auto load_tiles = [&](bool valid) {
+    auto load_tiles = [&](bool valid, int dbuf = 0) {
         const int tap = (kt * p.kH + kh) * p.kW + kw;
         const int c0 = ch * BK;
         // uniform: tap selector for the mask test, signed byte offset of the tap from the centre
@@ -240,16 +255,29 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             bool ok = (a_mask[i] & sel) == sel;
-            if (KTAIL) ok = ok && (c0 + (int)(((tid + NT * i) % F4R) * 4)) < p.kA;
+            if (KTAIL) ok = ok && (c0 + swz_col(tid + NT * i)) < p.kA;
             const unsigned off = a_off[i] + s_off;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0));
+            if constexpr (DMA) {
+                // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
+                if (wave_u * 64 + NT * i < A_F4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsrc_x, (lds_ptr_t)(As + dbuf * BM * LDK + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
+            } else {
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0));
+            }
         }
         const unsigned s_woff = valid ? (unsigned)(((size_t)tap * p.w_tap_stride + c0) * 4) : kOOB;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             unsigned off = b_off[i] + s_woff;
-            if (KTAIL) off = (c0 + (int)(((tid + NT * i) % F4R) * 4)) < p.kB ? off : kOOB;
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+            if (KTAIL) off = (c0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
+            if constexpr (DMA) {
+                if (wave_u * 64 + NT * i < B_F4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsrc_w, (lds_ptr_t)(Bs + dbuf * BN * LDK + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
+            } else {
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+            }
         }
     };
 
@@ -276,8 +304,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
 
-    const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (lane / MT) * 4;
-    const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (lane / MT) * 4;
+    const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (DMA ? 0 : (lane / MT) * 4);
+    const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (DMA ? 0 : (lane / MT) * 4);
+    const int frag_sw = ((lane % MT) >> SWS) & (F4R - 1);       // DMA: row swizzle of this lane's rows
 
     // ---- residual prefetch: for same-shape residual adds with few accumulator tiles per wave the
     // residual values are requested BEFORE the k-loop, so their HBM latency hides under it ----
@@ -336,8 +365,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             }
             return;
         }
-        const float* Ab = As + buf * BM * LDK + frag_off_a + ks * 4 * KG;
-        const float* Bb = Bs + buf * BN * LDK + frag_off_b + ks * 4 * KG;
+        const int koff = DMA ? (((ks * KG + lane / MT) ^ frag_sw) * 4) : ks * 4 * KG;
+        const float* Ab = As + buf * BM * LDK + frag_off_a + koff;
+        const float* Bb = Bs + buf * BN * LDK + frag_off_b + koff;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
 #pragma unroll
@@ -366,6 +396,35 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // (its last fragments were completed before that barrier), so step s may overwrite it; those
     // writes complete (lgkmcnt(0)) before the barrier of step s, after which step s+1 reads them.
     constexpr int STORE_KS = KSUB >= 3 ? 1 : 0;
+    if constexpr (DMA) {
+        // LDS-DMA staging: no staging registers, no ds_write.  The DMA of tile s+2 is issued right
+        // after the barrier of step s (which frees buffer s&1: its last fragments were read before
+        // the barrier) and has a whole k-step to land before the barrier of step s+1 drains it
+        // (__syncthreads() carries the vmcnt(0) for the pending LDS writes).
+        if (my_steps > 0) {
+            load_tiles(true, 0);
+            advance();
+            __syncthreads();
+            load_tiles(my_steps > 1, 1);
+            advance();
+            read_frags(0, 0, 0);
+            for (int it = 0; it < my_steps; ++it) {
+                const int buf = it & 1;
+#pragma unroll
+                for (int ks = 0; ks < KSUB; ++ks) {
+                    if (ks == KSUB - 1) {
+                        __syncthreads();
+                        load_tiles(it + 2 < my_steps, buf);
+                        advance();
+                        read_frags(buf ^ 1, 0, (ks + 1) % NSLOT);
+                    } else {
+                        read_frags(buf, ks + 1, (ks + 1) % NSLOT);
+                    }
+                    mma_frags(ks % NSLOT, 4);
+                }
+            }
+        }
+    } else
     if (my_steps > 0) {
         load_tiles(true);
         advance();
@@ -461,10 +520,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -478,14 +537,15 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
-template <int BM, int BN, int BK, int WM, int WN, int MT>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    if constexpr (BK == 24 && MT == 32) {
+    if constexpr (BK == 24 && MT == 32 && !DMA) {
         // kW-folded stem: one 24-wide chunk per tap of which at most 22 columns are live
-        if (a.k_live <= 22 && a.kA == 24 && a.kB == 24) return launch_one<BM, BN, BK, WM, WN, MT, false, true>(a, grid, st);
+        if (a.k_live <= 22 && a.kA == 24 && a.kB == 24)
+            return launch_one<BM, BN, BK, WM, WN, MT, false, true, false>(a, grid, st);
     }
-    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false>(a, grid, st);
-    return launch_one<BM, BN, BK, WM, WN, MT, false, false>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA>(a, grid, st);
 }
 
 struct ConvConfig {
@@ -495,7 +555,9 @@ struct ConvConfig {
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false> }
+#define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true> }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -523,6 +585,15 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 64, 16, 4, 2, 32),   // 21 short K, 8 waves
     PTX_CFG(128, 128, 16, 4, 2, 32),  // 22 short K, 8 waves, wide
     PTX_CFG(64, 128, 16, 2, 2, 32),   // 23 short K, wide
+    // LDS-DMA staging (buffer_load ... lds, swizzled lane-linear tiles)
+    PTX_CFG_DMA(64, 64, 32, 2, 2, 32),    // 24
+    PTX_CFG_DMA(128, 64, 32, 4, 2, 32),   // 25
+    PTX_CFG_DMA(128, 128, 32, 4, 2, 32),  // 26
+    PTX_CFG_DMA(64, 128, 32, 2, 2, 32),   // 27
+    PTX_CFG_DMA(64, 64, 16, 2, 2, 32),    // 28
+    PTX_CFG_DMA(128, 64, 16, 2, 2, 32),   // 29
+    PTX_CFG_DMA(32, 64, 32, 2, 2, 16),    // 30
+    PTX_CFG_DMA(256, 64, 32, 8, 1, 32),   // 31
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
