@@ -42,6 +42,7 @@ struct ConvArgs {
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
     int unit_pointwise;   // 1x1x1 / stride 1 / pad 0: skip the position decode
     int k_live;           // live (possibly non-zero) K columns per tap = desc.Ci
+    int tiles_per_plane;  // > 0: frame-fastest tile order (temporal L2 reuse), = Ho*Wo/BM
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -128,7 +129,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 
     const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
     const int n_tile = tile % p.n_tiles;
-    const int m_tile = tile / p.n_tiles;
+    int m_tile = tile / p.n_tiles;
+    if (p.tiles_per_plane > 0) {
+        // temporal filters: visit the frames of a spatial band back to back (frame index fastest) so
+        // the kT-frame input window of the band stays in the XCD's L2 instead of being re-fetched
+        // once per frame; only the dispatch ORDER changes, a tile still covers BM consecutive rows
+        const int clip_tiles = p.To * p.tiles_per_plane;
+        const int c = m_tile / clip_tiles, r = m_tile - c * clip_tiles;
+        m_tile = c * clip_tiles + (r % p.To) * p.tiles_per_plane + r / p.To;
+    }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int zb = blockIdx.y;
     const int zs = blockIdx.z;
@@ -594,6 +603,13 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA(128, 64, 16, 2, 2, 32),   // 29
     PTX_CFG_DMA(32, 64, 32, 2, 2, 16),    // 30
     PTX_CFG_DMA(256, 64, 32, 8, 1, 32),   // 31
+    PTX_CFG_DMA(64, 128, 16, 2, 2, 32),   // 32
+    PTX_CFG_DMA(128, 128, 16, 4, 2, 32),  // 33
+    PTX_CFG_DMA(128, 64, 16, 4, 2, 32),   // 34
+    PTX_CFG_DMA(32, 128, 32, 2, 2, 16),   // 35
+    PTX_CFG_DMA(112, 64, 32, 1, 4, 16),   // 36
+    PTX_CFG_DMA(64, 32, 32, 2, 2, 16),    // 37 (wave 32x16)
+    PTX_CFG_DMA(32, 32, 32, 2, 2, 16),    // 38 tiny tiles for very small M
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -687,6 +703,15 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
                 hipStream_t st) {
     const ConvConfig& c = kConfigs[config];
     a.m_tiles = cdiv(a.M, c.BM);
+    {
+        static int t_inner = -1;
+        if (t_inner < 0) { const char* e = getenv("PTX_T_INNER"); t_inner = e ? atoi(e) : 0; }   // measured: no gain (stem is MFMA-bound), off by default
+        const int plane = a.Ho * a.Wo;
+        const int64_t in_clip_bytes = (int64_t)a.Ti * a.Hi * a.Wi * a.ldx * 4;
+        // worth it only when one clip's input exceeds the per-XCD L2 (4 MiB) and the filter spans frames
+        a.tiles_per_plane = (t_inner && a.kT > 1 && a.To > 1 && plane % c.BM == 0 && in_clip_bytes > (8 << 20))
+                                ? plane / c.BM : 0;
+    }
     a.n_tiles = cdiv(a.ldy, c.BN);
     a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
     const int steps_total = a.kT * a.kH * a.kW * a.kchunks;

@@ -140,32 +140,49 @@ __global__ void __launch_bounds__(256) transpose_last2_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// small-Cin stem: NCDHW -> [N][T][H][Wo][ld] with the kW taps folded into the channel axis
+// small-Cin stem: NCDHW -> [N][T][H][Wo][ld] with the kW taps folded into the channel axis.
+// One workgroup per input row (n, t, h): the C channel rows are staged in LDS with coalesced
+// loads, then the Wo x ld output row (contiguous in memory) is written as float4s.  A thread's
+// float4 column q is fixed, so its four (kw, c) pairs are decoded once.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fold_kw_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
-                                                      int T, int H, int W, int kW, int sW, int pW, int Wo, int ld,
-                                                      size_t total4) {
+                                                      int T, int H, int W, int kW, int sW, int pW, int Wo, int ld) {
+    extern __shared__ float rowbuf[];      // [C][W]
+    const int h = blockIdx.x % H;
+    const int t = (blockIdx.x / H) % T;
+    const int n = blockIdx.x / (H * T);
+    const size_t plane = (size_t)T * H * W;
+    const float* xin = x + (size_t)n * C * plane + ((size_t)t * H + h) * W;
+    for (int i = threadIdx.x; i < C * W; i += 256) {
+        const int c = i / W, w = i - c * W;
+        rowbuf[i] = xin[(size_t)c * plane + w];
+    }
+    __syncthreads();
     const int f4r = ld / 4;
-    const int kvalid = kW * C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % f4r);
-        size_t row = i / f4r;
-        const int wo = (int)(row % Wo);
-        size_t t1 = row / Wo;
-        const int h = (int)(t1 % H);
-        t1 /= H;
-        const int t = (int)(t1 % T);
-        const int n = (int)(t1 / T);
+    const int rows_per_pass = 256 / f4r;
+    const int q = threadIdx.x % f4r;
+    const int r0 = threadIdx.x / f4r;
+    if (r0 >= rows_per_pass) return;
+    int off[4], kwp[4];
+    bool live[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = q * 4 + e;
+        const int kw = k / C, c = k - kw * C;
+        live[e] = k < kW * C;
+        kwp[e] = kw - pW;
+        off[e] = c * W + kw - pW;          // + wo * sW gives the LDS index of (c, wo*sW - pW + kw)
+    }
+    float* yrow = y + (size_t)blockIdx.x * Wo * ld;
+    for (int wo = r0; wo < Wo; wo += rows_per_pass) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = q * 4 + e;
-            const int kw = k / C, c = k - kw * C;
-            const int wi = wo * sW - pW + kw;
-            v[e] = (k < kvalid && wi >= 0 && wi < W) ? x[((((size_t)n * C + c) * T + t) * H + h) * W + wi] : 0.f;
+            const int wi = wo * sW + kwp[e];                  // input column of this tap
+            v[e] = (live[e] && wi >= 0 && wi < W) ? rowbuf[off[e] + wo * sW] : 0.f;
         }
         f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+        *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ld + q * 4) = o;
     }
 }
 
@@ -256,8 +273,10 @@ extern "C" int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C,
     if (ld < kW * C || ld % 4) return fail(PTX_ERR_INVALID, "fold_kw: ld=%d must cover kW*C=%d and be a multiple of 4", ld, kW * C);
     if (Wo != (W + 2 * pW - kW) / sW + 1) return fail(PTX_ERR_INVALID, "fold_kw: Wo mismatch");
     if ((uintptr_t)y & 15) return fail(PTX_ERR_INVALID, "fold_kw: misaligned output");
-    const size_t total4 = (size_t)N * T * H * Wo * (ld / 4);
-    hipLaunchKernelGGL(fold_kw_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, C, T, H, W, kW,
-                       sW, pW, Wo, ld, total4);
+    if (ld / 4 > 256 || (size_t)C * W * sizeof(float) > 64 * 1024)
+        return fail(PTX_ERR_UNSUPPORTED, "fold_kw: row of %d x %d floats does not fit the LDS staging buffer", C, W);
+    if ((int64_t)N * T * H > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "fold_kw: too many rows");
+    hipLaunchKernelGGL(fold_kw_kernel, dim3((unsigned)(N * T * H)), dim3(256), (size_t)C * W * sizeof(float),
+                       (hipStream_t)stream, x, y, C, T, H, W, kW, sW, pW, Wo, ld);
     return hip_check(hipGetLastError(), "fold_kw launch");
 }
