@@ -46,6 +46,19 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
+// Step barrier.  hipcc may schedule LDS reads of the NEXT buffer above a plain __syncthreads() when it
+// sees no aliasing store in this thread (observed on the LDS-DMA variant, whose only LDS writers are
+// other waves' buffer_load...lds): pin the order for both the optimiser and the machine scheduler.
+// The reads that follow take their base offsets through `post_barrier_offsets`, an asm volatile that
+// is ordered after the barrier and that the reads depend on (cdna_hip_programming.md 5.7 item 3).
+__device__ __forceinline__ void step_barrier() {
+    __syncthreads();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void post_barrier_offsets(int& a, int& b) {
+    asm volatile("; ds_reads of the next LDS buffer depend on these" : "+v"(a), "+v"(b)::"memory");
+}
+
 template <int MT> struct Mfma;
 template <> struct Mfma<32> {
     using acc_t = f32x16;
@@ -354,12 +367,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // 11 instead of 12 MFMAs per tap.
     static_assert(!K22 || (BK == 24 && MT == 32), "K22 is the BK = 24 / 32x32x2 stem path");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int frag22_a = (wm * WTM + (lane % MT)) * LDK + 16 + (lane / MT) * 2;
-    const int frag22_b = (wn * WTN + (lane % MT)) * LDK + 16 + (lane / MT) * 2;
-    auto read_frags = [&](int buf, int ks, int slot) {
+    auto read_frags = [&](int buf, int ks, int slot, int offa, int offb) {
         if (K22 && ks == KSUB - 1) {
-            const float* Ab = As + buf * BM * LDK + frag22_a;
-            const float* Bb = Bs + buf * BN * LDK + frag22_b;
+            const float* Ab = As + buf * BM * LDK + offa + 16 + (lane / MT) * 2 - (lane / MT) * 4;
+            const float* Bb = Bs + buf * BN * LDK + offb + 16 + (lane / MT) * 2 - (lane / MT) * 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK);
@@ -375,8 +386,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             return;
         }
         const int koff = DMA ? (((ks * KG + lane / MT) ^ frag_sw) * 4) : ks * 4 * KG;
-        const float* Ab = As + buf * BM * LDK + frag_off_a + koff;
-        const float* Bb = Bs + buf * BN * LDK + frag_off_b + koff;
+        const float* Ab = As + buf * BM * LDK + offa + koff;
+        const float* Bb = Bs + buf * BN * LDK + offb + koff;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
 #pragma unroll
@@ -413,21 +424,24 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         if (my_steps > 0) {
             load_tiles(true, 0);
             advance();
-            __syncthreads();
+            step_barrier();
+            int offa = frag_off_a, offb = frag_off_b;
+            post_barrier_offsets(offa, offb);
             load_tiles(my_steps > 1, 1);
             advance();
-            read_frags(0, 0, 0);
+            read_frags(0, 0, 0, offa, offb);
             for (int it = 0; it < my_steps; ++it) {
                 const int buf = it & 1;
 #pragma unroll
                 for (int ks = 0; ks < KSUB; ++ks) {
                     if (ks == KSUB - 1) {
-                        __syncthreads();
+                        step_barrier();
+                        post_barrier_offsets(offa, offb);
                         load_tiles(it + 2 < my_steps, buf);
                         advance();
-                        read_frags(buf ^ 1, 0, (ks + 1) % NSLOT);
+                        read_frags(buf ^ 1, 0, (ks + 1) % NSLOT, offa, offb);
                     } else {
-                        read_frags(buf, ks + 1, (ks + 1) % NSLOT);
+                        read_frags(buf, ks + 1, (ks + 1) % NSLOT, offa, offb);
                     }
                     mma_frags(ks % NSLOT, 4);
                 }
@@ -440,17 +454,20 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         store_tiles(0);
         load_tiles(my_steps > 1);
         advance();
-        __syncthreads();
-        read_frags(0, 0, 0);
+        step_barrier();
+        int offa = frag_off_a, offb = frag_off_b;
+        post_barrier_offsets(offa, offb);
+        read_frags(0, 0, 0, offa, offb);
         for (int it = 0; it < my_steps; ++it) {
             const int buf = it & 1;
 #pragma unroll
             for (int ks = 0; ks < KSUB; ++ks) {
                 if (ks == KSUB - 1) {
-                    __syncthreads();
-                    read_frags(buf ^ 1, 0, (ks + 1) % NSLOT);
+                    step_barrier();
+                    post_barrier_offsets(offa, offb);
+                    read_frags(buf ^ 1, 0, (ks + 1) % NSLOT, offa, offb);
                 } else {
-                    read_frags(buf, ks + 1, (ks + 1) % NSLOT);
+                    read_frags(buf, ks + 1, (ks + 1) % NSLOT, offa, offb);
                 }
                 if (ks == STORE_KS) {
                     store_tiles(buf ^ 1);

@@ -167,6 +167,29 @@ def test_conv_every_config_and_split(ptx):
     assert not bad, bad
 
 
+def test_conv_dma_bit_exact_vs_register_staged(ptx):
+    """Race detector for the LDS-DMA pipeline: tiles with the same MFMA shape accumulate every output
+    in the same k-order whatever the staging flavour or BK (16 | 32), so results must be bit-identical
+    to the register-staged kernel -- over repeated launches on a problem big enough to fill the chip
+    (any stale / early LDS read would show up as a difference)."""
+    lib = _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    x, w = rnd(4, 64, 6, 40, 40, seed=50), rnd(128, 64, 3, 3, 3, seed=51, scale=0.03)
+    bn = make_bn(128, 52)
+    base = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index("64x64x32/2x2/m32"), split=1)
+    for name in ("64x64x32/2x2/m32/dma", "64x64x16/2x2/m32/dma", "64x64x16/2x2/m32", "128x64x32/4x2/m32/dma",
+                 "128x128x32/4x2/m32/dma", "64x128x16/2x2/m32/dma", "256x64x32/8x1/m32/dma"):
+        for rep in range(6):
+            got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
+            assert torch.equal(got, base), "%s differs from the register-staged result (rep %d)" % (name, rep)
+    # 16x16x4 family among themselves
+    base16 = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index("112x64x32/1x4/m16"), split=1)
+    for name in ("32x64x32/2x2/m16/dma", "112x64x32/1x4/m16/dma", "32x128x32/2x2/m16/dma", "64x32x32/2x2/m16/dma"):
+        for rep in range(6):
+            got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
+            assert torch.equal(got, base16), "%s differs (rep %d)" % (name, rep)
+
+
 def test_conv_ragged_channels_every_config(ptx):
     lib = _lib(ptx)
     x, w = rnd(2, 51, 3, 7, 6, seed=8), rnd(85, 51, 1, 3, 3, seed=9, scale=0.05)
