@@ -627,6 +627,12 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA(112, 64, 32, 1, 4, 16),   // 36
     PTX_CFG_DMA(64, 32, 32, 2, 2, 16),    // 37 (wave 32x16)
     PTX_CFG_DMA(32, 32, 32, 2, 2, 16),    // 38 tiny tiles for very small M
+    // 48 / 96-wide N tiles: the (2+1)D mid-channel counts are 144 * 2^k (r2plus1d.py:68-69)
+    PTX_CFG_DMA(64, 48, 32, 4, 1, 16),    // 39
+    PTX_CFG_DMA(128, 48, 32, 8, 1, 16),   // 40
+    PTX_CFG_DMA(64, 96, 32, 2, 2, 16),    // 41
+    PTX_CFG_DMA(128, 96, 32, 4, 2, 16),   // 42
+    PTX_CFG_DMA(32, 96, 32, 2, 2, 16),    // 43
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -846,7 +852,8 @@ extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t ba
         a.w_bytes = (unsigned)wb;
     }
     // C columns [Nn, ldc) are written as zero (B rows >= Nn are read as zero)
+    // LDS-DMA tiles: 128x128 (8 waves) when that still yields >= 2 workgroups per CU, else 64x64
     const int64_t blocks128 = cdiv64(M, 128) * cdiv(ldc, 128) * batch;
-    const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 0 : 2;
+    const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 26 : 24;
     return launch_conv(a, config, 1, batch, nullptr, 0, (hipStream_t)stream);
 }

@@ -574,6 +574,8 @@ class Engine:
                         continue
                     if bn_ > 64 and stp.d.ldy <= 64:
                         continue
+                    if bn_ % 48 == 0 and stp.d.ldy % 48 != 0:     # 48/96-wide tiles: (2+1)D widths only
+                        continue
                     if bm >= 128 and M < 8192:
                         continue
                     blocks = ((M + bm - 1) // bm) * ((stp.d.ldy + bn_ - 1) // bn_)
