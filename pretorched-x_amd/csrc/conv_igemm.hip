@@ -101,7 +101,7 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // loading and to the fragment read address (cdna_hip_programming.md rule 21).
     constexpr int LDK = DMA ? BK : BK + 4;
     static_assert(!DMA || (!K22 && (BK == 32 || BK == 16)), "DMA staging: BK 32 or 16");
+    static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "3-stage ring needs DMA staging");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
     static_assert(TM * MT * WM == BM && TN * MT * WN == BN, "tile must split evenly");
@@ -132,8 +133,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     };
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                   // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]
+    float* As = smem;                        // [NSTAGE][BM][LDK]
+    float* Bs = smem + NSTAGE * BM * LDK;    // [NSTAGE][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -416,6 +417,50 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // (its last fragments were completed before that barrier), so step s may overwrite it; those
     // writes complete (lgkmcnt(0)) before the barrier of step s, after which step s+1 reads them.
     constexpr int STORE_KS = KSUB >= 3 ? 1 : 0;
+    if constexpr (DMA && NSTAGE == 3) {
+        // 3-stage LDS-DMA ring: tile s+3 is requested right after the barrier of step s, i.e. two full
+        // k-steps before it is read.  Every wave issues exactly NPS DMA instructions per step, so a
+        // counted `s_waitcnt vmcnt(NPS)` before the raw barrier retires tile s+1 while tile s+2 stays
+        // in flight (a plain __syncthreads() would drain everything -- cdna_hip_programming.md 5).
+        static_assert(A_F4 % NT == 0 && B_F4 % NT == 0, "uniform DMA count per wave");
+        constexpr int NPS = A_IT + B_IT;
+        auto ring_barrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NPS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        if (my_steps > 0) {
+            load_tiles(true, 0);
+            advance();
+            load_tiles(my_steps > 1, 1);
+            advance();
+            ring_barrier();
+            int offa = frag_off_a, offb = frag_off_b;
+            post_barrier_offsets(offa, offb);
+            load_tiles(my_steps > 2, 2);
+            advance();
+            read_frags(0, 0, 0, offa, offb);
+            int cur = 0;
+            for (int it = 0; it < my_steps; ++it) {
+                const int nxt = cur == 2 ? 0 : cur + 1;
+#pragma unroll
+                for (int ks = 0; ks < KSUB; ++ks) {
+                    if (ks == KSUB - 1) {
+                        ring_barrier();
+                        post_barrier_offsets(offa, offb);
+                        load_tiles(it + 3 < my_steps, cur);
+                        advance();
+                        read_frags(nxt, 0, (ks + 1) % NSLOT, offa, offb);
+                    } else {
+                        read_frags(cur, ks + 1, (ks + 1) % NSLOT, offa, offb);
+                    }
+                    mma_frags(ks % NSLOT, 4);
+                }
+                cur = nxt;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (all-OOB) DMAs
+        }
+    } else
     if constexpr (DMA) {
         // LDS-DMA staging: no staging registers, no ds_write.  The DMA of tile s+2 is issued right
         // after the barrier of step s (which frees buffer s&1: its last fragments were read before
@@ -546,10 +591,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA>;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -563,15 +608,15 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if constexpr (BK == 24 && MT == 32 && !DMA) {
         // kW-folded stem: one 24-wide chunk per tap of which at most 22 columns are live
         if (a.k_live <= 22 && a.kA == 24 && a.kB == 24)
-            return launch_one<BM, BN, BK, WM, WN, MT, false, true, false>(a, grid, st);
+            return launch_one<BM, BN, BK, WM, WN, MT, false, true, false, 2>(a, grid, st);
     }
-    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA>(a, grid, st);
-    return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA, NSTAGE>(a, grid, st);
 }
 
 struct ConvConfig {
@@ -581,9 +626,11 @@ struct ConvConfig {
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2> }
 #define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2> }
+#define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3> }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -633,6 +680,14 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA(64, 96, 32, 2, 2, 16),    // 41
     PTX_CFG_DMA(128, 96, 32, 4, 2, 16),   // 42
     PTX_CFG_DMA(32, 96, 32, 2, 2, 16),    // 43
+    // 3-stage DMA ring (tiles requested two k-steps ahead, counted vmcnt + raw barrier)
+    PTX_CFG_DMA3(64, 64, 16, 2, 2, 32),   // 44
+    PTX_CFG_DMA3(64, 64, 32, 2, 2, 32),   // 45
+    PTX_CFG_DMA3(128, 64, 32, 4, 2, 32),  // 46
+    PTX_CFG_DMA3(32, 64, 32, 2, 2, 16),   // 47
+    PTX_CFG_DMA3(128, 128, 32, 4, 2, 32), // 48
+    PTX_CFG_DMA3(64, 128, 16, 2, 2, 32),  // 49
+    PTX_CFG_DMA3(128, 64, 16, 2, 2, 32),  // 50
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -683,25 +738,22 @@ extern "C" int ptx_conv3d_config_supported(const ptx_conv3d_desc* d, int config)
 }
 
 extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
-    // Defaults distilled from Engine.autotune runs on MI355X (profiles/r01_*): 64x64 tiles at 4
-    // workgroups per CU win almost everywhere; the folded stem wants the 8-wave 256x64x24 tile; wide
-    // outputs with a large M take the 8-wave 128x128 tile; short K prefers BK = 16 (more workgroups
-    // in flight); small grids are widened with split-K.
+    // Defaults distilled from Engine.autotune runs on MI355X (profiles/r01_*); the tuner refines them.
     if (split_k) *split_k = 1;
     if (validate_desc(d) != PTX_OK) return 0;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     const int taps = d->kT * d->kH * d->kW;
     int cfg;
-    if (d->Kc % 32 != 0 && d->Kc % 24 == 0) {
-        cfg = M >= 256 * 1024 ? 16 : 6;
-    } else if (d->Kc % 32 != 0) {
-        cfg = (M >= 64 * 1024) ? 10 : 9;
-    } else if (taps * d->Kc <= 128) {
-        cfg = 9;                                   // K <= 128: one or two k-steps of 32
-    } else if (d->ldy >= 128 && cdiv64(M, 128) * cdiv(d->ldy, 128) >= 4 * kNumCU) {
-        cfg = 12;
+    if (d->Kc == 24) {
+        cfg = M >= 256 * 1024 ? 16 : 6;            // kW-folded stem: 8-wave 256x64x24 (register staged)
+    } else if (d->ldy % 48 == 0 && d->ldy % 64 != 0) {
+        cfg = 39;                                  // (2+1)D mid widths 144 * 2^k: 48-wide N tiles
+    } else if (M < 8192) {
+        cfg = d->ldy >= 128 ? 35 : 30;             // small M: 32-row tiles on 16x16x4 MFMA (DMA)
+    } else if (d->ldy >= 128 && taps * d->Kc > 128 && cdiv64(M, 128) * cdiv(d->ldy, 128) >= 4 * kNumCU) {
+        cfg = 26;                                  // wide output, big grid: 8-wave 128x128 (DMA)
     } else {
-        cfg = 2;
+        cfg = 28;                                  // default: 64x64x16 DMA tiles, 8 workgroups per CU
     }
     const ConvConfig& c = kConfigs[cfg];
     const int64_t blocks = cdiv64(M, c.BM) * cdiv(d->ldy, c.BN);
