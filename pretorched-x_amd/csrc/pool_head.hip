@@ -147,52 +147,43 @@ __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// in-place row softmax (or 1/cols scaling); one workgroup per row, row held in registers
+// in-place row softmax (or 1/cols scaling): ONE WAVEFRONT PER ROW, the row held in registers,
+// max / sum reduced with wave shuffles only -- no LDS, no barrier (4 rows per workgroup).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSoftmaxMaxPerThread = 16;   // rows up to 4096 columns
+constexpr int kSoftmaxMaxPerLane = 64;   // rows up to 4096 columns
 
-__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int cols, int ld, int scale_only) {
-    __shared__ float red[4];
-    __shared__ float red2[4];
-    float* row = x + (size_t)blockIdx.x * ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float v[kSoftmaxMaxPerThread];
+template <int PER_LANE>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long long rows, int cols, int ld,
+                                                           int scale_only) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* row = x + (size_t)r * ld;
+    const int lane = threadIdx.x & 63;
+    float v[PER_LANE];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < PER_LANE; ++i) {
+        const int c = lane + 64 * i;
         v[i] = (c < cols) ? row[c] : -INFINITY;
         mx = fmaxf(mx, v[i]);
     }
+    float inv;
     if (scale_only) {
-        const float inv = 1.0f / (float)cols;
+        inv = 1.0f / (float)cols;
+    } else {
+        mx = wave_max(mx);
+        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
-            const int c = tid + 256 * i;
-            if (c < cols) row[c] = v[i] * inv;
-            else if (c < ld) row[c] = 0.f;
+        for (int i = 0; i < PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (c < cols) ? expf(v[i] - mx) : 0.f;
+            sum += v[i];
         }
-        return;
+        inv = 1.0f / wave_sum(sum);
     }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
-        const int c = tid + 256 * i;
-        v[i] = (c < cols) ? expf(v[i] - mx) : 0.f;
-        sum += v[i];
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red2[wave] = sum;
-    __syncthreads();
-    sum = (red2[0] + red2[1]) + (red2[2] + red2[3]);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int i = 0; i < kSoftmaxMaxPerThread; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < PER_LANE; ++i) {
+        const int c = lane + 64 * i;
         if (c < cols) row[c] = v[i] * inv;
         else if (c < ld) row[c] = 0.f;
     }
@@ -259,10 +250,18 @@ extern "C" int ptx_softmax_rows(float* x, int64_t rows, int32_t cols, int32_t ld
                                 ptx_stream_t stream) {
     if (!x) return fail(PTX_ERR_INVALID, "softmax: null pointer");
     if (rows <= 0 || cols <= 0 || ld < cols) return fail(PTX_ERR_INVALID, "softmax: bad extents");
-    if (cols > 256 * kSoftmaxMaxPerThread || ld > 256 * kSoftmaxMaxPerThread)
-        return fail(PTX_ERR_UNSUPPORTED, "softmax: rows longer than %d are not supported", 256 * kSoftmaxMaxPerThread);
-    if (rows > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "softmax: too many rows");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld,
-                       scale_only);
+    if (ld > 64 * kSoftmaxMaxPerLane)
+        return fail(PTX_ERR_UNSUPPORTED, "softmax: rows longer than %d are not supported", 64 * kSoftmaxMaxPerLane);
+    if (rows > 4LL * 0x7fffffffLL) return fail(PTX_ERR_INVALID, "softmax: too many rows");
+    const dim3 grid((unsigned)cdiv64(rows, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (ld <= 64 * 4)
+        hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, dim3(256), 0, st, x, (long long)rows, cols, ld, scale_only);
+    else if (ld <= 64 * 16)
+        hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, dim3(256), 0, st, x, (long long)rows, cols, ld, scale_only);
+    else if (ld <= 64 * 32)
+        hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, dim3(256), 0, st, x, (long long)rows, cols, ld, scale_only);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<64>, grid, dim3(256), 0, st, x, (long long)rows, cols, ld, scale_only);
     return hip_check(hipGetLastError(), "softmax launch");
 }

@@ -480,6 +480,9 @@ class Engine:
     def features(self, model, x):
         """NCDHW in -> NCDHW feature map out (contiguous), like the reference's `features`."""
         self._validate(model, x, model.arch.dims)
+        big = self._chunked(self.features, model, x)
+        if big is not None:
+            return big
         x = x.contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
@@ -522,6 +525,27 @@ class Engine:
                 out = model.head_module(pooled)
         return out
 
+    LIMIT_BYTES = (1 << 31) - (1 << 20)      # libptx_amd uses 32-bit buffer offsets: < 2 GiB per tensor
+
+    def max_batch(self, model, sample_shape):
+        """Largest batch whose biggest plan tensor stays under the 2 GiB per-launch limit."""
+        one = Plan(self, model, (1,) + tuple(sample_shape), torch.device("meta"))
+        per_clip = max(a.t.numel() * 4 for a in one.acts)
+        return max(1, int(self.LIMIT_BYTES // per_clip))
+
+    def _chunked(self, fn, model, x):
+        """Run `fn(model, chunk)` over batch slices that respect the per-launch size limit."""
+        key = ("maxb", tuple(x.shape[1:]), id(model))
+        with self._lock:
+            mb = self._sig.get(key)
+            if mb is None:
+                mb = self._sig[key] = self.max_batch(model, x.shape[1:])
+        if x.shape[0] <= mb:
+            return None
+        n_chunks = -(-x.shape[0] // mb)
+        size = -(-x.shape[0] // n_chunks)
+        return torch.cat([fn(model, x[i:i + size]) for i in range(0, x.shape[0], size)], 0)
+
     def _maybe_tune(self, model, plan, x):
         if self.auto_tune and not plan.tuned:
             plan.tuned = True
@@ -531,6 +555,9 @@ class Engine:
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""
         self._validate(model, x, model.arch.dims)
+        big = self._chunked(self.forward, model, x)
+        if big is not None:
+            return big
         x = x.contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)

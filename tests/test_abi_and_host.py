@@ -129,6 +129,15 @@ def test_plan_compiler_matches_survey_worklist(ptx):
         assert abs(sum(s.macs for s in pl.conv_steps) / 1e9 - gm) < 0.01, name
 
 
+def test_batch_limit_from_dry_plan(ptx):
+    """libptx_amd addresses each tensor with 32-bit byte offsets (< 2 GiB per launch); the engine
+    derives the largest admissible batch from a batch-1 dry plan and splits bigger batches."""
+    m = ptx.resnet3d50(num_classes=339, pretrained=None)
+    mb = m.engine().max_batch(m, (3, 16, 224, 224))
+    per_clip = 16 * 112 * 112 * 64 * 4          # stem output, the largest tensor of the plan
+    assert mb == ((1 << 31) - (1 << 20)) // per_clip == 41
+
+
 def test_synth_recipe_is_deterministic(ptx):
     from pretorched_x_amd.testing import synth_clips, synth_state_dict
     m = ptx.resnet3d10()

@@ -167,6 +167,24 @@ def test_input_validation_on_device(ptx):
     assert torch.equal(y1, y2)
 
 
+def test_oversized_batches_are_split(ptx):
+    """Batches whose activations would exceed the 2 GiB per-launch limit are run in slices."""
+    model, _ = _build(ptx, "resnet3d10", dict(), 1)
+    x = synth_clips(5, 4, 32, 4).to(DEV)
+    whole = model(x)
+    wf = model.features(x)
+    eng = model.engine()
+    per_clip = max(a.t.numel() * 4 for a in eng.dry_plan(model, (1, 3, 4, 32, 32)).acts)
+    eng.LIMIT_BYTES = 2 * per_clip + 1            # at most 2 clips per launch -> 3 slices for B = 5
+    eng.invalidate()
+    assert eng.max_batch(model, (3, 4, 32, 32)) == 2
+    sliced = model(x)
+    sf = model.features(x)
+    assert sliced.shape == whole.shape and sf.shape == wf.shape
+    assert (sliced - whole).abs().max().item() <= 1e-5 * max(1.0, whole.abs().max().item())
+    assert (sf - wf).abs().max().item() <= 1e-5 * max(1.0, wf.abs().max().item())
+
+
 def test_autotune_keeps_parity(ptx):
     blob = load_golden("resnet3d50_small")
     model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), int(blob["w_seed"]))
