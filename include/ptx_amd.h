@@ -69,6 +69,9 @@ typedef struct ptx_conv3d_desc {
     uint32_t flags;          /* PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_EPI_RES_PADA */
     /* residual operand (PTX_EPI_RES_ADD: ldr only; PTX_EPI_RES_PADA: all fields) */
     int32_t ldr, res_C, res_T, res_H, res_W, res_sT, res_sH, res_sW;
+    /* second activation source of ptx_conv3d_dual_fwd (ignored by ptx_conv3d_fwd): x2 is NDHWC
+     * [N][x2_T][x2_H][x2_W][x2_ld] with x2_C channels, sampled at (to*x2_sT, ho*x2_sH, wo*x2_sW) */
+    int32_t x2_C, x2_ld, x2_T, x2_H, x2_W, x2_sT, x2_sH, x2_sW;
 } ptx_conv3d_desc;
 
 /* number of compiled tile configurations, and a printable name "BMxBNxBK/WMxWN/mfmaMT" */
@@ -88,6 +91,17 @@ size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* desc, int split_k);
 int ptx_conv3d_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_packed,
                    const float* bias, const float* res, float* y, void* workspace,
                    size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
+/*
+ * Two-source pointwise conv: the K axis is the concatenation of x's channels and x2's channels,
+ *   y[m][co] = epilogue( sum_c x[m][c] w[co][c] + sum_c2 x2[pos2(m)][c2] w[co][Kc + c2] + bias[co] )
+ * (1x1x1, unit stride on x; x2 is a strided gather).  This is a bottleneck's last conv with its
+ * shortcut-B branch folded in: conv3 -> bn3, downsample conv -> bn, add, relu
+ * (resnet3D.py:135-142 with :176-185) as ONE GEMM -- no residual tensor is written or re-read.
+ * w_packed: [1][Co_pad][Kc + Kc2] built by two ptx_pack_conv_weight calls (ld_k / k_off / bias_accumulate).
+ */
+int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* desc, const float* x, const float* x2,
+                        const float* w_packed, const float* bias, float* y, void* workspace,
+                        size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Weight packing: fold eval-mode BatchNorm (+ conv bias) into the filter and re-lay it out
@@ -106,6 +120,9 @@ typedef struct ptx_pack_desc {
     int32_t Co, Ci, kT, kH, kW;
     int32_t Kc, Co_pad;
     int32_t fold_kw;
+    /* K-concatenated packing (ptx_conv3d_dual_fwd): row stride of w_packed in floats (0 = Kc), first
+     * column written, and whether bias_out is accumulated into instead of overwritten */
+    int32_t ld_k, k_off, bias_accumulate;
 } ptx_pack_desc;
 
 size_t ptx_packed_weight_elems(const ptx_pack_desc* desc);

@@ -29,14 +29,16 @@ class ConvDesc(C.Structure):
                  "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "Kc", "Co_pad")] + \
                [("flags", C.c_uint32)] + \
                [(n, C.c_int32) for n in
-                ("ldr", "res_C", "res_T", "res_H", "res_W", "res_sT", "res_sH", "res_sW")]
+                ("ldr", "res_C", "res_T", "res_H", "res_W", "res_sT", "res_sH", "res_sW",
+                 "x2_C", "x2_ld", "x2_T", "x2_H", "x2_W", "x2_sT", "x2_sH", "x2_sW")]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
 
 
 class PackDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("Co", "Ci", "kT", "kH", "kW", "Kc", "Co_pad", "fold_kw")]
+    _fields_ = [(n, C.c_int32) for n in ("Co", "Ci", "kT", "kH", "kW", "Kc", "Co_pad", "fold_kw",
+                                         "ld_k", "k_off", "bias_accumulate")]
 
 
 class PoolDesc(C.Structure):
@@ -61,6 +63,7 @@ SIGNATURES = {
     "ptx_conv3d_pick_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
     "ptx_conv3d_workspace_bytes": (_Z, [C.POINTER(ConvDesc), C.c_int]),
     "ptx_conv3d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
+    "ptx_conv3d_dual_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
     "ptx_packed_weight_elems": (_Z, [C.POINTER(PackDesc)]),
     "ptx_pack_conv_weight": (C.c_int, [C.POINTER(PackDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "ptx_ncdhw_to_ndhwc": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),

@@ -43,6 +43,10 @@ struct ConvArgs {
     int unit_pointwise;   // 1x1x1 / stride 1 / pad 0: skip the position decode
     int k_live;           // live (possibly non-zero) K columns per tap = desc.Ci
     int tiles_per_plane;  // > 0: frame-fastest tile order (temporal L2 reuse), = Ho*Wo/BM
+    // dual-source pointwise conv (ptx_conv3d_dual_fwd): K chunks [0, kc1) read x, chunks [kc1, kchunks) read x2
+    const float* x2;
+    int dual, ldx2, kA2, kc1, wcol2, T2, H2, W2, s2T, s2H, s2W;
+    unsigned x2_bytes;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -197,6 +201,26 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         a_off[i] = ok ? (cpos * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
         a_mask[i] = ok ? mask : 0u;
     }
+    unsigned a_off2[A_IT];      // second activation source (strided gather), dual-source convs only
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) a_off2[i] = kOOB;
+    if (p.dual) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + NT * i;
+            const int m = m0 + idx / F4R;
+            if ((idx < A_F4) && (m < p.M)) {
+                const int wo = m % p.Wo;
+                int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                t /= p.Ho;
+                const int to = t % p.To;
+                const int n = t / p.To;
+                const unsigned pos2 = (unsigned)(((n * p.T2 + to * p.s2T) * p.H2 + ho * p.s2H) * p.W2 + wo * p.s2W);
+                a_off2[i] = (pos2 * (unsigned)p.ldx2 + (unsigned)swz_col(idx)) * 4u;
+            }
+        }
+    }
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -265,35 +289,47 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dual ? p.x2 : xg), 0, p.dual ? p.x2_bytes : 0u, 0x00020000);
 
     // issue the global loads of k-step (kt, kh, kw, ch) into registers; `valid` == false turns
     // every load into an OOB (zero, no traffic) access
     auto load_tiles = [&](bool valid, int dbuf = 0) {
         const int tap = (kt * p.kH + kh) * p.kW + kw;
-        const int c0 = ch * BK;
+        // dual-source convs: chunks >= kc1 read the second activation tensor (its own channel
+        // offset, base offsets and extent; weights continue at column wcol2)
+        const bool use2 = p.dual && ch >= p.kc1;
+        const int c0 = (use2 ? ch - p.kc1 : ch) * BK;
+        const int wc0 = use2 ? p.wcol2 + c0 : c0;
         // uniform: tap selector for the mask test, signed byte offset of the tap from the centre
         const unsigned sel = valid ? ((1u << kt) | (1u << (8 + kh)) | (1u << (16 + kw))) : 0xFFFFFFFFu;
         const unsigned s_off =
             (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.ldx + c0) * 4);
+        auto issue_a = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&base)[A_IT], unsigned soff, int klim) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            bool ok = (a_mask[i] & sel) == sel;
-            if (KTAIL) ok = ok && (c0 + swz_col(tid + NT * i)) < p.kA;
-            const unsigned off = a_off[i] + s_off;
-            if constexpr (DMA) {
-                // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
-                if (wave_u * 64 + NT * i < A_F4)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rsrc_x, (lds_ptr_t)(As + dbuf * BM * LDK + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
-            } else {
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0));
+            for (int i = 0; i < A_IT; ++i) {
+                bool ok = (a_mask[i] & sel) == sel;
+                if (KTAIL) ok = ok && (c0 + swz_col(tid + NT * i)) < klim;
+                const unsigned off = base[i] + soff;
+                if constexpr (DMA) {
+                    // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
+                    if (wave_u * 64 + NT * i < A_F4)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rs, (lds_ptr_t)(As + dbuf * BM * LDK + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
+                } else {
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, 0));
+                }
             }
-        }
-        const unsigned s_woff = valid ? (unsigned)(((size_t)tap * p.w_tap_stride + c0) * 4) : kOOB;
+        };
+        if (use2)
+            issue_a(rsrc_x2, a_off2, (unsigned)(c0 * 4), p.kA2);
+        else
+            issue_a(rsrc_x, a_off, s_off, p.kA);
+        const unsigned s_woff = valid ? (unsigned)(((size_t)tap * p.w_tap_stride + wc0) * 4) : kOOB;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             unsigned off = b_off[i] + s_woff;
-            if (KTAIL) off = (c0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
+            if (KTAIL) off = (wc0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
             if constexpr (DMA) {
                 if (wave_u * 64 + NT * i < B_F4)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -615,7 +651,8 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
         if (a.k_live <= 22 && a.kA == 24 && a.kB == 24)
             return launch_one<BM, BN, BK, WM, WN, MT, false, true, false, 2>(a, grid, st);
     }
-    if ((a.kA % BK) || (a.kB % BK)) return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
+        return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE>(a, grid, st);
     return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA, NSTAGE>(a, grid, st);
 }
 
@@ -789,6 +826,10 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     }
     a.n_tiles = cdiv(a.ldy, c.BN);
     a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
+    if (a.dual) {
+        a.kc1 = cdiv(a.kA, c.BK);
+        a.kchunks = a.kc1 + cdiv(a.kA2, c.BK);
+    }
     const int steps_total = a.kT * a.kH * a.kW * a.kchunks;
     if (split_k < 1) split_k = 1;
     if (split_k > steps_total) split_k = steps_total;
@@ -827,9 +868,9 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
 }
 }  // namespace ptx
 
-extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const float* w_packed, const float* bias,
-                              const float* res, float* y, void* workspace, size_t workspace_bytes, int config,
-                              int split_k, ptx_stream_t stream) {
+static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed,
+                         const float* bias, const float* res, float* y, void* workspace, size_t workspace_bytes,
+                         int config, int split_k, ptx_stream_t stream) {
     int s = validate_desc(d);
     if (s != PTX_OK) return s;
     if (!x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv3d: null tensor pointer");
@@ -874,7 +915,40 @@ extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const fl
     }
     a.ldr = d->ldr; a.res_C = d->res_C; a.res_T = d->res_T; a.res_H = d->res_H; a.res_W = d->res_W;
     a.res_sT = d->res_sT; a.res_sH = d->res_sH; a.res_sW = d->res_sW;
+    if (x2) {
+        if (d->kT * d->kH * d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT || d->pH || d->pW)
+            return fail(PTX_ERR_INVALID, "conv3d_dual: the first source must be a unit-stride 1x1x1 conv");
+        if (d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA))
+            return fail(PTX_ERR_INVALID, "conv3d_dual: the second source replaces the residual operand");
+        if (d->x2_C <= 0 || d->x2_ld < d->x2_C || d->x2_ld % 4 || d->x2_sT <= 0 || d->x2_sH <= 0 || d->x2_sW <= 0 ||
+            (d->To - 1) * d->x2_sT >= d->x2_T || (d->Ho - 1) * d->x2_sH >= d->x2_H || (d->Wo - 1) * d->x2_sW >= d->x2_W)
+            return fail(PTX_ERR_INVALID, "conv3d_dual: second-source geometry out of range");
+        if ((uintptr_t)x2 & 15) return fail(PTX_ERR_INVALID, "conv3d_dual: x2 must be 16-byte aligned");
+        const uint64_t xb2 = (uint64_t)d->N * d->x2_T * d->x2_H * d->x2_W * d->x2_ld * 4ull;
+        const int kc2 = (d->x2_C + 3) / 4 * 4;
+        if (xb2 >= 0x80000000ull) return fail(PTX_ERR_UNSUPPORTED, "conv3d_dual: x2 must be < 2 GiB");
+        a.dual = 1; a.x2 = x2; a.x2_bytes = (unsigned)xb2;
+        a.ldx2 = d->x2_ld; a.kA2 = d->x2_ld; a.wcol2 = d->Kc;
+        a.T2 = d->x2_T; a.H2 = d->x2_H; a.W2 = d->x2_W; a.s2T = d->x2_sT; a.s2H = d->x2_sH; a.s2W = d->x2_sW;
+        // packed filter rows hold [Kc | Kc2] columns
+        a.ldw = d->Kc + kc2; a.kB = a.ldw; a.w_tap_stride = (long long)d->Co_pad * a.ldw;
+        a.w_bytes = (unsigned)((uint64_t)d->Co_pad * a.ldw * 4ull);
+        a.k_live = d->Ci + d->x2_C;
+    }
     return launch_conv(a, config, split_k, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ptx_conv3d_fwd(const ptx_conv3d_desc* d, const float* x, const float* w_packed, const float* bias,
+                              const float* res, float* y, void* workspace, size_t workspace_bytes, int config,
+                              int split_k, ptx_stream_t stream) {
+    return conv3d_common(d, x, nullptr, w_packed, bias, res, y, workspace, workspace_bytes, config, split_k, stream);
+}
+
+extern "C" int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed,
+                                   const float* bias, float* y, void* workspace, size_t workspace_bytes, int config,
+                                   int split_k, ptx_stream_t stream) {
+    if (!x2) return fail(PTX_ERR_INVALID, "conv3d_dual: x2 == NULL");
+    return conv3d_common(d, x, x2, w_packed, bias, nullptr, y, workspace, workspace_bytes, config, split_k, stream);
 }
 
 extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t batch, int32_t M, int32_t Nn,

@@ -46,14 +46,15 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const
             const size_t src = ((((size_t)co * d.Ci + c) * d.kT + kt) * d.kH + kh) * d.kW + kw;
             v = w[src] * bn_scale(gamma, var, eps, co);
         }
-        out[i] = v;
+        const size_t ld = d.ld_k > 0 ? (size_t)d.ld_k : (size_t)d.Kc;
+        out[((size_t)tap * d.Co_pad + co) * ld + d.k_off + k] = v;
     }
 }
 
 __global__ void pack_bias_kernel(int Co, int Co_pad, const float* __restrict__ conv_bias,
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, int accumulate) {
     const int co = blockIdx.x * blockDim.x + threadIdx.x;
     if (co >= Co_pad) return;
     float b = 0.f;
@@ -63,7 +64,7 @@ __global__ void pack_bias_kernel(int Co, int Co_pad, const float* __restrict__ c
         const float mu = mean ? mean[co] : 0.f;
         b = (beta ? beta[co] : 0.f) + (cb - mu) * s;
     }
-    out[co] = b;
+    out[co] = accumulate ? out[co] + b : b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -204,7 +205,7 @@ extern "C" const char* ptx_last_error(void) { return last_error_buf(); }
 extern "C" size_t ptx_packed_weight_elems(const ptx_pack_desc* d) {
     if (!d) return 0;
     const size_t taps = d->fold_kw ? (size_t)d->kT * d->kH : (size_t)d->kT * d->kH * d->kW;
-    return taps * d->Co_pad * d->Kc;
+    return taps * d->Co_pad * (d->ld_k > 0 ? d->ld_k : d->Kc);
 }
 
 extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, const float* conv_bias,
@@ -214,19 +215,23 @@ extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, cons
     if (!d || !w || !w_packed || !bias_out) return fail(PTX_ERR_INVALID, "pack: null pointer");
     if (d->Co <= 0 || d->Ci <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0)
         return fail(PTX_ERR_INVALID, "pack: non-positive extent");
+    if (d->ld_k < 0 || d->k_off < 0 || (d->ld_k > 0 && (d->k_off + d->Kc > d->ld_k || d->ld_k % 4 || d->k_off % 4)))
+        return fail(PTX_ERR_INVALID, "pack: bad K-concatenation window (ld_k=%d k_off=%d Kc=%d)", d->ld_k, d->k_off, d->Kc);
+    if (d->ld_k == 0 && d->k_off != 0) return fail(PTX_ERR_INVALID, "pack: k_off needs ld_k");
     const int keff = d->fold_kw ? d->kW * d->Ci : d->Ci;
     if (d->Kc < keff || d->Kc % 4 || d->Co_pad < d->Co || d->Co_pad % 128)
         return fail(PTX_ERR_INVALID, "pack: Kc=%d must cover K=%d (multiple of 4); Co_pad=%d must cover Co=%d (multiple of 128)",
                     d->Kc, keff, d->Co_pad, d->Co);
     if ((bn_gamma != nullptr) != (bn_var != nullptr))
         return fail(PTX_ERR_INVALID, "pack: bn_gamma and bn_var must be given together");
-    const size_t total = ptx_packed_weight_elems(d);
+    const size_t taps = d->fold_kw ? (size_t)d->kT * d->kH : (size_t)d->kT * d->kH * d->kW;
+    const size_t total = taps * d->Co_pad * d->Kc;     // elements written by this call (one K window)
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, st, *d, w, bn_gamma, bn_var, bn_eps,
                        w_packed, total);
     PTX_HIP(hipGetLastError());
     hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(d->Co_pad, 256)), dim3(256), 0, st, d->Co, d->Co_pad, conv_bias,
-                       bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, bias_out);
+                       bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, bias_out, d->bias_accumulate);
     return hip_check(hipGetLastError(), "pack launch");
 }
 

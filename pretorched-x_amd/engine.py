@@ -150,14 +150,49 @@ class Packed:
         return keep
 
 
+class PackedDual:
+    """K-concatenated filter of a bottleneck's last 1x1x1 conv (+BN) and its shortcut-B conv (+BN):
+    rows [Kc | Kc2], summed biases -- the operand of ptx_conv3d_dual_fwd."""
+
+    def __init__(self, dev, conv, bn, conv2, bn2):
+        self.parts = [(conv, bn), (conv2, bn2)]
+        self.Co, self.Ci, self.Ci2 = conv.out_channels, conv.in_channels, conv2.in_channels
+        assert conv2.out_channels == self.Co
+        self.Kc, self.Kc2 = _r4(self.Ci), _r4(self.Ci2)
+        self.Co_pad = _r128(self.Co)
+        self.k_eff = (1, 1, 1)
+        ld = self.Kc + self.Kc2
+        self.descs = [PackDesc(self.Co, self.Ci, 1, 1, 1, self.Kc, self.Co_pad, 0, ld, 0, 0),
+                      PackDesc(self.Co, self.Ci2, 1, 1, 1, self.Kc2, self.Co_pad, 0, ld, self.Kc, 1)]
+        self.d = self.descs[0]
+        self.w = torch.zeros(self.Co_pad * ld, device=dev, dtype=torch.float32)
+        self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
+
+    def refresh(self):
+        null = C.c_void_p(0)
+        for d, (conv, bn) in zip(self.descs, self.parts):
+            w = conv.weight.detach().contiguous()
+            cb = conv.bias.detach().contiguous() if conv.bias is not None else None
+            ts = [t.contiguous() for t in (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)]
+            check(_lib.lib().ptx_pack_conv_weight(C.byref(d), _ptr(w), _ptr(cb) if cb is not None else null,
+                                                  _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]),
+                                                  C.c_float(float(bn.eps)), _ptr(self.w), _ptr(self.b), _stream()),
+                  "ptx_pack_conv_weight (dual)")
+
+
 class ConvStep:
-    """One ptx_conv3d_fwd launch with everything but the stream frozen."""
-    __slots__ = ("d", "x", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs")
+    """One ptx_conv3d_fwd (or, with a second source, ptx_conv3d_dual_fwd) launch with everything but
+    the stream frozen."""
+    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs")
 
     def __call__(self, st):
         p = self.plan
-        check(_lib.lib().ptx_conv3d_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
-                                        p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
+        if self.x2 is not None:
+            check(_lib.lib().ptx_conv3d_dual_fwd(C.byref(self.d), self.x, self.x2, self.w, self.b, self.y,
+                                                 p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
+        else:
+            check(_lib.lib().ptx_conv3d_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
+                                            p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
 
 
 class Plan:
@@ -176,6 +211,7 @@ class Plan:
         self.in_ptr = C.c_void_p(0)      # set per run
         self.keepalive = []
         self.tuned = False
+        self.fuse_shortcut = os.environ.get("PTX_FUSE_SHORTCUT", "1") != "0"
         with _device_ctx(dev):
             self._build(model)
             if self.ws_bytes:
@@ -193,13 +229,21 @@ class Plan:
             self.packs.append(p)
         return self._pack_cache[key]
 
+    def pack_dual(self, conv, bn, conv2, bn2):
+        key = ("dual", id(conv), id(bn), id(conv2), id(bn2))
+        if key not in self._pack_cache:
+            p = PackedDual(self.dev, conv, bn, conv2, bn2)
+            self._pack_cache[key] = p
+            self.packs.append(p)
+        return self._pack_cache[key]
+
     def act(self, N, T, H, W, C_, ld=None):
         a = Act(self.dev, N, T, H, W, C_, ld)
         self.acts.append(a)      # steps hold raw pointers: the plan owns every buffer
         return a
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
-             pro_relu=False, label="conv", y=None):
+             pro_relu=False, label="conv", y=None, x2=None, x2_stride=1):
         kT, kH, kW = pk.k_eff
         sT, sH, sW = stride
         pT, pH, pW = padding
@@ -230,6 +274,12 @@ class Plan:
         st.d, st.x, st.w, st.b, st.res, st.y = d, _ptr(x.t), _ptr(pk.w), _ptr(pk.b), resptr, _ptr(y.t)
         st.plan, st.label = self, label
         st.macs = x.N * To * Ho * Wo * pk.Co * pk.Ci * pk.d.kT * pk.d.kH * pk.d.kW
+        st.x2 = None
+        if x2 is not None:                      # K-concatenated second activation source (shortcut B)
+            d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = x2.C, x2.ld, x2.T, x2.H, x2.W
+            d.x2_sT = d.x2_sH = d.x2_sW = int(x2_stride)
+            st.x2 = _ptr(x2.t)
+            st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
         tuned = _tuned_table().get(key)
         if tuned is not None:
@@ -359,6 +409,19 @@ class Plan:
 
     def _block(self, arch, blk, x, name):
         s = blk.stride
+        fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block == "bottleneck"
+                and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.downsample[0], (nn.Conv3d, nn.Conv2d)))
+        if fuse:
+            # conv3 + bn3 and the shortcut conv + bn share the output tile: one GEMM over the
+            # concatenated K = [conv2 output channels | block input channels (strided gather)], no
+            # residual tensor is materialised (reference resnet3D.py:135-142 + :176-185)
+            o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
+            o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
+            pk = self.pack_dual(blk.conv3, blk.bn3, blk.downsample[0], blk.downsample[1])
+            o = self.conv(o, pk, (1, 1, 1), (0, 0, 0), relu=True, x2=x, x2_stride=s, label=name + ".conv3+downsample")
+            if blk.has_nl:
+                o = self.nonlocal_block(o, blk.nonlocalblock, name + ".nonlocalblock")
+            return o
         if blk.has_shortcut and arch.shortcut == "B":
             res = self.conv_bn(x, blk.downsample[0], blk.downsample[1], label=name + ".downsample")
             kind = None

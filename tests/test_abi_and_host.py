@@ -28,8 +28,9 @@ def test_struct_layouts_match_header(ptx):
     text = open(L.HEADER_PATH).read()
 
     def fields_of(struct):
+        import re
         body = text.split("typedef struct %s {" % struct)[1].split("}")[0]
-        body = "\n".join(line.split("/*")[0] for line in body.splitlines())
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         out = []
         for decl in body.split(";"):
             decl = decl.strip()
@@ -110,13 +111,26 @@ def test_no_cpu_fallback(ptx):
 
 
 def test_plan_compiler_matches_survey_worklist(ptx):
-    """config 2 = 53 convs, 318.763 GMAC, 23 distinct problems."""
+    """config 2 = 53 convs, 318.763 GMAC, 23 distinct problems.  The engine
+    folds each stage's shortcut-B conv into the block's last conv (one K-concatenated GEMM), so it
+    launches 49 kernels for the same 53 convs / the same MACs."""
     m = ptx.resnet3d50(num_classes=339, pretrained=None)
     plan = m.engine().dry_plan(m, (8, 3, 16, 224, 224))
-    assert len(plan.conv_steps) == 53
+    assert len(plan.conv_steps) == 49
+    fused = [s for s in plan.conv_steps if s.x2 is not None]
+    assert [s.label for s in fused] == ["layer%d.0.conv3+downsample" % i for i in (1, 2, 3, 4)]
+    assert (fused[1].d.x2_C, fused[1].d.x2_sT, fused[1].d.Ci, fused[1].d.Co) == (256, 2, 128, 512)
     gmac = sum(s.macs for s in plan.conv_steps) / 1e9
     assert abs(gmac - 318.763) < 0.01
-    geom = {s.d.key()[:22] for s in plan.conv_steps}              # geometry only (no epilogue flags):
+    import os
+    os.environ["PTX_FUSE_SHORTCUT"] = "0"
+    try:
+        m2 = ptx.resnet3d50(num_classes=339, pretrained=None)
+        plan2 = m2.engine().dry_plan(m2, (8, 3, 16, 224, 224))
+    finally:
+        del os.environ["PTX_FUSE_SHORTCUT"]
+    assert len(plan2.conv_steps) == 53
+    geom = {s.d.key()[:22] for s in plan2.conv_steps}             # geometry only (no epilogue flags):
     assert len(geom) == 23                                        # C4 covers conv3 and the shortcut
     assert tuple(plan.feat.t.shape) == (8, 1, 7, 7, 2048)
     stem = plan.conv_steps[0].d

@@ -219,6 +219,51 @@ def test_conv_epilogues(ptx):
           ref_conv(x, w3, (2, 2, 2), one, bn=bn, relu=True, res_pad=rp2, res_stride=2))
 
 
+def test_dual_source_conv(ptx):
+    """ptx_conv3d_dual_fwd == relu(bn3(conv3(o)) + bn_d(conv_d(x)[stride s])) (resnet3D.py:135-142, :176-185),
+    i.e. a bottleneck's last conv with its shortcut-B branch folded in as extra K columns."""
+    L, lib = ptx._lib, _lib(ptx)
+    null = C.c_void_p(0)
+    for (N, T, H, W, C1, C2, Co, s_) in [(2, 4, 8, 8, 64, 64, 256, 1), (2, 2, 7, 7, 128, 256, 512, 2), (1, 1, 5, 6, 20, 36, 72, 2)]:
+        T2, H2, W2 = (T - 1) * s_ + 1, (H - 1) * s_ + 1 + (s_ - 1), (W - 1) * s_ + 1
+        o, x = rnd(N, C1, T, H, W, seed=60), rnd(N, C2, T2, H2, W2, seed=61)
+        w3, wd = rnd(Co, C1, 1, 1, 1, seed=62, scale=C1 ** -0.5), rnd(Co, C2, 1, 1, 1, seed=63, scale=C2 ** -0.5)
+        bn3, bnd = make_bn(Co, 64), make_bn(Co, 65)
+        want = ref_conv(o, w3, (1, 1, 1), (0, 0, 0), bn=bn3) + ref_conv(x, wd, (s_, s_, s_), (0, 0, 0), bn=bnd)
+        want = F.relu(want)
+        Kc, Kc2, Co_pad = _r4(C1), _r4(C2), (Co + 127) // 128 * 128
+        ld = Kc + Kc2
+        wp = torch.full((Co_pad * ld,), float("nan"), device=DEV)
+        bp = torch.full((Co_pad,), float("nan"), device=DEV)
+        for (wt, bn, Ci_, kc, koff, acc) in ((w3, bn3, C1, Kc, 0, 0), (wd, bnd, C2, Kc2, Kc, 1)):
+            pd = L.PackDesc(Co, Ci_, 1, 1, 1, kc, Co_pad, 0, ld, koff, acc)
+            ts = [t.to(DEV) for t in bn[:4]]
+            wdv = wt.contiguous().to(DEV)
+            L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wdv), null, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                             C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack dual")
+            torch.cuda.synchronize()
+        od, xd = to_cl(o), to_cl(x)
+        ldy = _r4(Co)
+        for cfg, split in ((-1, 0), (2, 1), (24, 1), (28, 2), (30, 1), (44, 1)):
+            yd = torch.full((N, T, H, W, ldy), float("nan"), device=DEV)
+            d = L.ConvDesc()
+            d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C1, od.shape[-1]
+            d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, Co, ldy
+            d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+            d.Kc, d.Co_pad, d.flags = Kc, Co_pad, L.PTX_EPI_RELU
+            d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = C2, xd.shape[-1], T2, H2, W2
+            d.x2_sT = d.x2_sH = d.x2_sW = s_
+            ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
+            ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
+            L.check(lib.ptx_conv3d_dual_fwd(C.byref(d), _p(od), _p(xd), _p(wp), _p(bp), _p(yd), _p(ws), ws_bytes, cfg,
+                                            split, _st()), "dual conv")
+            torch.cuda.synchronize()
+            close(from_cl(yd, Co), want)
+    # the second source may not be combined with a residual operand
+    d.flags = L.PTX_EPI_RES_ADD
+    assert lib.ptx_conv3d_dual_fwd(C.byref(d), _p(od), _p(xd), _p(wp), _p(bp), _p(yd), None, 0, -1, 1, _st()) == 1
+
+
 def test_stem_fold_path(ptx):
     """ptx_fold_kw_ncdhw + fold_kw weight pack + (7,7,1) conv == Conv3d(3,64,7,s(1,2,2),p3) + BN + ReLU
     (resnet3D.py:153-155)."""
