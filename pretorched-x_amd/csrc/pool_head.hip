@@ -39,6 +39,56 @@ __global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const
     }
 }
 
+// k = 3, s = 2, p = 1 along W (the reference's only pooling geometry, resnet3D.py:156): a thread
+// produces WSEG consecutive outputs of one (n, to, ho, 4-channel group) and slides along W, so the
+// input column shared by neighbouring windows is loaded once: (2*WSEG + 1) * kT * kH loads for WSEG
+// outputs (19 per output at WSEG = 8) instead of 27.
+template <int WSEG>
+__global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
+                                                              float* __restrict__ y, size_t total) {
+    const int f4r = d.ld / 4;
+    const int segs = (d.Wo + WSEG - 1) / WSEG;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % f4r);
+        size_t r = i / f4r;
+        const int seg = (int)(r % segs);
+        r /= segs;
+        const int ho = (int)(r % d.Ho);
+        r /= d.Ho;
+        const int to = (int)(r % d.To);
+        const int n = (int)(r / d.To);
+        const int t_lo = max(0, to * d.sT - d.pT), t_hi = min(d.Ti, to * d.sT - d.pT + d.kT);
+        const int h_lo = max(0, ho * d.sH - d.pH), h_hi = min(d.Hi, ho * d.sH - d.pH + d.kH);
+        const float* base = x + ((size_t)n * d.Ti * d.Hi * d.Wi) * d.ld + q * 4;
+        auto colmax = [&](int w) -> f32x4 {
+            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (w < 0 || w >= d.Wi) return m;
+            for (int t = t_lo; t < t_hi; ++t)
+                for (int h = h_lo; h < h_hi; ++h) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (((size_t)t * d.Hi + h) * d.Wi + w) * d.ld);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
+                    m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            return m;
+        };
+        const int wo0 = seg * WSEG;
+        f32x4 prev = colmax(2 * wo0 - 1);
+        float* yrow = y + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo) * d.ld + q * 4;
+#pragma unroll
+        for (int j = 0; j < WSEG; ++j) {
+            const int wo = wo0 + j;
+            if (wo < d.Wo) {
+                const f32x4 c0 = colmax(2 * wo), c1 = colmax(2 * wo + 1);
+                f32x4 o;
+                o.x = fmaxf(prev.x, fmaxf(c0.x, c1.x)); o.y = fmaxf(prev.y, fmaxf(c0.y, c1.y));
+                o.z = fmaxf(prev.z, fmaxf(c0.z, c1.z)); o.w = fmaxf(prev.w, fmaxf(c0.w, c1.w));
+                *reinterpret_cast<f32x4*>(yrow + (size_t)wo * d.ld) = o;
+                prev = c1;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // global average pool
 // ---------------------------------------------------------------------------------------------
@@ -213,6 +263,13 @@ extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float
     const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
     if (to != d->To || ho != d->Ho || wo != d->Wo) return fail(PTX_ERR_INVALID, "maxpool3d: output extent mismatch");
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "maxpool3d: misaligned pointer");
+    if (d->kW == 3 && d->sW == 2 && d->pW == 1 && d->Wo >= 8) {
+        constexpr int WSEG = 8;
+        const size_t total = (size_t)d->N * d->To * d->Ho * cdiv(d->Wo, WSEG) * (d->ld / 4);
+        hipLaunchKernelGGL(maxpool3d_slide_kernel<WSEG>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d, x,
+                           y, total);
+        return hip_check(hipGetLastError(), "maxpool3d launch");
+    }
     const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (d->ld / 4);
     hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, *d, x, y, total4);
     return hip_check(hipGetLastError(), "maxpool3d launch");
