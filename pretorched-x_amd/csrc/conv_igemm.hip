@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // loading and to the fragment read address (cdna_hip_programming.md rule 21).
     constexpr int LDK = DMA ? BK : BK + 4;
     static_assert(!DMA || (!K22 && (BK == 32 || BK == 16)), "DMA staging: BK 32 or 16");
-    static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "3-stage ring needs DMA staging");
+    static_assert(NSTAGE == 2 || (NSTAGE >= 3 && NSTAGE <= 6 && DMA), "deeper rings need DMA staging");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
     static_assert(TM * MT * WM == BM && TN * MT * WN == BN, "tile must split evenly");
@@ -231,22 +231,28 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         b_off[i] = ok ? ((unsigned)(n0 + row) * (unsigned)p.ldw + (unsigned)col) * 4u : kOOB;
     }
 
-    // ---- block-uniform tap pruning: taps that only ever see zero padding are skipped ----
+    // ---- block-uniform tap pruning: a (kt, kh) tap plane that lands in the zero padding for EVERY
+    // row of this tile is skipped.  Exact for any tile (also when it straddles frames or clips): the
+    // per-row validity bitmasks are OR-reduced over the workgroup (wave shuffles + one LDS word). ----
     int kt_lo = 0, kt_hi = p.kT - 1, kh_lo = 0, kh_hi = p.kH - 1;
-    {
-        const int m_last = min(m0 + BM, p.M) - 1;
-        const int plane = p.Ho * p.Wo;
-        const int vol = p.To * plane;
-        if (m0 / vol == m_last / vol) {
-            const int to_a = (m0 % vol) / plane, to_b = (m_last % vol) / plane;
-            kt_lo = max(0, p.pT - to_b * p.sT);
-            kt_hi = min(p.kT - 1, p.Ti - 1 + p.pT - to_a * p.sT);
-            if (to_a == to_b) {
-                const int ho_a = (m0 % plane) / p.Wo, ho_b = (m_last % plane) / p.Wo;
-                kh_lo = max(0, p.pH - ho_b * p.sH);
-                kh_hi = min(p.kH - 1, p.Hi - 1 + p.pH - ho_a * p.sH);
-            }
-        }
+    if (p.kT * p.kH > 1) {
+        unsigned m_or = 0;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) m_or |= a_mask[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m_or |= (unsigned)__shfl_xor((int)m_or, o, 64);
+        unsigned* scratch = reinterpret_cast<unsigned*>(smem);     // tile buffers are not live yet
+        if (tid == 0) scratch[0] = 0u;
+        __syncthreads();
+        if (lane == 0) atomicOr(&scratch[0], m_or);
+        __syncthreads();
+        m_or = scratch[0];
+        __syncthreads();                                            // before the first tile lands here
+        const unsigned mt = m_or & 0xFFu, mh = (m_or >> 8) & 0xFFu;
+        kt_lo = mt ? __builtin_ctz(mt) : 1;
+        kt_hi = mt ? 31 - __builtin_clz(mt) : 0;
+        kh_lo = mh ? __builtin_ctz(mh) : 1;
+        kh_hi = mh ? 31 - __builtin_clz(mh) : 0;
     }
     // The block iterates the PRUNED k-space {kt_lo..kt_hi} x {kh_lo..kh_hi} x kW x kchunks, tap-major,
     // channel-chunk-minor; split-K slices that space evenly.  (kt, kh, kw, ch) is the next k-step to
@@ -453,38 +459,41 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // (its last fragments were completed before that barrier), so step s may overwrite it; those
     // writes complete (lgkmcnt(0)) before the barrier of step s, after which step s+1 reads them.
     constexpr int STORE_KS = KSUB >= 3 ? 1 : 0;
-    if constexpr (DMA && NSTAGE == 3) {
-        // 3-stage LDS-DMA ring: tile s+3 is requested right after the barrier of step s, i.e. two full
-        // k-steps before it is read.  Every wave issues exactly NPS DMA instructions per step, so a
-        // counted `s_waitcnt vmcnt(NPS)` before the raw barrier retires tile s+1 while tile s+2 stays
-        // in flight (a plain __syncthreads() would drain everything -- cdna_hip_programming.md 5).
+    if constexpr (DMA && NSTAGE >= 3) {
+        // N-stage LDS-DMA ring: tile s+NSTAGE is requested right after the barrier of step s, i.e.
+        // NSTAGE-1 k-steps before it is read.  Every wave issues exactly NPS DMA instructions per
+        // step, so a counted `s_waitcnt vmcnt((NSTAGE-2)*NPS)` before the raw barrier retires tile s+1
+        // while the younger tiles stay in flight (a plain __syncthreads() would drain everything --
+        // cdna_hip_programming.md section 5).
         static_assert(A_F4 % NT == 0 && B_F4 % NT == 0, "uniform DMA count per wave");
         constexpr int NPS = A_IT + B_IT;
+        static_assert((NSTAGE - 2) * NPS < 64, "vmcnt field");
         auto ring_barrier = [&]() {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NPS) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NSTAGE - 2) * NPS) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
         if (my_steps > 0) {
-            load_tiles(true, 0);
-            advance();
-            load_tiles(my_steps > 1, 1);
-            advance();
+#pragma unroll
+            for (int t = 0; t < NSTAGE - 1; ++t) {
+                load_tiles(t < my_steps, t);
+                advance();
+            }
             ring_barrier();
             int offa = frag_off_a, offb = frag_off_b;
             post_barrier_offsets(offa, offb);
-            load_tiles(my_steps > 2, 2);
+            load_tiles(NSTAGE - 1 < my_steps, NSTAGE - 1);
             advance();
             read_frags(0, 0, 0, offa, offb);
             int cur = 0;
             for (int it = 0; it < my_steps; ++it) {
-                const int nxt = cur == 2 ? 0 : cur + 1;
+                const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
 #pragma unroll
                 for (int ks = 0; ks < KSUB; ++ks) {
                     if (ks == KSUB - 1) {
                         ring_barrier();
                         post_barrier_offsets(offa, offb);
-                        load_tiles(it + 3 < my_steps, cur);
+                        load_tiles(it + NSTAGE < my_steps, cur);
                         advance();
                         read_frags(nxt, 0, (ks + 1) % NSLOT, offa, offb);
                     } else {
@@ -668,6 +677,8 @@ struct ConvConfig {
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2> }
 #define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3> }
+#define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4> }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -725,6 +736,12 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA3(128, 128, 32, 4, 2, 32), // 48
     PTX_CFG_DMA3(64, 128, 16, 2, 2, 32),  // 49
     PTX_CFG_DMA3(128, 64, 16, 2, 2, 32),  // 50
+    // 4-stage rings for small grids (layer3 / layer4: <= 2 workgroups per CU, latency bound per k-step)
+    PTX_CFG_DMA4(32, 64, 32, 2, 2, 16),   // 51
+    PTX_CFG_DMA4(64, 64, 32, 2, 2, 32),   // 52
+    PTX_CFG_DMA4(32, 128, 32, 2, 2, 16),  // 53
+    PTX_CFG_DMA4(64, 64, 16, 2, 2, 32),   // 54
+    PTX_CFG_DMA4(64, 128, 32, 2, 2, 32),  // 55
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
