@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // XOR swizzle of the 16-byte slot index that is applied to the per-lane SOURCE address when
     // loading and to the fragment read address (cdna_hip_programming.md rule 21).
     constexpr int LDK = DMA ? BK : BK + 4;
-    static_assert(!DMA || (!K22 && (BK == 32 || BK == 16)), "DMA staging: BK 32 or 16");
+    static_assert(!DMA || (!K22 && (BK == 64 || BK == 32 || BK == 16)), "DMA staging: BK 64, 32 or 16");
     static_assert(NSTAGE == 2 || (NSTAGE >= 3 && NSTAGE <= 6 && DMA), "deeper rings need DMA staging");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
@@ -127,10 +127,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     constexpr int F4R = BK / 4;              // float4 per tile row
     constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
     constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
-    // swizzle: physical 16-B slot = logical slot ^ ((row >> SWS) & (F4R - 1)); with 128-B rows (F4R 8)
-    // SWS = 1, with 64-B rows (F4R 4) SWS = 2 -- any 16 distinct rows of a ds_read_b128 lane group
-    // then cover all 16 slots of the 256-B bank row.
-    constexpr int SWS = (F4R == 8) ? 1 : 2;
+    // swizzle: physical 16-B slot = logical slot ^ ((row >> SWS) & (F4R - 1)); with 256-B rows (F4R 16)
+    // SWS = 0, with 128-B rows (F4R 8) SWS = 1, with 64-B rows (F4R 4) SWS = 2 -- any 16 distinct
+    // rows of a ds_read_b128 lane group then cover all 16 slots of the 256-B bank row.
+    constexpr int SWS = (F4R == 16) ? 0 : (F4R == 8) ? 1 : 2;
     auto swz_col = [&](int idx) -> int {       // logical channel column fetched by staging slot idx
         const int row = idx / F4R, ps = idx % F4R;
         return (DMA ? (ps ^ ((row >> SWS) & (F4R - 1))) : ps) * 4;
@@ -742,6 +742,12 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA4(32, 128, 32, 2, 2, 16),  // 53
     PTX_CFG_DMA4(64, 64, 16, 2, 2, 32),   // 54
     PTX_CFG_DMA4(64, 128, 32, 2, 2, 32),  // 55
+    // BK = 64: half as many barriers per MFMA for long-K problems on small grids
+    PTX_CFG_DMA(64, 64, 64, 2, 2, 32),    // 56
+    PTX_CFG_DMA(32, 64, 64, 2, 2, 16),    // 57
+    PTX_CFG_DMA(64, 128, 64, 2, 2, 32),   // 58
+    PTX_CFG_DMA(32, 128, 64, 2, 2, 16),   // 59
+    PTX_CFG_DMA(128, 64, 64, 4, 2, 32),   // 60
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -662,6 +662,8 @@ class Engine:
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
                     if (bk == 24) != (stp.d.Kc == 24):      # BK = 24 tiles are for the kW-folded stem only
                         continue
+                    if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
+                        continue
                     if bn_ > 64 and stp.d.ldy <= 64:
                         continue
                     if bn_ % 48 == 0 and stp.d.ldy % 48 != 0:     # 48/96-wide tiles: (2+1)D widths only

@@ -12,7 +12,7 @@ root = sys.argv[1]
 
 
 def short(name):
-    return name.replace("void ptx::", "").replace("ptx::", "").replace("(ptx::ConvArgs)", "")[:60]
+    return name.replace("void ptx::", "").replace("ptx::", "").replace("(ptx::ConvArgs)", "").replace("conv_igemm_kernel", "conv_igemm")[:60]
 
 
 for f in sorted(glob.glob(os.path.join(root, "trace*", "*.db"))):

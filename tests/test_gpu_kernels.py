@@ -181,14 +181,16 @@ def test_conv_dma_bit_exact_vs_register_staged(ptx):
                  "128x128x32/4x2/m32/dma", "64x128x16/2x2/m32/dma", "256x64x32/8x1/m32/dma",
                  "64x64x16/2x2/m32/dma3", "64x64x32/2x2/m32/dma3", "128x64x32/4x2/m32/dma3",
                  "128x128x32/4x2/m32/dma3", "64x128x16/2x2/m32/dma3", "128x64x16/2x2/m32/dma3",
-                 "64x64x32/2x2/m32/dma4", "64x64x16/2x2/m32/dma4", "64x128x32/2x2/m32/dma4"):
+                 "64x64x32/2x2/m32/dma4", "64x64x16/2x2/m32/dma4", "64x128x32/2x2/m32/dma4",
+                 "64x64x64/2x2/m32/dma", "64x128x64/2x2/m32/dma", "128x64x64/4x2/m32/dma"):
         for rep in range(6):
             got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
             assert torch.equal(got, base), "%s differs from the register-staged result (rep %d)" % (name, rep)
     # 16x16x4 family among themselves
     base16 = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index("112x64x32/1x4/m16"), split=1)
     for name in ("32x64x32/2x2/m16/dma", "112x64x32/1x4/m16/dma", "32x128x32/2x2/m16/dma", "64x32x32/2x2/m16/dma",
-                 "32x64x32/2x2/m16/dma3", "32x64x32/2x2/m16/dma4", "32x128x32/2x2/m16/dma4"):
+                 "32x64x32/2x2/m16/dma3", "32x64x32/2x2/m16/dma4", "32x128x32/2x2/m16/dma4",
+                 "32x64x64/2x2/m16/dma", "32x128x64/2x2/m16/dma"):
         for rep in range(6):
             got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
             assert torch.equal(got, base16), "%s differs (rep %d)" % (name, rep)
