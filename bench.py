@@ -115,14 +115,19 @@ def main():
         # may under-report wide streaming reads by up to 2x on gfx950 -- reported uncorrected)
         traffic = None
         try:
+            import re
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            bm_, bn_, bk_ = dom_name.split("/")[0].split("x")
-            wm_, wn_ = dom_name.split("/")[1].split("x")
-            pat = "conv_igemm_kernel<%s, %s, %s, %s, %s, %s," % (bm_, bn_, bk_, wm_, wn_, dom_name.split("/m")[1].split("/")[0])
-            want_dma = dom_name.endswith("/dma")
+            tile, waves, mt = dom_name.split("/")[:3]
+            stage = dom_name.split("/")[3] if dom_name.count("/") >= 3 else ""
+            want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
+            want_dma = stage.startswith("dma")
+            want_nstage = int(stage[3:]) if len(stage) > 3 else 2
             for k, v in tj.items():
-                if k.startswith(pat) and (k.rstrip("(").rstrip(">").endswith("true") == want_dma) \
-                        and v.get("WRITE_SIZE_KiB") is not None:
+                m = re.match(r"conv_igemm<([^>]*)>", k)
+                if not m or v.get("WRITE_SIZE_KiB") is None:
+                    continue
+                targs = [a.strip() for a in m.group(1).split(",")]
+                if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
                     traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
                     break
         except Exception:
