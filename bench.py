@@ -150,7 +150,7 @@ def main():
         # ---- CPU baseline: the oracle restatement of the reference path on this box's host cores ----
         cpu = None
         parity = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
             from oracle import functional as OF
             cfg = OF.ARCHS["resnet3d50"]
             ncpu = os.cpu_count() or 1
