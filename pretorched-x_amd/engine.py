@@ -211,6 +211,7 @@ class Plan:
         self.in_ptr = C.c_void_p(0)      # set per run
         self.keepalive = []
         self.tuned = False
+        self.graph = None
         self.fuse_shortcut = os.environ.get("PTX_FUSE_SHORTCUT", "1") != "0"
         with _device_ctx(dev):
             self._build(model)
@@ -482,6 +483,10 @@ class Engine:
         # tile configurations of conv problems that are not in the tuned table are timed (HIP events,
         # < 1 s per network) the first time a plan runs; PTX_AUTOTUNE=0 keeps the heuristic defaults
         self.auto_tune = os.environ.get("PTX_AUTOTUNE", "1") != "0"
+        # opt-in hipGraph replay of forward(): the whole plan (+ pool + classifier) is captured once per
+        # (shape, device) and replayed -- one host call instead of ~90 launches.  Pays off for
+        # launch-bound shapes (small clips / batch 1); neutral at config-2 size.
+        self.use_graph = os.environ.get("PTX_GRAPH", "0") == "1"
 
     def __deepcopy__(self, memo):
         return Engine()
@@ -615,6 +620,34 @@ class Engine:
             if any(json.dumps(s.d.key()) not in _tuned_table() for s in plan.conv_steps):
                 self.autotune(model, x, iters=2, only_untuned=True)
 
+    def _forward_graph(self, model, plan, x):
+        """Capture (once) and replay forward() as a hipGraph.  The input is staged into a static
+        buffer; the logits are copied out of the graph's private pool."""
+        head = model.head_module
+        key = (id(head), head.weight.data_ptr() if isinstance(head, nn.Linear) else 0)
+        g = plan.graph
+        if g is None or g["key"] != key:
+            static_x = torch.empty_like(x)
+            static_x.copy_(x)
+            self._forward_eager(model, plan, static_x)            # warm-up: everything allocated / tuned
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._forward_eager(model, plan, static_x)
+            g = plan.graph = dict(key=key, graph=graph, x=static_x, out=static_out)
+        g["x"].copy_(x)
+        g["graph"].replay()
+        return g["out"].clone()
+
+    def _forward_eager(self, model, plan, x):
+        f = plan.run_features(x)
+        check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
+              "ptx_global_avgpool")
+        out = self._head(model, _ptr(plan.pooled), f.N, f.C, x.device)
+        if out is None:
+            out = model.head_module(plan.pooled.clone())
+        return out
+
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""
         self._validate(model, x, model.arch.dims)
@@ -625,6 +658,8 @@ class Engine:
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
+            if self.use_graph:
+                return self._forward_graph(model, plan, x)
             f = plan.run_features(x)
             check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
                   "ptx_global_avgpool")

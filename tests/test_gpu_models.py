@@ -185,6 +185,41 @@ def test_oversized_batches_are_split(ptx):
     assert (sf - wf).abs().max().item() <= 1e-5 * max(1.0, wf.abs().max().item())
 
 
+def test_hipgraph_replay_matches_eager(ptx):
+    """Opt-in hipGraph mode: forward() captured once per shape and replayed; same kernels, so the
+    logits are bit-identical to the eager launches, also after an in-place weight update (the packed
+    filters are refreshed outside the graph, in the buffers the graph reads)."""
+    import time
+    model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), 7)
+    xs = [synth_clips(1, 8, 64, s).to(DEV) for s in (1, 2, 3)]
+    eager = [model(x).clone() for x in xs]
+    eng = model.engine()
+    eng.use_graph = True
+    try:
+        for x, want in zip(xs, eager):
+            assert torch.equal(model(x), want)
+        with torch.no_grad():
+            model.layer3[1].bn2.weight.mul_(1.25)
+        got = model(xs[0])
+        eng.use_graph = False
+        assert torch.equal(model(xs[0]), got) and not torch.equal(got, eager[0])
+        # launch-bound shape: replay should not be slower than ~90 eager launches
+        def bench(n=30):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                model(xs[0])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t_eager = bench()
+        eng.use_graph = True
+        model(xs[0])
+        t_graph = bench()
+        print("1x3x8x64x64 forward: eager %.3f ms, hipGraph replay %.3f ms" % (t_eager, t_graph))
+    finally:
+        eng.use_graph = False
+
+
 def test_autotune_keeps_parity(ptx):
     blob = load_golden("resnet3d50_small")
     model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), int(blob["w_seed"]))
