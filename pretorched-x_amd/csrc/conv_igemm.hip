@@ -2,16 +2,26 @@
 // bias(+folded BN) + residual + ReLU epilogue.  Channels-last activations (NDHWC), K-major
 // packed filters.  One kernel template serves every conv of the hot path:
 // the 7x7x7 stem (after the kW fold), 3x3x3 body, 1x1x1 pointwise / shortcut-B, the (1,k,k) and
-// (k,1,1) factored convs, and -- in batched mode -- the non-local block's NT matmuls.
+// (k,1,1) factored convs, the two-source "conv3 + shortcut" GEMM and -- in batched mode -- the
+// non-local block's NT matmuls.
 //
 // GEMM view:  M = N*To*Ho*Wo output positions, N = Co, K = taps * Ci.
 //   A[m][k]  gathered on the fly from x (zero outside the image): for one filter tap the BK
-//            channels of a row are contiguous in NDHWC, so every lane issues one 16-byte load.
+//            channels of a row are contiguous in NDHWC, so every lane moves one 16-byte piece.
 //   B[n][k]  = w_packed[tap][co][c]  (K contiguous).
-// Both operand tiles are staged global -> registers -> LDS ([rows][BK+4] floats: the +4 pad makes
-// the ds_read_b128 fragment reads of 32 distinct rows conflict-free) and double buffered: the
-// loads of k-step s+1 are issued before the MFMAs of step s and written to the other buffer
-// after them, one barrier per k-step.
+// Staging, two flavours per tile shape:
+//   * LDS-DMA (default): `buffer_load ... lds` writes 16 B per lane straight into a lane-linear,
+//     UNPADDED LDS image; ds_read_b128 bank conflicts are avoided by XOR-swizzling the 16-byte slot
+//     index on the per-lane SOURCE address and on the fragment read address.  2..4-stage ring.
+//   * register-staged: global -> VGPR -> LDS ([rows][BK+4] floats), used by the BK = 24 stem tile.
+// Every load is branch-free: anything that must read as zero (padding taps, rows >= M, channel
+// tails) gets a byte offset >= num_records of the buffer resource, for which the hardware returns /
+// writes 0 without touching memory.  Per-row base offsets and tap-validity bitmasks are hoisted
+// out of the k-loop (4 VALU per activation load, 1 per filter load).
+// The k-step is software-pipelined inside the wave: the barrier sits before the last sub-step,
+// whose fragments are already in registers; the next tile's first fragments are requested under
+// those MFMAs.  Taps that are padding for EVERY row of the tile are skipped (exact, OR of the row
+// masks over the workgroup); split-K slices the pruned k-space.
 //
 // MFMA: v_mfma_f32_32x32x2_f32 (or 16x16x4): lane l supplies A[row = l % MT][k = l / MT] and
 // B[k = l / MT][col = l % MT].  A lane's ds_read_b128 returns 4 consecutive k of its row; the

@@ -244,7 +244,7 @@ class Plan:
         return a
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
-             pro_relu=False, label="conv", y=None, x2=None, x2_stride=1):
+             label="conv", y=None, x2=None, x2_stride=1):
         kT, kH, kW = pk.k_eff
         sT, sH, sW = stride
         pT, pH, pW = padding
@@ -253,7 +253,7 @@ class Plan:
         Wo = (x.W + 2 * pW - kW) // sW + 1
         if y is None:
             y = self.act(x.N, To, Ho, Wo, pk.Co)
-        flags = (PTX_EPI_RELU if relu else 0) | (PTX_PRO_RELU if pro_relu else 0)
+        flags = PTX_EPI_RELU if relu else 0
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
         d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, y.ld

@@ -143,6 +143,43 @@ def test_plan_compiler_matches_survey_worklist(ptx):
         assert abs(sum(s.macs for s in pl.conv_steps) / 1e9 - gm) < 0.01, name
 
 
+def test_every_factory_compiles_a_plan(ptx):
+    """All exported video factories build and compile (dry plan, no GPU): deep ResNet3Ds, the I3D-style
+    inflated variant, (2+1)D and non-local nets."""
+    cases = [("resnet3d101", dict(num_classes=400, pretrained=None), 101), ("resnet3d152", dict(num_classes=400, pretrained=None), 152),
+             ("resnet3d200", dict(pretrained=None), 200), ("resneti3d50", dict(num_classes=400, pretrained=None), 50),
+             ("r2plus1d34", dict(num_classes=400), None), ("nonlocalresnet3d50", dict(num_nonlocal_blocks=10, pretrained=None), None)]
+    for name, kw, depth in cases:
+        m = ptx.__dict__[name](**kw)
+        plan = m.engine().dry_plan(m, (1, 3, 8, 64, 64))
+        if depth:     # conv layers of a bottleneck ResNet-d: d - 2 (+4 shortcut convs), 4 of them fused away
+            assert sum(1 + (s.x2 is not None) for s in plan.conv_steps) == depth - 2 + 4 + 1, name
+        assert plan.feat.C == 512 * m.arch.expansion
+    assert ptx.resnet3d200(pretrained=None).last_linear.out_features == 339      # reference quirk (num_classes unused)
+    nl10 = ptx.nonlocalresnet3d50(num_nonlocal_blocks=10, pretrained=None)
+    assert sum(hasattr(b, "nonlocalblock") for l in (nl10.layer2, nl10.layer3) for b in l) == 10
+
+
+def test_checkpoint_loading_paths(ptx, monkeypatch):
+    """load_pretrained / inflate_pretrained (reference torchvision_models.py:158-191) with the download
+    stubbed out: `fc.*` keys land in `last_linear`, 2-D filters are repeated along T without 1/T scaling,
+    the preprocessing attributes appear only on pretrained models."""
+    src = ptx.resnet3d50(num_classes=339, pretrained=None)
+    ckpt = {("fc." + k[len("last_linear."):] if k.startswith("last_linear.") else k): v.clone() + 0.5
+            for k, v in src.state_dict().items()}
+    monkeypatch.setattr(ptx, "_fetch", lambda url: dict(ckpt))
+    m = ptx.resnet3d50(num_classes=339, pretrained="moments")
+    assert torch.equal(m.last_linear.weight, ckpt["fc.weight"]) and m.input_size == [3, 224, 224] and m.mean == [0.485, 0.456, 0.406]
+    with pytest.raises(AssertionError):
+        ptx.resnet3d50(num_classes=400, pretrained="moments")
+    # inflation: a 2-D checkpoint ([Co,Ci,kH,kW]) expanded to [Co,Ci,kT,kH,kW]
+    ckpt2d = {k: (v[:, :, 0].clone() if v.dim() == 5 else v.clone()) for k, v in ckpt.items()}
+    monkeypatch.setattr(ptx, "_fetch", lambda url: dict(ckpt2d))
+    mi = ptx.resneti3d50(num_classes=339, pretrained="moments")
+    w = mi.layer1[0].conv2.weight
+    assert w.shape[2] == 3 and torch.equal(w[:, :, 0], w[:, :, 2]) and torch.equal(w[:, :, 1], ckpt2d["layer1.0.conv2.weight"])
+
+
 def test_batch_limit_from_dry_plan(ptx):
     """libptx_amd addresses each tensor with 32-bit byte offsets (< 2 GiB per launch); the engine
     derives the largest admissible batch from a batch-1 dry plan and splits bigger batches."""
