@@ -64,6 +64,10 @@ ARCHS = {
     "nonlocal_r2plus1d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", conv="2p1d",
                                    nonlocal_layers=[0, 2, 3, 0]),
     "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
+    "resnet34": ArchCfg("basic", [3, 4, 6, 3], "B", dims=2),
+    "resnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", dims=2),
+    "resnet101": ArchCfg("bottleneck", [3, 4, 23, 3], "B", dims=2),
+    "resnet152": ArchCfg("bottleneck", [3, 8, 36, 3], "B", dims=2),
 }
 
 
@@ -247,6 +251,43 @@ def multiscale_relation(sd, x, num_input, num_relations=3, rng=np.random):
             outs.append(relation(sd, sub, "relations.%d." % si, scale))
     out_features = outs[0].shape[-1]
     return torch.stack(outs).sum(0).view(x.size(0), -1, out_features)
+
+
+def hierarchical_relation(sd, x, p, num_inputs):
+    """trn.HierarchicalRelation.forward (trn.py:150-160) for the only depth at which the reference
+    runs (depth 0: relation_size >= num_inputs, which is what TRN always constructs, trn.py:230):
+    `stack([final_relation(input)]).mean(0)`."""
+    if any(k.startswith(p + "relations.") for k in sd):
+        raise RuntimeError("depth >= 1: the reference forward raises in torch.stack")
+    x = x.view(-1, num_inputs, x.size(-1))
+    return torch.stack([relation(sd, x, p + "final_relation.", num_inputs)]).mean(0)
+
+
+def trn_features(backbone_cfg, sd, x, num_segments, consensus="HTRN", rng=np.random):
+    """trn.TRN.features (trn.py:246-255): per-frame backbone (its last_linear is a Dropout: identity
+    in eval) -> [B, 1, T, F] -> temporal relation -> squeeze()."""
+    bsd = {k[len("base_model."):]: v for k, v in sd.items() if k.startswith("base_model.")}
+    frames = x.reshape((-1, 3) + tuple(x.shape[-2:]))
+    feat = features(backbone_cfg, bsd, frames)
+    pooled = F.adaptive_avg_pool2d(feat, 1).view(feat.size(0), -1)
+    rep = pooled.view(x.size(0), -1, num_segments, pooled.size(-1))
+    tsd = {k[len("temporal_relation."):]: v for k, v in sd.items() if k.startswith("temporal_relation.")}
+    if consensus == "TRN":
+        out = relation(tsd, rep, "", num_segments)
+    elif consensus == "HTRN":
+        out = hierarchical_relation(tsd, rep, "", num_segments)
+    elif consensus == "MSTRN":
+        out = multiscale_relation(tsd, rep, num_segments, 3, rng)
+    else:
+        raise ValueError("Unrecognized temporal consensus.")
+    return out.squeeze()
+
+
+def trn_forward(backbone_cfg, sd, x, num_segments, consensus="HTRN", rng=np.random):
+    """trn.TRN.forward (trn.py:257-263)."""
+    with torch.no_grad():
+        f = trn_features(backbone_cfg, sd, x, num_segments, consensus, rng)
+        return F.linear(f, sd["last_linear.weight"], sd["last_linear.bias"])
 
 
 # --------------------------------------------------------------------------------------------

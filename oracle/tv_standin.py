@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- stand-in for `torchvision.models.resnet18`.
+"""TEST INFRASTRUCTURE ONLY -- stand-in for `torchvision.models.resnet{18,34,50,101,152}`.
 
 The reference's 2-D `resnet18` (pretorched/models/torchvision_models.py:484-492) delegates all
 arithmetic to third-party torchvision (`models.resnet18(pretrained=False, num_classes=...)`),
@@ -8,6 +8,9 @@ nor installed in this image.  This module restates the published canonical ResNe
 4 stages of 2 basic blocks (64/128/256/512, stride-2 stages use a 1x1 conv + BN shortcut) ->
 global average pool -> Linear.  Attribute names are the ones `modify_resnets`
 (torchvision_models.py:443-464) touches: conv1 bn1 relu maxpool layer1..4 avgpool fc.
+
+resnet50/101/152 use the published bottleneck (1x1 -> 3x3 carrying the stride -> 1x1, expansion 4),
+the shape torchvision has always shipped; resnet50 is the per-frame backbone of TRN (trn.py:207).
 
 **Parity unpinned**: the reference holds no test or golden vector for this path, so this
 stand-in *is* the oracle for config 1 and is labelled as such wherever it is used.
@@ -35,8 +38,32 @@ class _Basic2d(nn.Module):
         return self.relu(y + idt)
 
 
+class _Bottleneck2d(nn.Module):
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = 4 * width
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False),
+                                            nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + idt)
+
+
 class _ResNet2d(nn.Module):
-    def __init__(self, depths, num_classes):
+    def __init__(self, depths, num_classes, bottleneck=False):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -46,11 +73,16 @@ class _ResNet2d(nn.Module):
         for i, (width, depth) in enumerate(zip((64, 128, 256, 512), depths)):
             blocks = []
             for j in range(depth):
-                blocks.append(_Basic2d(cin, width, 2 if (i > 0 and j == 0) else 1))
-                cin = width
+                stride = 2 if (i > 0 and j == 0) else 1
+                if bottleneck:
+                    blocks.append(_Bottleneck2d(cin, width, stride))
+                    cin = 4 * width
+                else:
+                    blocks.append(_Basic2d(cin, width, stride))
+                    cin = width
             setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
         self.avgpool = nn.AdaptiveAvgPool2d(1)
-        self.fc = nn.Linear(512, num_classes)
+        self.fc = nn.Linear(cin, num_classes)
 
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
@@ -61,3 +93,27 @@ class _ResNet2d(nn.Module):
 def resnet18(pretrained=False, num_classes=1000):
     assert not pretrained, "no network in this image"
     return _ResNet2d((2, 2, 2, 2), num_classes)
+
+
+def resnet34(pretrained=False, num_classes=1000):
+    assert not pretrained, "no network in this image"
+    return _ResNet2d((3, 4, 6, 3), num_classes)
+
+
+def resnet50(pretrained=False, num_classes=1000):
+    assert not pretrained, "no network in this image"
+    return _ResNet2d((3, 4, 6, 3), num_classes, bottleneck=True)
+
+
+def resnet101(pretrained=False, num_classes=1000):
+    assert not pretrained, "no network in this image"
+    return _ResNet2d((3, 4, 23, 3), num_classes, bottleneck=True)
+
+
+def resnet152(pretrained=False, num_classes=1000):
+    assert not pretrained, "no network in this image"
+    return _ResNet2d((3, 8, 36, 3), num_classes, bottleneck=True)
+
+
+FACTORIES = {"resnet18": resnet18, "resnet34": resnet34, "resnet50": resnet50, "resnet101": resnet101,
+             "resnet152": resnet152}

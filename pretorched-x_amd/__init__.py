@@ -20,7 +20,8 @@ import torch
 from . import _lib
 from ._lib import PtxError
 from .engine import Engine, relation_mlp
-from .zoo import ARCHS, Arch, MultiScaleRelation, Relation, VideoResNet, factored_mid_channels
+from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation,
+                  Relation, VideoResNet, factored_mid_channels)
 
 __version__ = "0.1.0"
 
@@ -44,8 +45,13 @@ _URLS = {
         "resnet3d50": _HOST + "resnet3d50_16seg_moments-6eb53860.pth",
         "resnet50": "http://moments.csail.mit.edu/moments_models/resnet50_moments-fd0c4436.pth",
     },
-    "imagenet": {"resnet18": "https://download.pytorch.org/models/resnet18-5c106cde.pth"},
-    "places365": {"resnet18": _HOST + "resnet18_places365-dbad67aa.pth"},
+    "imagenet": {"resnet18": "https://download.pytorch.org/models/resnet18-5c106cde.pth",
+                 "resnet34": "https://download.pytorch.org/models/resnet34-333f7ec4.pth",
+                 "resnet50": "https://download.pytorch.org/models/resnet50-19c8e357.pth",
+                 "resnet101": "https://download.pytorch.org/models/resnet101-5d3b4d8f.pth",
+                 "resnet152": "https://download.pytorch.org/models/resnet152-b121ed2d.pth"},
+    "places365": {"resnet18": _HOST + "resnet18_places365-dbad67aa.pth",
+                  "resnet50": _HOST + "resnet50_places365-a570fcfc.pth"},
 }
 _NUM_CLASSES = {"kinetics-400": 400, "moments": 339, "imagenet": 1000, "places365": 365}
 
@@ -58,10 +64,12 @@ for _name in ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d1
             "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": _NUM_CLASSES[_ds],
             "input_size": [3, 224, 224]}
 for _ds in ("imagenet", "places365"):
-    pretrained_settings["resnet18"][_ds] = {
-        "input_space": "RGB", "input_range": [0, 1], "url": _URLS[_ds]["resnet18"],
-        "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": _NUM_CLASSES[_ds],
-        "input_size": [3, 224, 224]}
+    for _name in _URLS[_ds]:
+        pretrained_settings[_name][_ds] = {
+            "input_space": "RGB", "input_range": [0, 1], "url": _URLS[_ds][_name],
+            "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": _NUM_CLASSES[_ds],
+            "input_size": [3, 224, 224]}
+pretrained_settings["trn"]["moments"] = {"url": "", "num_classes": 339}       # trn.py:10-17
 pretrained_settings["resnet50"]["moments"] = {
     "input_space": "RGB", "input_range": [0, 1], "url": _URLS["moments"]["resnet50"],
     "std": _IMAGENET_STD, "mean": _IMAGENET_MEAN, "num_classes": 339, "input_size": [3, 224, 224]}
@@ -199,14 +207,42 @@ def nonlocal_r2plus1d50(num_classes=339):
     return _build("nonlocal_r2plus1d50", num_classes)
 
 
-def resnet18(num_classes=1000, pretrained="imagenet"):
-    """2-D ResNet-18 (reference torchvision_models.py:484-492), run as the T == 1 case."""
-    model = _build("resnet18", num_classes)
-    if pretrained is not None:
-        load_pretrained(model, num_classes, pretrained_settings["resnet18"][pretrained])
+def _resnet2d_factory(name):
+    def factory(num_classes=1000, pretrained="imagenet"):
+        model = _build(name, num_classes)
+        if pretrained is not None:
+            load_pretrained(model, num_classes, pretrained_settings[name][pretrained])
+        return model
+    factory.__name__ = name
+    factory.__doc__ = ("2-D %s (reference torchvision_models.py:484-536, arithmetic in torchvision there), "
+                       "run as the T == 1 case of the same HIP engine." % name)
+    return factory
+
+
+resnet18 = _resnet2d_factory("resnet18")
+resnet34 = _resnet2d_factory("resnet34")
+resnet50 = _resnet2d_factory("resnet50")
+resnet101 = _resnet2d_factory("resnet101")
+resnet152 = _resnet2d_factory("resnet152")
+
+
+def trn(num_classes=339, num_segments=8, consensus="MSTRN", arch="resnet50", pretrained="moments",
+        frame_bottleneck_dim=1024, video_feature_dim=1024):
+    """reference trn.py:345-355.  As there, `consensus`, the two widths and `pretrained=None` are
+    NOT forwarded to TRN (which therefore uses its own defaults: 'HTRN', 1024/1024, a 'moments'
+    backbone download); construct `TRN(...)` directly to choose them."""
+    if pretrained:
+        settings = pretrained_settings["trn"][pretrained]
+        assert num_classes == settings["num_classes"], \
+            "num_classes should be {}, but is {}".format(settings["num_classes"], num_classes)
+        model = TRN(num_classes=num_classes, num_segments=num_segments, arch=arch)
+        model.load_state_dict(_fetch(settings["url"] or None))
+    else:
+        model = TRN(num_classes=num_classes, num_segments=num_segments, arch=arch)
     return model
 
 
 model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
                "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
-               "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18"]
+               "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
+               "resnet101", "resnet152", "trn"]

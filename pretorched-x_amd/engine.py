@@ -771,6 +771,26 @@ class Engine:
 # ---------------------------------------------------------------------------------------------
 # TRN relation MLP (trn.py:39-45): ReLU -> Linear -> ReLU -> Linear
 # ---------------------------------------------------------------------------------------------
+def linear(x, lin, flags=0):
+    """y = x @ W^T + b through ptx_linear_fwd for any [..., K] float32 CUDA tensor (TRN classifier,
+    trn.py:257-258)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise PtxError("linear: input must be a float32 CUDA tensor (no CPU fallback)")
+    if not isinstance(lin, torch.nn.Linear):
+        return lin(x)                                   # user-replaced head: theirs to run
+    K = lin.in_features
+    flat = x.contiguous().view(-1, K)
+    M = flat.shape[0]
+    with torch.cuda.device(x.device):
+        out = torch.empty((M, lin.out_features), device=x.device, dtype=torch.float32)
+        w = lin.weight.detach().contiguous()
+        b = lin.bias.detach().contiguous() if lin.bias is not None else None
+        check(_lib.lib().ptx_linear_fwd(_ptr(flat), _ptr(w), _ptr(b) if b is not None else C.c_void_p(0),
+                                        _ptr(out), M, K, lin.out_features, K, lin.out_features, flags,
+                                        _stream()), "ptx_linear_fwd")
+    return out.view(tuple(x.shape[:-1]) + (lin.out_features,))
+
+
 def relation_mlp(flat, lin1, lin2, out=None, accumulate=False):
     if not flat.is_cuda or flat.dtype != torch.float32:
         raise PtxError("relation_mlp: input must be a float32 CUDA tensor (no CPU fallback)")

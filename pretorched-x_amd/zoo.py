@@ -56,7 +56,13 @@ ARCHS = {
     "r2plus1d34": Arch("basic", (3, 4, 6, 3), "B", conv="2p1d", head="fc"),
     "r2plus1d50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="2p1d", head="fc"),
     "nonlocal_r2plus1d50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="2p1d", nonlocal_layers=(0, 2, 3, 0)),
+    # 2-D torchvision-shaped ResNets (torchvision_models.py:484-536), executed as the T == 1 case;
+    # resnet50 is the per-frame backbone of TRN (trn.py:207)
     "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
+    "resnet34": Arch("basic", (3, 4, 6, 3), "B", dims=2),
+    "resnet50": Arch("bottleneck", (3, 4, 6, 3), "B", dims=2),
+    "resnet101": Arch("bottleneck", (3, 4, 23, 3), "B", dims=2),
+    "resnet152": Arch("bottleneck", (3, 8, 36, 3), "B", dims=2),
 }
 
 
@@ -265,3 +271,124 @@ class MultiScaleRelation(nn.Module):
                 # the sum over relations (trn.py:110) is fused into the second Linear's epilogue
                 total = relation_mlp(flat, rel.relate[1], rel.relate[3], out=total, accumulate=total is not None)
         return total.view(input.size(0), -1, self.out_features)
+
+
+class HierarchicalRelation(nn.Module):
+    """trn.py:115-160.  The reference's forward only runs when `depth == 0` (relation_size >=
+    num_inputs): for depth >= 1 its `linear(input).sum(-2)` reduces the singleton axis left by
+    `Relation.view(B, -1, out)`, the per-level outputs keep different window counts and
+    `torch.stack(outs)` raises.  TRN always lands on depth 0, because it passes
+    `frame_bottleneck_dim` (1024) in the `relation_size` slot (trn.py:230-233).  Mirrored: the
+    parameter tree (relations / linears / final_linear / final_relation) is built for any depth so
+    checkpoints load; forward executes depth 0 on the GPU and raises the reference's error class
+    otherwise."""
+
+    def __init__(self, num_inputs, in_features, out_features, relation_size=4, relation_dist=1,
+                 bottleneck_dim=1024):
+        super().__init__()
+        import math
+        self.num_inputs, self.in_features, self.out_features = num_inputs, in_features, out_features
+        self.relation_size, self.relation_dist, self.bottleneck_dim = relation_size, relation_dist, bottleneck_dim
+        depth = int(math.ceil((num_inputs - relation_size) / (relation_size - 1)))
+        self.depth = max(depth, 0)
+        num_inputs_final = num_inputs + depth * (1 - relation_size)
+        self.relations = nn.ModuleList([Relation(relation_size, in_features, in_features)
+                                        for _ in range(self.depth)])
+        self.linears = nn.ModuleList([nn.Linear(in_features, out_features) for _ in range(self.depth)])
+        self.final_linear = nn.Linear(in_features, out_features)       # unused by forward upstream too
+        self.final_relation = Relation(num_inputs_final, in_features, out_features)
+        self.eval()
+
+    def forward(self, input):
+        if self.depth != 0:
+            raise RuntimeError("HierarchicalRelation with depth %d: the reference forward (trn.py:150-160) "
+                               "raises in torch.stack for depth >= 1; only depth 0 is defined" % self.depth)
+        input = input.view(-1, self.num_inputs, self.in_features)
+        # stack([final_relation(input)]).mean(0) over one element is the identity
+        return self.final_relation(input)
+
+
+class MultiScaleHierarchicalRelation(nn.Module):
+    """trn.py:163-191: parameter tree only.  Every scale < num_inputs builds a depth >= 1
+    HierarchicalRelation, whose reference forward raises (see above), so no output is defined."""
+
+    def __init__(self, num_inputs, in_features, out_features, relation_dist=1, bottleneck_dim=512):
+        super().__init__()
+        self.num_inputs, self.in_features, self.out_features = num_inputs, in_features, out_features
+        self.scales = range(num_inputs, 1, -1)
+        self.num_scales = len(self.scales)
+        self.h_relations = nn.ModuleList([
+            HierarchicalRelation(num_inputs, in_features, out_features, relation_size=s,
+                                 relation_dist=relation_dist, bottleneck_dim=bottleneck_dim)
+            for s in self.scales])
+        self.final_relation = Relation(self.num_scales, out_features, out_features, bottleneck_dim=bottleneck_dim)
+        self.eval()
+
+    def forward(self, input):
+        raise RuntimeError("MultiScaleHierarchicalRelation: the reference forward (trn.py:186-191) raises "
+                           "in torch.stack for every num_inputs > 2; no output is defined")
+
+
+class TRN(nn.Module):
+    """Temporal Relation Network (trn.py:194-263): a 2-D backbone run on every frame, a temporal
+    relation head over the per-frame features and a Linear classifier.  All arithmetic runs in
+    libptx_amd: frames go through the HIP engine as a [B*T,3,H,W] batch (the backbone's
+    `last_linear` is a Dropout, i.e. the identity here), the relation MLPs and the classifier
+    through ptx_linear_fwd.
+
+    `pretrained=None` builds the backbone without weights (the reference cannot: it reads
+    `base_model.mean/std`, which only exist after a download, trn.py:211-214); the settings are
+    then taken from the arch's 'moments' (else 'imagenet') entry."""
+
+    consensus_mods = {"TRN": Relation, "HTRN": HierarchicalRelation, "MSTRN": MultiScaleRelation,
+                      "MSHTRN": MultiScaleHierarchicalRelation}
+
+    def __init__(self, num_classes, num_segments=8, arch="resnet50", frame_bottleneck_dim=1024,
+                 video_feature_dim=1024, consensus="HTRN", pretrained="moments", dropout=0.5, partial_bn=True):
+        super().__init__()
+        from . import __dict__ as factories, pretrained_settings
+        self.arch, self.reshape, self.dropout = arch, True, dropout
+        self.consensus, self.num_classes, self.num_segments = consensus, num_classes, num_segments
+        self.video_feature_dim, self.frame_bottleneck_dim = video_feature_dim, frame_bottleneck_dim
+        num_pc = 1000 if pretrained == "imagenet" else 339
+        self.base_model = factories[arch](num_pc, pretrained)
+        if pretrained is None:
+            table = pretrained_settings[arch]
+            settings = table.get("moments", table.get("imagenet"))
+            for k in ("input_space", "input_size", "input_range", "mean", "std"):
+                setattr(self.base_model, k, settings[k])
+        self.frame_feature_dim = self.base_model.last_linear.in_features
+        self.base_model.last_linear = nn.Dropout(self.dropout)
+        self.std, self.mean = self.base_model.std, self.base_model.mean
+        self.input_size = self.base_model.input_size[1:]
+        self.input_space = self.base_model.input_space
+        if consensus not in self.consensus_mods:
+            raise ValueError("Unrecognized temporal consensus.")
+        self.temporal_relation = self.consensus_mods[consensus](
+            self.num_segments, self.frame_feature_dim, self.video_feature_dim, self.frame_bottleneck_dim)
+        self.last_linear = nn.Linear(self.video_feature_dim, self.num_classes)
+        self.eval()
+
+    def features(self, input):
+        """[B, T, 3, H, W] (or [B, T*3, H, W]) -> [B, video_feature_dim]  (trn.py:246-255);
+        like the reference, `.squeeze()` also drops the batch axis when B == 1."""
+        batch_size = input.size(0)
+        frames = input.reshape((-1, 3) + tuple(input.shape[-2:]))
+        base_rep = self.base_model(frames)                                  # [B*T, F]
+        base_rep = base_rep.view(batch_size, -1, self.num_segments, base_rep.size(-1))
+        return self.temporal_relation(base_rep).squeeze()
+
+    def logits(self, features):
+        from .engine import linear
+        return linear(features, self.last_linear)
+
+    def forward(self, input):
+        return self.logits(self.features(input))
+
+    @property
+    def crop_size(self):
+        return self.input_size
+
+    @property
+    def scale_size(self):
+        return self.input_size[0] * 256 // 224

@@ -49,11 +49,13 @@ GOLDEN_CASES = {
     "r2plus1d50_small": ("r2plus1d50", dict(num_classes=400)),
     "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "resnet18_cfg1": ("resnet18", dict(num_classes=1000, pretrained=None)),
+    "resnet50_2d_small": ("resnet50", dict(num_classes=339, pretrained=None)),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),
     "nonlocalresnet3d50_cfg3": ("nonlocalresnet3d50", dict(pretrained=None)),
 }
+TRN_CASES = ("trn_htrn_small", "trn_mstrn_small", "trn_trn_b1")
 FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3")
 
 
@@ -69,3 +71,14 @@ def golden_input(blob):
     shape = tuple(int(v) for v in blob["shape"])
     g = torch.Generator().manual_seed(int(blob["x_seed"]))
     return torch.randn(*shape, generator=g)
+
+
+def golden_trn(ptx, case):
+    """(model kwargs, product TRN on CPU with the fixture's synthetic weights loaded, input, blob)."""
+    import json
+    from pretorched_x_amd.testing import synth_state_dict
+    blob = load_golden(case)
+    kw = json.loads(str(blob["kwargs"]))
+    model = ptx.TRN(pretrained=None, **kw)
+    model.load_state_dict(synth_state_dict(model.state_dict(), int(blob["w_seed"])))
+    return kw, model, golden_input(blob), blob

@@ -1,7 +1,10 @@
 """Generate tests/golden/*.npz by running the REAL reference (/root/reference, via oracle.ref_shim)
 on CPU with the deterministic synthetic weights/inputs of pretorched_x_amd.testing.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
+
+With case names only those fixtures are regenerated (state_keys.json is merged, not rewritten);
+`trn` selects the TRN head + wrapper fixtures.
 
 The reference tree does not exist on the GPU box, so these small fixtures (logits, small feature
 maps, state_dict key lists) are committed; the GPU parity tests compare the HIP engine against
@@ -13,6 +16,7 @@ input = synth_clips(..., seed=X_SEED); outputs from `model.features` / `model(x)
 import json
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -41,6 +45,7 @@ CASES = {
     "r2plus1d50_small": ("r2plus1d50", (2, 3, 8, 64, 64), dict(num_classes=400)),
     "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", (2, 3, 8, 64, 64), dict(num_classes=339)),
     "resnet18_cfg1": ("resnet18", (1, 3, 224, 224), dict(num_classes=1000, pretrained=None)),
+    "resnet50_2d_small": ("resnet50", (3, 3, 96, 64), dict(num_classes=339, pretrained=None)),
     # BASELINE.json config 3 at full size (8 x 3 x 32 x 112 x 112): the composite and its two parents
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=400)),
@@ -53,6 +58,7 @@ RECIPES = {
     # evaluation) is 1.3e-3 -- above the 1e-3 bar; 0.05 brings it to 1.2e-5
     "nonlocal_r2plus1d50_cfg3": dict(inner_bn_damp=0.9, nl_bn_damp=0.05),
     "r2plus1d50_cfg3": dict(inner_bn_damp=0.9),
+    "resnet50_2d_small": dict(last_bn_damp=0.7),
     "nonlocalresnet3d50_cfg3": dict(last_bn_damp=0.65, nl_bn_damp=0.05),
 }
 
@@ -78,18 +84,52 @@ def build_composite(ref, r2):
                                               shortcut_type="B", num_classes=num_classes)
 
 
+# TRN wrapper fixtures: name -> (TRN kwargs, input [B,T,3,H,W], numpy seed for MSTRN's subset draw)
+TRN_CASES = {
+    "trn_htrn_small": (dict(num_classes=51, num_segments=4, consensus="HTRN"), (2, 4, 3, 64, 64), None),
+    "trn_mstrn_small": (dict(num_classes=51, num_segments=4, consensus="MSTRN", frame_bottleneck_dim=256,
+                             video_feature_dim=128), (2, 4, 3, 64, 64), 11),
+    "trn_trn_b1": (dict(num_classes=17, num_segments=3, consensus="TRN", frame_bottleneck_dim=128,
+                        video_feature_dim=64), (1, 3, 3, 64, 96), None),
+}
+
+
+def build_ref_trn(ref, trn, **kw):
+    """The reference TRN (trn.py:194-244) cannot be constructed without a download: it reads
+    base_model.mean/std (set only by load_pretrained).  Here `pretrainedmodels.__dict__[arch]`
+    resolves to the reference's own 2-D wrapper (torchvision_models.py:506-514, over the torchvision
+    stand-in) built with pretrained=None and given the 'moments' settings by hand."""
+    tvm = ref.models.torchvision_models
+
+    def make(arch):
+        def factory(num_pc, pretrained):
+            m = ref.__dict__[arch](num_classes=num_pc, pretrained=None)
+            st = tvm.pretrained_settings[arch].get("moments", tvm.pretrained_settings[arch]["imagenet"])
+            m.input_space, m.input_size, m.input_range = st["input_space"], st["input_size"], st["input_range"]
+            m.mean, m.std = st["mean"], st["std"]
+            return m
+        return factory
+
+    trn.pretrainedmodels = types.SimpleNamespace(**{a: make(a) for a in tv_standin.FACTORIES})
+    return trn.TRN(**kw)
+
+
 def main():
+    only = set(sys.argv[1:])
     torch.manual_seed(0)
-    ref = ref_shim.import_reference({"resnet18": tv_standin.resnet18})
+    ref = ref_shim.import_reference(tv_standin.FACTORIES)
     r2 = ref_shim.import_r2plus1d()
     trn = ref_shim.import_trn()
     composite = build_composite(ref, r2)
-    keys_out = {}
+    keys_path = os.path.join(OUT, "state_keys.json")
+    keys_out = json.load(open(keys_path)) if (only and os.path.exists(keys_path)) else {}
 
     # (2+1)D reference models must be *built and run* before any resnet3d* factory patches
     # ResNet3D.forward at class level (SURVEY.md F7) -- so handle them first.
     order = sorted(CASES, key=lambda n: 0 if "r2plus1d" in n else 1)
     for case in order:
+        if only and case not in only:
+            continue
         arch, shape, kw = CASES[case]
         if arch == "nonlocal_r2plus1d50":
             model = composite(**kw)
@@ -137,6 +177,12 @@ def main():
         print("%-28s logits %s max|.|=%.3f argmax=%s" % (case, tuple(logits.shape), logits.abs().max().item(),
                                                         logits.argmax(1).tolist()))
 
+    if not only or "trn" in only:
+        make_trn(ref, trn, keys_out)
+    json.dump(keys_out, open(keys_path, "w"))
+
+
+def make_trn(ref, trn, keys_out):
     # TRN relation heads (standalone nn.Modules)
     g = torch.Generator().manual_seed(X_SEED)
     xr = torch.randn(4, 1, 8, 256, generator=g)
@@ -156,7 +202,35 @@ def main():
     np.savez_compressed(os.path.join(OUT, "trn_relation.npz"), relation=yr.numpy(), multiscale=ym.numpy(),
                         np_seed=7, w_seed=W_SEED, x_seed=X_SEED)
     print("trn relation", tuple(yr.shape), "multiscale", tuple(ym.shape))
-    json.dump(keys_out, open(os.path.join(OUT, "state_keys.json"), "w"))
+
+    # HierarchicalRelation at the only depth the reference forward runs (0), as TRN builds it
+    hr = trn.HierarchicalRelation(8, 256, 96, 1024).eval()
+    sd = synth_state_dict(hr.state_dict(), W_SEED)
+    hr.load_state_dict(sd)
+    keys_out["hierarchical_relation"] = [[k, list(v.shape)] for k, v in hr.state_dict().items()]
+    with torch.no_grad():
+        yh = hr(xr)
+    np.savez_compressed(os.path.join(OUT, "trn_hierarchical.npz"), out=yh.numpy(), w_seed=W_SEED, x_seed=X_SEED)
+
+    # the TRN wrapper (trn.py:194-263) over the reference's 2-D resnet50 wrapper (torchvision stand-in)
+    for case, (kw, shape, np_seed) in TRN_CASES.items():
+        model = build_ref_trn(ref, trn, **kw)
+        model.eval()                       # (the reference's TRN.train override returns None)
+        sd = synth_state_dict(model.state_dict(), W_SEED)
+        model.load_state_dict(sd)
+        keys_out[case] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        g = torch.Generator().manual_seed(X_SEED)
+        x = torch.randn(*shape, generator=g)
+        if np_seed is not None:
+            np.random.seed(np_seed)
+        with torch.no_grad():
+            feat = model.features(x)
+            logits = model.logits(feat)
+        np.savez_compressed(os.path.join(OUT, case + ".npz"), logits=logits.numpy(), features=feat.numpy(),
+                            shape=np.array(shape), w_seed=W_SEED, x_seed=X_SEED,
+                            np_seed=-1 if np_seed is None else np_seed, kwargs=np.array(json.dumps(kw)))
+        print("%-28s logits %s max|.|=%.3f features %s" % (case, tuple(logits.shape), logits.abs().max().item(),
+                                                          tuple(feat.shape)))
 
 
 def _r2_forward(model, x):

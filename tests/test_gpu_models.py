@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, golden_input, golden_recipe, load_golden
+from conftest import GOLDEN_CASES, TRN_CASES, golden_input, golden_recipe, golden_trn, load_golden
 from oracle import functional as OF
 from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
@@ -43,7 +43,7 @@ SMALL = [c for c in GOLDEN_CASES if c not in FULL_SIZE]
 def test_model_parity_small(ptx, case):
     arch, kw = GOLDEN_CASES[case]
     blob = load_golden(case)
-    model, sd = _build(ptx, arch, kw, int(blob["w_seed"]))
+    model, sd = _build(ptx, arch, kw, **golden_recipe(blob))
     x = golden_input(blob)
     xd = x.to(DEV)
     feats = model.features(xd)
@@ -264,3 +264,44 @@ def test_clip_parallel_world1_on_gpu(ptx):
         assert torch.equal(out, model(x))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", TRN_CASES)
+def test_trn_wrapper_parity(ptx, case):
+    """TRN.features / logits / forward (trn.py:246-263) on the GPU: per-frame 2-D resnet50 through the
+    HIP engine, relation MLPs and classifier through ptx_linear_fwd -- against the real reference's
+    outputs (golden; its backbone arithmetic is the torchvision stand-in) and the oracle."""
+    kw, model, x, blob = golden_trn(ptx, case)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    xd = x.to(DEV)
+    seed = int(blob["np_seed"])
+    if seed >= 0:
+        np.random.seed(seed)
+    feats = model.features(xd)
+    logits = model.logits(feats)
+    if seed >= 0:
+        np.random.seed(seed)
+    fwd = model(xd)
+    torch.cuda.synchronize()
+    assert feats.is_cuda and logits.is_cuda
+    assert torch.equal(fwd, logits)
+    _check(feats, torch.from_numpy(blob["features"]), case + " features vs golden")
+    _check(logits, torch.from_numpy(blob["logits"]), case + " logits vs golden")
+    rng = np.random.RandomState(seed) if seed >= 0 else np.random
+    want = OF.trn_forward(OF.ARCHS["resnet50"], sd, x, kw["num_segments"], kw["consensus"], rng)
+    _check(logits, want, case + " logits vs oracle")
+    if x.shape[0] > 1:
+        assert torch.equal(logits.cpu().argmax(-1), want.argmax(-1))
+
+
+def test_trn_user_head_and_errors(ptx):
+    kw, model, x, _ = golden_trn(ptx, "trn_trn_b1")
+    model = model.to(DEV).eval()
+    model.last_linear = torch.nn.Identity()                 # README "last_linear" contract
+    out = model(x.to(DEV))
+    assert tuple(out.shape) == (kw["video_feature_dim"],)   # B == 1: squeeze() drops the batch axis too
+    with pytest.raises(Exception):
+        model(x)                                            # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ptx.TRN(5, consensus="nope", pretrained=None)

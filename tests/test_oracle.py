@@ -4,7 +4,10 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, golden_input, load_golden
+import json
+import os
+
+from conftest import GOLDEN, GOLDEN_CASES, TRN_CASES, golden_input, golden_recipe, golden_trn, load_golden
 from oracle import functional as OF
 from oracle import ref_shim, tv_standin
 from pretorched_x_amd.testing import synth_state_dict
@@ -16,9 +19,9 @@ needs_ref = pytest.mark.skipif(not ref_shim.have_reference(), reason="reference 
 GOLDEN_TOL = 2e-4
 
 
-def _arch_sd(ptx, arch, kw, seed):
+def _arch_sd(ptx, arch, kw, recipe):
     model = ptx.__dict__[arch](**kw)
-    return model.arch, synth_state_dict(model.state_dict(), seed)
+    return model.arch, synth_state_dict(model.state_dict(), **recipe)
 
 
 from conftest import FULL_SIZE
@@ -29,7 +32,7 @@ def test_oracle_matches_golden(ptx, case):
     arch, kw = GOLDEN_CASES[case]
     blob = load_golden(case)
     cfg = OF.ARCHS[arch]
-    _, sd = _arch_sd(ptx, arch, kw, int(blob["w_seed"]))
+    _, sd = _arch_sd(ptx, arch, kw, golden_recipe(blob))
     x = golden_input(blob)
     with torch.no_grad():
         feat = OF.features(cfg, sd, x)
@@ -58,6 +61,68 @@ def test_oracle_trn_golden():
     rng = np.random.RandomState(int(blob["np_seed"]))   # same stream as np.random.seed(7)
     y = OF.multiscale_relation(sd, x, 8, 3, rng)
     assert np.abs(y.numpy() - blob["multiscale"]).max() <= GOLDEN_TOL
+
+
+def test_oracle_hierarchical_relation_golden(ptx):
+    blob = load_golden("trn_hierarchical")
+    x = torch.randn(4, 1, 8, 256, generator=torch.Generator().manual_seed(int(blob["x_seed"])))
+    hr = ptx.HierarchicalRelation(8, 256, 96, 1024)            # as TRN builds it: depth 0
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))["hierarchical_relation"]
+    assert [[k, list(v.shape)] for k, v in hr.state_dict().items()] == keys
+    sd = synth_state_dict(hr.state_dict(), int(blob["w_seed"]))
+    y = OF.hierarchical_relation(sd, x, "", 8)
+    assert y.shape == blob["out"].shape
+    assert np.abs(y.numpy() - blob["out"]).max() <= GOLDEN_TOL
+    # depth >= 1: the reference forward raises (torch.stack of unequal window counts); so do we
+    deep = ptx.HierarchicalRelation(8, 32, 16, 4)
+    assert deep.depth == 2 and len(deep.relations) == 2 and len(deep.linears) == 2
+    with pytest.raises(RuntimeError):
+        deep(torch.zeros(2, 8, 32))
+    with pytest.raises(RuntimeError):
+        ptx.MultiScaleHierarchicalRelation(8, 32, 16)(torch.zeros(2, 8, 32))
+
+
+@pytest.mark.parametrize("case", TRN_CASES)
+def test_oracle_trn_wrapper_golden(ptx, case):
+    """TRN.features/logits (trn.py:246-263): state_dict ABI equal to the reference model's, oracle
+    equal to the reference outputs (backbone arithmetic: torchvision stand-in, parity unpinned)."""
+    kw, model, x, blob = golden_trn(ptx, case)
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))[case]
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == keys
+    rng = np.random.RandomState(int(blob["np_seed"])) if int(blob["np_seed"]) >= 0 else np.random
+    sd = model.state_dict()
+    cfg = OF.ARCHS["resnet50"]
+    with torch.no_grad():
+        feat = OF.trn_features(cfg, sd, x, kw["num_segments"], kw["consensus"], rng)
+        out = torch.nn.functional.linear(feat, sd["last_linear.weight"], sd["last_linear.bias"])
+    for got, name in ((feat, "features"), (out, "logits")):
+        want = torch.from_numpy(blob[name])
+        assert got.shape == want.shape, name
+        assert (got - want).abs().max().item() <= GOLDEN_TOL * max(1.0, want.abs().max().item()), name
+
+
+@needs_ref
+def test_oracle_trn_bit_equal_to_reference():
+    import types
+    ref = ref_shim.import_reference(tv_standin.FACTORIES)
+    trn = ref_shim.import_trn()
+
+    def base(num_pc, pretrained):
+        m = ref.resnet50(num_classes=num_pc, pretrained=None)
+        m.mean, m.std, m.input_size, m.input_space = [0.5] * 3, [0.5] * 3, [3, 224, 224], "RGB"
+        return m
+    trn.pretrainedmodels = types.SimpleNamespace(resnet50=base)
+    for consensus in ("TRN", "HTRN", "MSTRN"):
+        model = trn.TRN(7, num_segments=3, consensus=consensus, frame_bottleneck_dim=64, video_feature_dim=32)
+        model.eval()
+        sd = synth_state_dict(model.state_dict(), 9)
+        model.load_state_dict(sd)
+        x = torch.randn(2, 3, 3, 32, 32, generator=torch.Generator().manual_seed(6))
+        np.random.seed(5)
+        with torch.no_grad():
+            want = model(x)
+        got = OF.trn_forward(OF.ARCHS["resnet50"], sd, x, 3, consensus, np.random.RandomState(5))
+        assert torch.equal(got, want), consensus
 
 
 @needs_ref
