@@ -60,7 +60,7 @@ typedef struct ptx_conv3d_desc {
     int32_t N, Ti, Hi, Wi;   /* input positions                                   */
     int32_t Ci, ldx;         /* input channels, input channel stride (floats)     */
     int32_t To, Ho, Wo;      /* output positions                                  */
-    int32_t Co, ldy;         /* output channels, output channel stride            */
+    int32_t Co, ldy;         /* output channels, output row stride (>= Co rounded up to 4) */
     int32_t kT, kH, kW;      /* filter taps                                       */
     int32_t sT, sH, sW;      /* strides                                           */
     int32_t pT, pH, pW;      /* zero padding                                      */
@@ -86,7 +86,10 @@ size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* desc, int split_k);
 /*
  * y[m][co] = epilogue( sum_{tap,c} x[pos(m,tap)][c] * w_packed[tap][co][c] + bias[co] )
  * x: NDHWC input; w_packed/bias: from ptx_pack_conv_weight; res: residual operand or NULL;
- * y: NDHWC output (channels [Co, ldy) are written as zero); config < 0 -> ptx_conv3d_pick_config.
+ * y: NDHWC output with row stride ldy; columns [0, round_up(Co,4)) of every row are written
+ * ([Co, round_up(Co,4)) as zero), columns beyond are left untouched -- so y may point at a channel
+ * slice of a wider tensor (torch.cat(dim=1) of branch outputs: slowfast.py:145-151).
+ * config < 0 -> ptx_conv3d_pick_config.
  */
 int ptx_conv3d_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_packed,
                    const float* bias, const float* res, float* y, void* workspace,
@@ -149,17 +152,58 @@ int ptx_ndhwc_to_ncdhw(const float* x, float* y, int32_t N, int32_t C, int64_t S
 int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H,
                       int32_t W, int32_t kW, int32_t sW, int32_t pW, int32_t Wo, int32_t ld,
                       ptx_stream_t stream);
+/* Same, reading a strided view of the clip: element (n,c,t,h,w) lives at
+ * x[n*stride_n + c*stride_c + t*stride_t + h*W + w] (rows stay contiguous).  Temporal subsampling
+ * `input[:, :, ::tau]` (slowfast.py:228,345,393-394) is stride_t = tau*H*W with T = ceil(T_full/tau). */
+int ptx_fold_kw_strided(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W,
+                        int64_t stride_n, int64_t stride_c, int64_t stride_t, int32_t kW, int32_t sW,
+                        int32_t pW, int32_t Wo, int32_t ld, ptx_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Pre-processing edge: the tensor half of TransformImage (transforms/utils.py:72-75) on decoded
+ * uint8 frames, on the device:  ToTensor (u8 -> f32, /255), ToSpaceBGR (swap channels 0 and 2),
+ * ToRange255 (*255), Normalize ((v - mean[c]) / std[c]) -- the same fp32 operations in the same
+ * order, so results are bit-identical to the reference's CPU tensors.
+ * frames: [N][T][H][W][C] uint8 (decoded video frames, channel-interleaved), C <= 4.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_norm_desc {
+    float mean[4], std[4];   /* per OUTPUT channel (after the optional BGR swap) */
+    int32_t swap_rb;         /* input_space == 'BGR'  (utils.py:73)              */
+    int32_t to_255;          /* max(input_range) == 255 (utils.py:74)            */
+} ptx_norm_desc;
+/* -> y NCDHW fp32 [N][C][T][H][W]: exactly the tensor the reference models take */
+int ptx_frames_u8_to_ncdhw(const uint8_t* frames, float* y, int32_t N, int32_t T, int32_t H, int32_t W,
+                           int32_t C, const ptx_norm_desc* norm, ptx_stream_t stream);
+/* -> the stem's kW-folded operand (see ptx_fold_kw_ncdhw) in one pass: normalise + fold, no fp32
+ * NCDHW tensor is materialised.  frame_step: use every frame_step-th frame (T = frames used). */
+int ptx_fold_kw_frames_u8(const uint8_t* frames, float* y, int32_t N, int32_t C, int32_t T, int32_t H,
+                          int32_t W, int32_t frame_step, int32_t T_full, int32_t kW, int32_t sW, int32_t pW,
+                          int32_t Wo, int32_t ld, const ptx_norm_desc* norm, ptx_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Pooling and head.
  * ------------------------------------------------------------------------------------------ */
+#define PTX_POOL_SAME 1u      /* To/Ho/Wo are given (TF "SAME": ceil(in/stride)); pT/pH/pW are the FRONT
+                                 pads, the back pads are whatever the output extent implies        */
+#define PTX_POOL_PAD_ZERO 2u  /* padded taps contribute 0 (F.pad then MaxPool3d) instead of -inf     */
 typedef struct ptx_pool3d_desc {
-    int32_t N, Ti, Hi, Wi, C, ld; /* input NDHWC, ld shared by input and output */
+    int32_t N, Ti, Hi, Wi, C, ld; /* input NDHWC, ld = input row stride */
     int32_t To, Ho, Wo;
     int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW;
+    int32_t ldy;                  /* output row stride; 0 = same as ld.  Columns [0, round_up(C,4)) are
+                                     written, so y may be a channel slice of a concatenated tensor */
+    uint32_t flags;               /* PTX_POOL_* */
 } ptx_pool3d_desc;
-/* max_pool3d with -inf padding (resnet3D.py:156: MaxPool3d k3 s2 p1) */
+/* max_pool3d with -inf padding (resnet3D.py:156: MaxPool3d k3 s2 p1; slowfast.py:123 (1,3,3)) */
 int ptx_maxpool3d_fwd(const ptx_pool3d_desc* desc, const float* x, float* y, ptx_stream_t stream);
+/* y[r][0..cols) = x[r][0..cols) for r < rows (row strides ldx / ldy, all multiples of 4): places a
+ * tensor into a channel slice of another -- torch.cat(dim=1) plumbing (slowfast.py:145, 395) */
+int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,
+               ptx_stream_t stream);
+/* y[o][j][i] = mean_{d<k} x[o][j*stride + d][i]   for j < (T - k)/stride + 1   (x [outer][T][inner]):
+ * temporal average windows / mean over the remaining time steps of a per-frame head */
+int ptx_window_mean(const float* x, float* y, int32_t outer, int32_t T, int32_t inner, int32_t k,
+                    int32_t stride, ptx_stream_t stream);
 /* adaptive_avg_pool3d(1): x [N][S][ld] (channels-last) or [N][C][S] (channels_first != 0)
  * -> y [N][C]   (torchvision_models.py:461) */
 int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,

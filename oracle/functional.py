@@ -227,6 +227,87 @@ def forward(cfg: ArchCfg, sd, x):
 
 
 # --------------------------------------------------------------------------------------------
+# pre-processing edge: the tensor half of TransformImage (transforms/utils.py:72-75)
+# --------------------------------------------------------------------------------------------
+def transform_frames(frames, mean, std, input_space="RGB", input_range=(0, 1)):
+    """uint8 frames [N,T,H,W,C] -> fp32 [N,C,T,H,W], frame by frame as the reference composes it:
+    torchvision ToTensor (`.to(float32).div(255)`, HWC -> CHW), ToSpaceBGR (utils.py:9-20),
+    ToRange255 (:23-31), torchvision Normalize (`.sub_(mean).div_(std)`).  torchvision is an unpinned
+    third-party dependency absent from this image; these are its documented semantics."""
+    t = frames.permute(0, 4, 1, 2, 3).to(torch.float32).div(255)
+    if input_space == "BGR":
+        t = t[:, [2, 1, 0]].contiguous()
+    if max(input_range) == 255:
+        t = t.mul(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, -1, 1, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, -1, 1, 1, 1)
+    return t.sub(m).div(s)
+
+
+# --------------------------------------------------------------------------------------------
+# SlowFast (slowfast.py)
+# --------------------------------------------------------------------------------------------
+def _sf_block(sd, x, p, block, stride):
+    """slowfast.Bottleneck.forward (:81-99) / BasicBlock.forward (:37-53).  The head conv's shape
+    (1x1x1 | (3,1,1) | (1,3,3)) is read off the stored filter."""
+    kt, kh, _ = sd[p + ".conv1.weight"].shape[2:]
+    if block == "bottleneck":
+        out = F.relu(_bn(sd, _conv(sd, x, p + ".conv1", 1, (kt // 2, 0, 0)), p + ".bn1"))
+        out = F.relu(_bn(sd, _conv(sd, out, p + ".conv2", (1, stride, stride), (0, 1, 1)), p + ".bn2"))
+        out = _bn(sd, _conv(sd, out, p + ".conv3", 1, 0), p + ".bn3")
+    else:
+        if kh == 3:     # head_conv == 1: (1,3,3) carrying the stride (:14-18)
+            out = _conv(sd, x, p + ".conv1", (1, stride, stride), (0, 1, 1))
+        else:           # head_conv == 3: (3,1,1), unstrided (:20-23)
+            out = _conv(sd, x, p + ".conv1", 1, (1, 0, 0))
+        out = F.relu(_bn(sd, out, p + ".bn1"))
+        out = _bn(sd, _conv(sd, out, p + ".conv2", (1, stride, stride), (0, 1, 1)), p + ".bn2")   # conv2 has a bias
+    residual = x
+    if (p + ".downsample.0.weight") in sd:
+        residual = _bn(sd, _conv(sd, x, p + ".downsample.0", (1, stride, stride), 0), p + ".downsample.1")
+    return F.relu(out + residual)
+
+
+def _sf_stage(sd, x, p, block, nblocks, stride):
+    for bi in range(nblocks):
+        x = _sf_block(sd, x, "%s.%d" % (p, bi), block, stride if bi == 0 else 1)
+    return x
+
+
+def _sf_stem(sd, x, p):
+    kt = sd[p + "conv1.weight"].shape[2]
+    x = F.relu(_bn(sd, _conv(sd, x, p + "conv1", (1, 2, 2), (kt // 2, 3, 3)), p + "bn1"))
+    return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+
+
+def slowfast_forward(sd, x, block, layers, mode="sf", slow_stride=16, fast_stride=2):
+    """slowfast.SlowFast.forward (:393-398) with Fast.forward (:280-299) and Slow.forward (:140-156);
+    mode 's' / 'f': SlowOnly.forward (:227-241) / FastOnly.forward (:347-363).  Dropout: eval."""
+    strides = (1, 2 if block == "bottleneck" else 1, 2, 2)
+    names = ("res2", "res3", "res4", "res5")
+    with torch.no_grad():
+        if mode == "sf":
+            f = _sf_stem(sd, x[:, :, ::fast_stride], "fast.")
+            lateral = [F.conv3d(f, sd["fast.lateral_p1.weight"], None, (8, 1, 1), (2, 0, 0))]
+            for name, n, st in zip(names, layers, strides):
+                f = _sf_stage(sd, f, "fast." + name, block, n, st)
+                if name != "res5":
+                    lateral.append(F.conv3d(f, sd["fast.lateral_%s.weight" % name], None, (8, 1, 1), (2, 0, 0)))
+            fast = F.adaptive_avg_pool3d(f, 1).view(-1, f.size(1))
+            s = _sf_stem(sd, x[:, :, ::slow_stride], "slow.")
+            for i, (name, n, st) in enumerate(zip(names, layers, strides)):
+                s = torch.cat([s, lateral[i]], dim=1)
+                s = _sf_stage(sd, s, "slow." + name, block, n, st)
+            slow = F.adaptive_avg_pool3d(s, 1).view(-1, s.size(1))
+            return F.linear(torch.cat([slow, fast], dim=1), sd["last_linear.weight"])
+        h = _sf_stem(sd, x[:, :, ::(slow_stride if mode == "s" else fast_stride)], "")
+        for name, n, st in zip(names, layers, strides):
+            h = _sf_stage(sd, h, name, block, n, st)
+        h = F.adaptive_avg_pool3d(h, 1).view(-1, h.size(1))
+        return F.linear(h, sd["last_linear.weight"], sd["last_linear.bias"])
+
+
+# --------------------------------------------------------------------------------------------
 # TRN relation heads
 # --------------------------------------------------------------------------------------------
 def relation(sd, x, p, num_inputs):

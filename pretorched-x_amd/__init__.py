@@ -20,6 +20,8 @@ import torch
 from . import _lib
 from ._lib import PtxError
 from .engine import Engine, relation_mlp
+from . import transforms  # noqa: F401
+from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
 from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation,
                   Relation, VideoResNet, factored_mid_channels)
 

@@ -44,7 +44,25 @@ class PackDesc(C.Structure):
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("N", "Ti", "Hi", "Wi", "C", "ld", "To", "Ho", "Wo",
-                 "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW")]
+                 "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "ldy")] + [("flags", C.c_uint32)]
+
+
+class NormDesc(C.Structure):
+    """ptx_norm_desc: TransformImage's tensor half (reference transforms/utils.py:72-75)."""
+    _fields_ = [("mean", C.c_float * 4), ("std", C.c_float * 4), ("swap_rb", C.c_int32), ("to_255", C.c_int32)]
+
+    @classmethod
+    def make(cls, mean, std, input_space="RGB", input_range=(0, 1)):
+        d = cls()
+        for i in range(4):
+            d.mean[i] = float(mean[i]) if i < len(mean) else 0.0
+            d.std[i] = float(std[i]) if i < len(std) else 1.0
+        d.swap_rb = int(input_space == "BGR")
+        d.to_255 = int(max(input_range) == 255)
+        return d
+
+
+PTX_POOL_SAME, PTX_POOL_PAD_ZERO = 1, 2
 
 
 _P = C.c_void_p
@@ -69,7 +87,12 @@ SIGNATURES = {
     "ptx_ncdhw_to_ndhwc": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
     "ptx_ndhwc_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
     "ptx_fold_kw_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ptx_fold_kw_strided": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "ptx_frames_u8_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
+    "ptx_fold_kw_frames_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
     "ptx_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "ptx_copy2d": (C.c_int, [_P, _P, _L, _I, _L, _L, _P]),
+    "ptx_window_mean": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ptx_global_avgpool": (C.c_int, [_P, _P, _I, _I, _L, _I, _I, _P]),
     "ptx_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _U, _P]),
     "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),

@@ -43,6 +43,8 @@ struct ConvArgs {
     float* partial;
     int N, Ti, Hi, Wi, ldx, kA;
     int To, Ho, Wo, Co, ldy;
+    int ncol;             // output columns written per row = round_up(Co, 4) <= ldy (ldy is the row stride:
+                          // a conv may write a channel slice of a wider, concatenated tensor)
     int kT, kH, kW, sT, sH, sW, pT, pH, pW;
     int ldw, kB, w_rows, M;
     long long w_tap_stride;
@@ -399,7 +401,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             const int m = mrow + MF::row(r, lane);
             const unsigned off = ((unsigned)m * (unsigned)p.ldr + (unsigned)co) * 4u;
             rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                        rsrc_r, (res_add && co < p.ldy && m < p.M) ? off : kOOB, 0, 0));
+                                                        rsrc_r, (res_add && co < p.ncol && m < p.M) ? off : kOOB, 0, 0));
         }
     };
     if (kResEarly) {
@@ -582,14 +584,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // ---- epilogue: bias + residual + ReLU, branch-free through buffer resources (out-of-range
     // stores are dropped, out-of-range loads read 0); residual values of a tile are requested in
     // one batch before they are consumed. ----
-    float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ldy : p.y + (size_t)zb * p.bs_y;
+    // split-K partial slabs are dense [M][ncol]; the final tensor has row stride ldy
+    float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ncol : p.y + (size_t)zb * p.bs_y;
+    const unsigned ldo = to_partial ? (unsigned)p.ncol : (unsigned)p.ldy;
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);
     const bool res_pada = !to_partial && (p.flags & PTX_EPI_RES_PADA);
     const bool relu = !to_partial && (p.flags & PTX_EPI_RELU);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn * WTN + j * MT + (lane % MT);
-        const bool co_ok = co < p.ldy;
+        const bool co_ok = co < p.ncol;
         const float bv = (!to_partial && p.bias && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -611,7 +615,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     v += p.res[pos * p.ldr + co];
                 }
                 v = relu ? fmaxf(v, 0.f) : v;
-                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
+                const unsigned off = ((unsigned)m * ldo + (unsigned)co) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y,
                                                       (co_ok && m < p.M) ? off : kOOB, 0, 0);
             }
@@ -621,8 +625,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 
 // y = epilogue(sum over splits of partial)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
-    const size_t total4 = (size_t)p.M * p.ldy / 4;
-    const size_t slab = (size_t)p.M * p.ldy;
+    const size_t total4 = (size_t)p.M * p.ncol / 4;
+    const size_t slab = (size_t)p.M * p.ncol;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + i * 4);
         for (int z = 1; z < p.split_k; ++z) {
@@ -630,14 +634,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
             v += u;
         }
         const size_t e = i * 4;
-        const int m = (int)(e / p.ldy);
-        const int co = (int)(e - (size_t)m * p.ldy);
+        const int m = (int)(e / p.ncol);
+        const int co = (int)(e - (size_t)m * p.ncol);
         f32x4 o;
         o.x = conv_epilogue(p, v.x, m, co);
         o.y = conv_epilogue(p, v.y, m, co + 1);
         o.z = conv_epilogue(p, v.z, m, co + 2);
         o.w = conv_epilogue(p, v.w, m, co + 3);
-        *reinterpret_cast<f32x4*>(p.y + e) = o;
+        *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + co) = o;
     }
 }
 
@@ -774,9 +778,9 @@ static int validate_desc(const ptx_conv3d_desc* d) {
         return fail(PTX_ERR_INVALID, "conv3d: bad filter geometry");
     if (d->kT > 8 || d->kH > 8 || d->kW > 8)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: filter extents above 8 are not supported (%d,%d,%d)", d->kT, d->kH, d->kW);
-    if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < d->ldy)
-        return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d ldy=%d",
-                    d->Kc, d->Co_pad, d->Ci, d->ldy);
+    if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < (d->Co + 3) / 4 * 4)
+        return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d Co=%d",
+                    d->Kc, d->Co_pad, d->Ci, d->Co);
     // output extent must match the conv arithmetic
     const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
     const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
@@ -813,20 +817,21 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     if (validate_desc(d) != PTX_OK) return 0;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     const int taps = d->kT * d->kH * d->kW;
+    const int ncol = (d->Co + 3) / 4 * 4;
     int cfg;
     if (d->Kc == 24) {
         cfg = M >= 256 * 1024 ? 16 : 6;            // kW-folded stem: 8-wave 256x64x24 (register staged)
-    } else if (d->ldy % 48 == 0 && d->ldy % 64 != 0) {
+    } else if (ncol % 48 == 0 && ncol % 64 != 0) {
         cfg = 39;                                  // (2+1)D mid widths 144 * 2^k: 48-wide N tiles
     } else if (M < 8192) {
-        cfg = d->ldy >= 128 ? 35 : 30;             // small M: 32-row tiles on 16x16x4 MFMA (DMA)
-    } else if (d->ldy >= 128 && taps * d->Kc > 128 && cdiv64(M, 128) * cdiv(d->ldy, 128) >= 4 * kNumCU) {
+        cfg = ncol >= 128 ? 35 : 30;             // small M: 32-row tiles on 16x16x4 MFMA (DMA)
+    } else if (ncol >= 128 && taps * d->Kc > 128 && cdiv64(M, 128) * cdiv(ncol, 128) >= 4 * kNumCU) {
         cfg = 26;                                  // wide output, big grid: 8-wave 128x128 (DMA)
     } else {
         cfg = 28;                                  // default: 64x64x16 DMA tiles, 8 workgroups per CU
     }
     const ConvConfig& c = kConfigs[cfg];
-    const int64_t blocks = cdiv64(M, c.BM) * cdiv(d->ldy, c.BN);
+    const int64_t blocks = cdiv64(M, c.BM) * cdiv(ncol, c.BN);
     const int steps = taps * cdiv(d->Kc, c.BK);
     int sk = 1;
     if (blocks < 2 * kNumCU) {
@@ -840,7 +845,7 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
 
 extern "C" size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* d, int split_k) {
     if (!d || split_k <= 1) return 0;
-    return (size_t)split_k * d->N * d->To * d->Ho * d->Wo * d->ldy * sizeof(float);
+    return (size_t)split_k * d->N * d->To * d->Ho * d->Wo * ((d->Co + 3) / 4 * 4) * sizeof(float);
 }
 
 namespace ptx {
@@ -857,7 +862,8 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         a.tiles_per_plane = (t_inner && a.kT > 1 && a.To > 1 && plane % c.BM == 0 && in_clip_bytes > (8 << 20))
                                 ? plane / c.BM : 0;
     }
-    a.n_tiles = cdiv(a.ldy, c.BN);
+    a.ncol = (a.Co + 3) / 4 * 4;
+    a.n_tiles = cdiv(a.ncol, c.BN);
     a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
     if (a.dual) {
         a.kc1 = cdiv(a.kA, c.BK);
@@ -881,7 +887,7 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
                         a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo) ? 1 : 0;
     if (split_k > 1) {
-        const size_t need = (size_t)split_k * a.M * a.ldy * sizeof(float);
+        const size_t need = (size_t)split_k * a.M * a.ncol * sizeof(float);
         if (!workspace || workspace_bytes < need)
             return fail(PTX_ERR_WORKSPACE, "conv3d: split_k=%d needs %zu workspace bytes, got %zu", split_k, need,
                         workspace_bytes);
@@ -892,7 +898,7 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     int s = c.launch(a, grid, st);
     if (s != PTX_OK) return s;
     if (split_k > 1) {
-        const size_t total4 = (size_t)a.M * a.ldy / 4;
+        const size_t total4 = (size_t)a.M * a.ncol / 4;
         unsigned blocks = (unsigned)std::min<size_t>((total4 + 255) / 256, (size_t)kNumCU * 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
         return hip_check(hipGetLastError(), "splitk_reduce launch");
@@ -921,7 +927,8 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     if (d->flags & PTX_PRO_RELU)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: PTX_PRO_RELU is only implemented by ptx_linear_fwd");
     if (d->flags & PTX_EPI_RES_ADD) {
-        if (d->ldr < d->ldy) return fail(PTX_ERR_INVALID, "conv3d: residual stride %d < ldy %d", d->ldr, d->ldy);
+        if (d->ldr < (d->Co + 3) / 4 * 4)
+            return fail(PTX_ERR_INVALID, "conv3d: residual stride %d does not cover Co=%d", d->ldr, d->Co);
     }
     if (d->flags & PTX_EPI_RES_PADA) {
         if (d->res_C > d->ldr || d->res_C > d->Co || (d->To - 1) * d->res_sT >= d->res_T ||

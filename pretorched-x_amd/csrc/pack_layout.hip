@@ -147,16 +147,16 @@ __global__ void __launch_bounds__(256) transpose_last2_kernel(const float* __res
 // float4 column q is fixed, so its four (kw, c) pairs are decoded once.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fold_kw_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
-                                                      int T, int H, int W, int kW, int sW, int pW, int Wo, int ld) {
+                                                      int T, int H, int W, long long stride_n, long long stride_c,
+                                                      long long stride_t, int kW, int sW, int pW, int Wo, int ld) {
     extern __shared__ float rowbuf[];      // [C][W]
     const int h = blockIdx.x % H;
     const int t = (blockIdx.x / H) % T;
     const int n = blockIdx.x / (H * T);
-    const size_t plane = (size_t)T * H * W;
-    const float* xin = x + (size_t)n * C * plane + ((size_t)t * H + h) * W;
+    const float* xin = x + (size_t)n * stride_n + (size_t)t * stride_t + (size_t)h * W;
     for (int i = threadIdx.x; i < C * W; i += 256) {
         const int c = i / W, w = i - c * W;
-        rowbuf[i] = xin[(size_t)c * plane + w];
+        rowbuf[i] = xin[(size_t)c * stride_c + w];
     }
     __syncthreads();
     const int f4r = ld / 4;
@@ -181,6 +181,66 @@ __global__ void __launch_bounds__(256) fold_kw_kernel(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) {
             const int wi = wo * sW + kwp[e];                  // input column of this tap
             v[e] = (live[e] && wi >= 0 && wi < W) ? rowbuf[off[e] + wo * sW] : 0.f;
+        }
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ld + q * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// uint8 frames [N][T][H][W][C] -> normalised fp32 (TransformImage's tensor half, utils.py:72-75).
+// The fp32 operations and their order are the reference's (ToTensor /255, ToRange255 *255,
+// Normalize (v - mean) / std); the _rn intrinsics keep the compiler from contracting them into FMAs
+// or reciprocal multiplies, so the result is bit-identical to the CPU tensors.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float normalise_u8(unsigned char u, float mean, float stdv, int to_255) {
+    float v = __fdiv_rn((float)u, 255.0f);
+    if (to_255) v = __fmul_rn(v, 255.0f);
+    return __fdiv_rn(__fsub_rn(v, mean), stdv);
+}
+
+__global__ void __launch_bounds__(256) frames_u8_to_ncdhw_kernel(const unsigned char* __restrict__ f, float* __restrict__ y,
+                                                                 size_t total, int C, long long THW, ptx_norm_desc nd) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t s = e % (size_t)THW;              // (t, h, w)
+        const size_t nc = e / (size_t)THW;
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        const int cin = (nd.swap_rb && (c == 0 || c == 2)) ? 2 - c : c;
+        y[e] = normalise_u8(f[(n * THW + s) * C + cin], nd.mean[c], nd.std[c], nd.to_255);
+    }
+}
+
+// one block per (n, t, h) input row: W*C bytes -> normalised floats in LDS (kept channel-interleaved, so
+// the folded row of output column wo is the contiguous run rowbuf[(wo*sW - pW)*C ...][0, kW*C)).
+__global__ void __launch_bounds__(256) fold_kw_frames_u8_kernel(const unsigned char* __restrict__ f, float* __restrict__ y,
+                                                                int C, int T, int H, int W, int frame_step, int T_full,
+                                                                int kW, int sW, int pW, int Wo, int ld, ptx_norm_desc nd) {
+    extern __shared__ float rowbuf[];      // [W][C]
+    const int h = blockIdx.x % H;
+    const int t = (blockIdx.x / H) % T;
+    const int n = blockIdx.x / (H * T);
+    const unsigned char* fin = f + ((((size_t)n * T_full + (size_t)t * frame_step) * H + h) * W) * C;
+    for (int i = threadIdx.x; i < W * C; i += 256) {
+        const int w = i / C, c = i - w * C;
+        const int cin = (nd.swap_rb && (c == 0 || c == 2)) ? 2 - c : c;
+        rowbuf[i] = normalise_u8(fin[w * C + cin], nd.mean[c], nd.std[c], nd.to_255);
+    }
+    __syncthreads();
+    const int f4r = ld / 4;
+    const int rows_per_pass = 256 / f4r;
+    const int q = threadIdx.x % f4r;
+    const int r0 = threadIdx.x / f4r;
+    if (r0 >= rows_per_pass) return;
+    float* yrow = y + (size_t)blockIdx.x * Wo * ld;
+    for (int wo = r0; wo < Wo; wo += rows_per_pass) {
+        const int base = (wo * sW - pW) * C;           // rowbuf index of folded column 0 (may be negative)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;
+            const int idx = base + k;
+            v[e] = (k < kW * C && idx >= 0 && idx < W * C) ? rowbuf[idx] : 0.f;
         }
         f32x4 o = {v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ld + q * 4) = o;
@@ -270,8 +330,17 @@ extern "C" int ptx_transpose_last2(const float* x, float* y, int32_t batch, int3
     return hip_check(hipGetLastError(), "transpose_last2 launch");
 }
 
+static int check_fold_args(const void* x, const void* y, int N, int C, int T, int H, int W, int kW, int sW, int pW, int Wo,
+                           int ld);
+
 extern "C" int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W,
                                  int32_t kW, int32_t sW, int32_t pW, int32_t Wo, int32_t ld, ptx_stream_t stream) {
+    const int64_t plane = (int64_t)T * H * W;
+    return ptx_fold_kw_strided(x, y, N, C, T, H, W, (int64_t)C * plane, plane, (int64_t)H * W, kW, sW, pW, Wo, ld, stream);
+}
+
+static int check_fold_args(const void* x, const void* y, int N, int C, int T, int H, int W, int kW, int sW, int pW, int Wo,
+                           int ld) {
     if (!x || !y) return fail(PTX_ERR_INVALID, "fold_kw: null pointer");
     if (N <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || kW <= 0 || sW <= 0 || pW < 0 || Wo <= 0)
         return fail(PTX_ERR_INVALID, "fold_kw: non-positive extent");
@@ -281,7 +350,54 @@ extern "C" int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C,
     if (ld / 4 > 256 || (size_t)C * W * sizeof(float) > 64 * 1024)
         return fail(PTX_ERR_UNSUPPORTED, "fold_kw: row of %d x %d floats does not fit the LDS staging buffer", C, W);
     if ((int64_t)N * T * H > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "fold_kw: too many rows");
+    return PTX_OK;
+}
+
+extern "C" int ptx_fold_kw_strided(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W,
+                                   int64_t stride_n, int64_t stride_c, int64_t stride_t, int32_t kW, int32_t sW,
+                                   int32_t pW, int32_t Wo, int32_t ld, ptx_stream_t stream) {
+    int s = check_fold_args(x, y, N, C, T, H, W, kW, sW, pW, Wo, ld);
+    if (s) return s;
+    if (stride_n <= 0 || stride_c < (int64_t)H * W || stride_t < (int64_t)H * W)
+        return fail(PTX_ERR_INVALID, "fold_kw: strides must be at least one H x W plane");
     hipLaunchKernelGGL(fold_kw_kernel, dim3((unsigned)(N * T * H)), dim3(256), (size_t)C * W * sizeof(float),
-                       (hipStream_t)stream, x, y, C, T, H, W, kW, sW, pW, Wo, ld);
+                       (hipStream_t)stream, x, y, C, T, H, W, (long long)stride_n, (long long)stride_c,
+                       (long long)stride_t, kW, sW, pW, Wo, ld);
     return hip_check(hipGetLastError(), "fold_kw launch");
+}
+
+static int check_norm(const ptx_norm_desc* nd, int C) {
+    if (!nd) return fail(PTX_ERR_INVALID, "frames_u8: null norm descriptor");
+    if (C <= 0 || C > 4) return fail(PTX_ERR_INVALID, "frames_u8: C=%d must be 1..4", C);
+    for (int c = 0; c < C; ++c)
+        if (!(nd->std[c] != 0.f)) return fail(PTX_ERR_INVALID, "frames_u8: std[%d] must be non-zero", c);
+    if (nd->swap_rb && C < 3) return fail(PTX_ERR_INVALID, "frames_u8: BGR swap needs 3 channels");
+    return PTX_OK;
+}
+
+extern "C" int ptx_frames_u8_to_ncdhw(const uint8_t* frames, float* y, int32_t N, int32_t T, int32_t H, int32_t W,
+                                      int32_t C, const ptx_norm_desc* norm, ptx_stream_t stream) {
+    if (!frames || !y) return fail(PTX_ERR_INVALID, "frames_u8: null pointer");
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0) return fail(PTX_ERR_INVALID, "frames_u8: non-positive extent");
+    int s = check_norm(norm, C);
+    if (s) return s;
+    const long long THW = (long long)T * H * W;
+    const size_t total = (size_t)N * C * THW;
+    hipLaunchKernelGGL(frames_u8_to_ncdhw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, y,
+                       total, C, THW, *norm);
+    return hip_check(hipGetLastError(), "frames_u8_to_ncdhw launch");
+}
+
+extern "C" int ptx_fold_kw_frames_u8(const uint8_t* frames, float* y, int32_t N, int32_t C, int32_t T, int32_t H,
+                                     int32_t W, int32_t frame_step, int32_t T_full, int32_t kW, int32_t sW, int32_t pW,
+                                     int32_t Wo, int32_t ld, const ptx_norm_desc* norm, ptx_stream_t stream) {
+    int s = check_fold_args(frames, y, N, C, T, H, W, kW, sW, pW, Wo, ld);
+    if (s) return s;
+    s = check_norm(norm, C);
+    if (s) return s;
+    if (frame_step <= 0 || T_full <= 0 || (int64_t)(T - 1) * frame_step >= T_full)
+        return fail(PTX_ERR_INVALID, "fold_kw_frames_u8: T=%d frames at step %d do not fit T_full=%d", T, frame_step, T_full);
+    hipLaunchKernelGGL(fold_kw_frames_u8_kernel, dim3((unsigned)(N * T * H)), dim3(256), (size_t)C * W * sizeof(float),
+                       (hipStream_t)stream, frames, y, C, T, H, W, frame_step, T_full, kW, sW, pW, Wo, ld, *norm);
+    return hip_check(hipGetLastError(), "fold_kw_frames_u8 launch");
 }

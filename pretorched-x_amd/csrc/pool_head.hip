@@ -11,7 +11,9 @@ namespace ptx {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
                                                         float* __restrict__ y, size_t total4) {
-    const int f4r = d.ld / 4;
+    const int f4r = (d.C + 3) / 4;
+    const int ldy = d.ldy ? d.ldy : d.ld;
+    const bool pad_zero = (d.flags & PTX_POOL_PAD_ZERO) != 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % f4r);
         size_t pos = i / f4r;
@@ -34,8 +36,11 @@ __global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const
                     m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                 }
             }
-        // pad channels [C, ld) hold zeros on input, so they stay zero on output
-        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+        if (pad_zero && ((t_hi - t_lo) != d.kT || (h_hi - h_lo) != d.kH || (w_hi - w_lo) != d.kW)) {
+            m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
+        }
+        // pad channels [C, round_up(C,4)) hold zeros on input, so they stay zero on output
+        *reinterpret_cast<f32x4*>(y + pos * ldy + q * 4) = m;
     }
 }
 
@@ -46,7 +51,8 @@ __global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const
 template <int WSEG>
 __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
                                                               float* __restrict__ y, size_t total) {
-    const int f4r = d.ld / 4;
+    const int f4r = (d.C + 3) / 4;
+    const int ldy = d.ldy ? d.ldy : d.ld;
     const int segs = (d.Wo + WSEG - 1) / WSEG;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % f4r);
@@ -73,7 +79,7 @@ __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d,
         };
         const int wo0 = seg * WSEG;
         f32x4 prev = colmax(2 * wo0 - 1);
-        float* yrow = y + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo) * d.ld + q * 4;
+        float* yrow = y + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo) * ldy + q * 4;
 #pragma unroll
         for (int j = 0; j < WSEG; ++j) {
             const int wo = wo0 + j;
@@ -82,7 +88,7 @@ __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d,
                 f32x4 o;
                 o.x = fmaxf(prev.x, fmaxf(c0.x, c1.x)); o.y = fmaxf(prev.y, fmaxf(c0.y, c1.y));
                 o.z = fmaxf(prev.z, fmaxf(c0.z, c1.z)); o.w = fmaxf(prev.w, fmaxf(c0.w, c1.w));
-                *reinterpret_cast<f32x4*>(yrow + (size_t)wo * d.ld) = o;
+                *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ldy) = o;
                 prev = c1;
             }
         }
@@ -239,6 +245,32 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// concat plumbing and temporal window means (tiny, bandwidth bound)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy2d_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total4,
+                                                     int cols4, long long ldx, long long ldy) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cols4;
+        const int q = (int)(i - r * cols4);
+        *reinterpret_cast<f32x4*>(y + r * ldy + q * 4) = *reinterpret_cast<const f32x4*>(x + r * ldx + q * 4);
+    }
+}
+
+__global__ void __launch_bounds__(256) window_mean_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total,
+                                                          int T, int To, int inner, int k, int stride) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % inner);
+        size_t r = e / inner;
+        const int j = (int)(r % To);
+        const size_t o = r / To;
+        const float* src = x + (o * T + (size_t)j * stride) * inner + i;
+        float acc = 0.f;
+        for (int d = 0; d < k; ++d) acc += src[(size_t)d * inner];
+        y[e] = acc / (float)k;
+    }
+}
+
 static unsigned grid_for(size_t work_items) {
     size_t b = (work_items + 255) / 256;
     const size_t cap = (size_t)kNumCU * 8;
@@ -254,25 +286,61 @@ using namespace ptx;
 extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float* y, ptx_stream_t stream) {
     if (!d || !x || !y) return fail(PTX_ERR_INVALID, "maxpool3d: null pointer");
     if (d->N <= 0 || d->C <= 0 || d->ld < d->C || d->ld % 4 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0 ||
-        d->sT <= 0 || d->sH <= 0 || d->sW <= 0)
+        d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 || d->pH < 0 || d->pW < 0 || d->To <= 0 || d->Ho <= 0 ||
+        d->Wo <= 0)
         return fail(PTX_ERR_INVALID, "maxpool3d: bad descriptor");
-    if (2 * d->pT > d->kT || 2 * d->pH > d->kH || 2 * d->pW > d->kW)
-        return fail(PTX_ERR_INVALID, "maxpool3d: padding larger than half the window");
-    const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
-    const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
-    const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
-    if (to != d->To || ho != d->Ho || wo != d->Wo) return fail(PTX_ERR_INVALID, "maxpool3d: output extent mismatch");
+    const int c4 = (d->C + 3) / 4 * 4;
+    if (d->ldy < 0 || (d->ldy > 0 && (d->ldy < c4 || d->ldy % 4)))
+        return fail(PTX_ERR_INVALID, "maxpool3d: output stride %d must cover C=%d and be a multiple of 4", d->ldy, d->C);
+    if (d->flags & ~(PTX_POOL_SAME | PTX_POOL_PAD_ZERO)) return fail(PTX_ERR_INVALID, "maxpool3d: unknown flags");
+    if (d->flags & PTX_POOL_SAME) {
+        // explicit output extent: every window must start inside the (front-padded) input
+        if (d->pT >= d->kT || d->pH >= d->kH || d->pW >= d->kW || (d->To - 1) * d->sT - d->pT >= d->Ti ||
+            (d->Ho - 1) * d->sH - d->pH >= d->Hi || (d->Wo - 1) * d->sW - d->pW >= d->Wi)
+            return fail(PTX_ERR_INVALID, "maxpool3d: SAME geometry leaves a window without a valid tap");
+    } else {
+        if (2 * d->pT > d->kT || 2 * d->pH > d->kH || 2 * d->pW > d->kW)
+            return fail(PTX_ERR_INVALID, "maxpool3d: padding larger than half the window");
+        const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
+        const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
+        const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
+        if (to != d->To || ho != d->Ho || wo != d->Wo) return fail(PTX_ERR_INVALID, "maxpool3d: output extent mismatch");
+    }
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "maxpool3d: misaligned pointer");
-    if (d->kW == 3 && d->sW == 2 && d->pW == 1 && d->Wo >= 8) {
+    if (d->flags == 0 && d->kW == 3 && d->sW == 2 && d->pW == 1 && d->Wo >= 8) {
         constexpr int WSEG = 8;
-        const size_t total = (size_t)d->N * d->To * d->Ho * cdiv(d->Wo, WSEG) * (d->ld / 4);
+        const size_t total = (size_t)d->N * d->To * d->Ho * cdiv(d->Wo, WSEG) * (c4 / 4);
         hipLaunchKernelGGL(maxpool3d_slide_kernel<WSEG>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d, x,
                            y, total);
         return hip_check(hipGetLastError(), "maxpool3d launch");
     }
-    const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (d->ld / 4);
+    const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (c4 / 4);
     hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, *d, x, y, total4);
     return hip_check(hipGetLastError(), "maxpool3d launch");
+}
+
+extern "C" int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,
+                          ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "copy2d: null pointer");
+    if (rows <= 0 || cols <= 0 || cols % 4 || ldx < cols || ldy < cols || ldx % 4 || ldy % 4)
+        return fail(PTX_ERR_INVALID, "copy2d: cols and strides must be positive multiples of 4 covering cols");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "copy2d: misaligned pointer");
+    const size_t total4 = (size_t)rows * (cols / 4);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, cols / 4,
+                       (long long)ldx, (long long)ldy);
+    return hip_check(hipGetLastError(), "copy2d launch");
+}
+
+extern "C" int ptx_window_mean(const float* x, float* y, int32_t outer, int32_t T, int32_t inner, int32_t k,
+                               int32_t stride, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "window_mean: null pointer");
+    if (outer <= 0 || T <= 0 || inner <= 0 || k <= 0 || k > T || stride <= 0)
+        return fail(PTX_ERR_INVALID, "window_mean: bad extents (T=%d k=%d stride=%d)", T, k, stride);
+    const int To = (T - k) / stride + 1;
+    const size_t total = (size_t)outer * To * inner;
+    hipLaunchKernelGGL(window_mean_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, T, To,
+                       inner, k, stride);
+    return hip_check(hipGetLastError(), "window_mean launch");
 }
 
 extern "C" int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,

@@ -21,8 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ConvDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
-                   PTX_PRO_RELU, PTX_EPI_ACCUM, PtxError, check)
+from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
+                   PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None
@@ -99,6 +99,19 @@ class Act:
     @property
     def S(self):
         return self.T * self.H * self.W
+
+    def slice(self, c0, C_):
+        """Channels [c0, c0 + C_) of this activation as an output target: same row stride, so a conv /
+        pool writing it fills its part of a channel concatenation (torch.cat(dim=1)) in place."""
+        assert c0 % 4 == 0 and c0 + C_ <= self.ld
+        v = Act.__new__(Act)
+        v.N, v.T, v.H, v.W, v.C, v.ld = self.N, self.T, self.H, self.W, C_, self.ld
+        v.t = self.t[..., c0:c0 + C_]
+        return v
+
+
+def _t3(v):
+    return (int(v),) * 3 if isinstance(v, int) else tuple(int(i) for i in v)
 
 
 class Packed:
@@ -196,9 +209,11 @@ class ConvStep:
 
 
 class Plan:
-    def __init__(self, engine, model, shape, dev):
+    def __init__(self, engine, model, shape, dev, norm=None):
         self.dev = dev
-        self.shape = tuple(shape)
+        self.shape = tuple(shape)        # always the NCDHW / NCHW view of the input
+        self.norm = norm                 # NormDesc when the input is uint8 frames (Engine.forward_frames)
+        self.head = None                 # custom classifier tail (two-pathway / per-frame heads)
         self.lib = _lib.lib()
         self.steps = []          # callables(stream)
         self.conv_steps = []
@@ -278,7 +293,7 @@ class Plan:
         st.x2 = None
         if x2 is not None:                      # K-concatenated second activation source (shortcut B)
             d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = x2.C, x2.ld, x2.T, x2.H, x2.W
-            d.x2_sT = d.x2_sH = d.x2_sW = int(x2_stride)
+            d.x2_sT, d.x2_sH, d.x2_sW = _t3(x2_stride)
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
@@ -297,7 +312,7 @@ class Plan:
         self.conv_steps.append(st)
         return y
 
-    def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv"):
+    def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv", y=None):
         """nn.Conv{2,3}d or a (2+1)D pair, followed by `bn`, with the epilogue fused."""
         if hasattr(conv, "spatial_conv"):      # r2plus1d.py:85-88
             ks, ss, ps = _geom(conv.spatial_conv)
@@ -308,14 +323,14 @@ class Plan:
                             relu=True, label=label + ".spatial")
             kt, st_, pt = _geom(conv.temporal_conv)
             return self.conv(mid, self.pack(conv.temporal_conv, bn), st_, pt, relu=relu, res=res,
-                             res_kind=res_kind, res_stride=res_stride, label=label + ".temporal")
+                             res_kind=res_kind, res_stride=res_stride, label=label + ".temporal", y=y)
         k, s, p = _geom(conv)
         fold = _foldable(conv, x)
         if fold:
             x = self.fold_input(x, conv)
             s, p = (s[0], s[1], 1), (p[0], p[1], 0)
         return self.conv(x, self.pack(conv, bn, fold), s, p, relu=relu, res=res, res_kind=res_kind,
-                         res_stride=res_stride, label=label)
+                         res_stride=res_stride, label=label, y=y)
 
     def fold_input(self, raw, conv):
         """raw: RawInput (NCDHW user tensor).  Emits ptx_fold_kw_ncdhw."""
@@ -327,9 +342,21 @@ class Plan:
         y = self.act(raw.N, raw.T, raw.H, Wo, kW * raw.C, ld)
         lib, yp = self.lib, _ptr(y.t)
         N, C_, T, H, W = raw.N, raw.C, raw.T, raw.H, raw.W
+        step_t, T_full = raw.t_step, raw.T_full
+        if raw.norm is not None:         # decoded uint8 frames [N,T,H,W,C]: normalise + fold in one pass
+            norm = raw.norm
+            self.keepalive.append(norm)
 
-        def step(st, self=self):
-            check(lib.ptx_fold_kw_ncdhw(self.in_ptr, yp, N, C_, T, H, W, kW, sW, pW, Wo, ld, st), "ptx_fold_kw_ncdhw")
+            def step(st, self=self):
+                check(lib.ptx_fold_kw_frames_u8(self.in_ptr, yp, N, C_, T, H, W, step_t, T_full, kW, sW, pW, Wo, ld,
+                                                C.byref(norm), st), "ptx_fold_kw_frames_u8")
+        else:                            # NCDHW fp32; `input[:, :, ::step]` is a stride, not a copy
+            plane = H * W
+            sn, sc, stt = C_ * T_full * plane, T_full * plane, step_t * plane
+
+            def step(st, self=self):
+                check(lib.ptx_fold_kw_strided(self.in_ptr, yp, N, C_, T, H, W, sn, sc, stt, kW, sW, pW, Wo, ld, st),
+                      "ptx_fold_kw_strided")
         self.steps.append(step)
         return y
 
@@ -343,12 +370,21 @@ class Plan:
         self.steps.append(step)
         return y
 
-    def maxpool(self, x, k, s, p):
-        To = (x.T + 2 * p[0] - k[0]) // s[0] + 1
-        Ho = (x.H + 2 * p[1] - k[1]) // s[1] + 1
-        Wo = (x.W + 2 * p[2] - k[2]) // s[2] + 1
-        y = self.act(x.N, To, Ho, Wo, x.C, x.ld)
-        d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.ld, To, Ho, Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+    def maxpool(self, x, k, s, p, y=None, same=False):
+        """max_pool3d.  same=True: TF-"SAME" geometry (out = ceil(in/stride), front pad = total//2) with
+        zero-valued padding -- F.pad followed by an unpadded MaxPool3d, as I3D ports do."""
+        if same:
+            To, Ho, Wo = (-(-x.T // s[0]), -(-x.H // s[1]), -(-x.W // s[2]))
+            p = tuple(max((o - 1) * st + kk - i, 0) // 2 for o, st, kk, i in zip((To, Ho, Wo), s, k, (x.T, x.H, x.W)))
+        else:
+            To = (x.T + 2 * p[0] - k[0]) // s[0] + 1
+            Ho = (x.H + 2 * p[1] - k[1]) // s[1] + 1
+            Wo = (x.W + 2 * p[2] - k[2]) // s[2] + 1
+        if y is None:
+            y = self.act(x.N, To, Ho, Wo, x.C, x.ld)
+        assert (y.N, y.T, y.H, y.W, y.C) == (x.N, To, Ho, Wo, x.C), "pool output shape"
+        d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.ld, To, Ho, Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2],
+                     y.ld, (PTX_POOL_SAME | PTX_POOL_PAD_ZERO) if same else 0)
         lib, xp, yp = self.lib, _ptr(x.t), _ptr(y.t)
         self.keepalive.append(d)
 
@@ -388,6 +424,11 @@ class Plan:
 
     # ---------------------------------------------------------------- network
     def _build(self, model):
+        kind = getattr(model, "plan_kind", "resnet")
+        if kind == "slowfast":
+            return self._build_slowfast(model)
+        if kind == "i3d":
+            return self._build_i3d(model)
         arch = model.arch
         shp = self.shape
         if arch.dims == 2:
@@ -395,7 +436,7 @@ class Plan:
             T = 1
         else:
             N, Cin, T, H, W = shp
-        raw = RawInput(N, Cin, T, H, W)
+        raw = RawInput(N, Cin, T, H, W, norm=self.norm)
         x = self.conv_bn(raw, model.conv1, model.bn1, relu=True, label="conv1")
         if arch.dims == 2:
             x = self.maxpool(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
@@ -408,7 +449,9 @@ class Plan:
         # head buffers
         self.pooled = torch.empty((x.N, x.C), device=self.dev, dtype=torch.float32)
 
-    def _block(self, arch, blk, x, name):
+    def _block(self, arch, blk, x, name, out=None):
+        """One residual block.  `out`: optional pre-allocated target (a channel slice of the next
+        stage's concatenated input, slowfast.py:145-151) for the block's final conv."""
         s = blk.stride
         fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block == "bottleneck"
                 and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.downsample[0], (nn.Conv3d, nn.Conv2d)))
@@ -419,7 +462,8 @@ class Plan:
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
             pk = self.pack_dual(blk.conv3, blk.bn3, blk.downsample[0], blk.downsample[1])
-            o = self.conv(o, pk, (1, 1, 1), (0, 0, 0), relu=True, x2=x, x2_stride=s, label=name + ".conv3+downsample")
+            o = self.conv(o, pk, (1, 1, 1), (0, 0, 0), relu=True, x2=x, x2_stride=_geom(blk.downsample[0])[1], y=out,
+                          label=name + ".conv3+downsample")
             if blk.has_nl:
                 o = self.nonlocal_block(o, blk.nonlocalblock, name + ".nonlocalblock")
             return o
@@ -434,16 +478,117 @@ class Plan:
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
             o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
-                             label=name + ".conv3")
+                             label=name + ".conv3", y=out)
         else:
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, res=res, res_kind=kind, res_stride=s,
-                             label=name + ".conv2")
+                             label=name + ".conv2", y=out)
         if blk.has_nl:
             o = self.nonlocal_block(o, blk.nonlocalblock, name + ".nonlocalblock")
         return o
 
+    # ---------------------------------------------------------------- SlowFast (slowfast.py:102-398)
+    def _build_slowfast(self, model):
+        N, Cin, T, H, W = self.shape
+        arch, mode = model.arch, model.mode
+        pool = ((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        stages = ("res2", "res3", "res4", "res5")
+
+        def out_hw(blk, x):
+            # (1,3,3) pad (0,1,1) conv carrying the block's spatial stride (slowfast.py:16-20,72-74)
+            return (x.H - 1) // blk.stride + 1, (x.W - 1) // blk.stride + 1
+
+        fast_feat = slow_feat = None
+        taps = []                                            # fast activations feeding the lateral convs
+        if mode in ("sf", "f"):
+            fast = model.fast if mode == "sf" else model
+            step = model.fast_stride
+            raw = RawInput(N, Cin, len(range(0, T, step)), H, W, t_step=step, T_full=T, norm=self.norm)
+            f = self.conv_bn(raw, fast.conv1, fast.bn1, relu=True, label="fast.conv1")
+            f = self.maxpool(f, *pool)
+            taps.append(f)
+            for name in stages:
+                for bi, blk in enumerate(getattr(fast, name)):
+                    f = self._block(arch, blk, f, "fast.%s.%d" % (name, bi))
+                taps.append(f)
+            fast_feat = f
+        if mode in ("sf", "s"):
+            slow = model.slow if mode == "sf" else model
+            step = model.slow_stride
+            raw = RawInput(N, Cin, len(range(0, T, step)), H, W, t_step=step, T_full=T, norm=self.norm)
+            s = self.conv_bn(raw, slow.conv1, slow.bn1, relu=True, label="slow.conv1")
+            laterals = ([model.fast.lateral_p1, model.fast.lateral_res2, model.fast.lateral_res3,
+                         model.fast.lateral_res4] if mode == "sf" else None)
+
+            def fuse_lateral(i, main_C, dims):
+                """Allocate cat([main, lateral_i(fast tap i)], dim=1) and emit the lateral conv into its slice."""
+                lat = laterals[i]
+                k, st_, pd = _geom(lat)
+                src = taps[i]
+                lt = ((src.T + 2 * pd[0] - k[0]) // st_[0] + 1, src.H, src.W)
+                if lt != dims:
+                    raise PtxError("SlowFast: lateral %d yields %s but the slow pathway is %s at that stage -- "
+                                   "torch.cat would fail in the reference too (slowfast.py:145-151); the lateral convs "
+                                   "stride time by 8, so slow_stride must be 8 * fast_stride" % (i, lt, dims))
+                cat = self.act(N, dims[0], dims[1], dims[2], main_C + lat.out_channels)
+                self.conv(src, self.pack(lat, None), st_, pd, y=cat.slice(main_C, lat.out_channels),
+                          label="fast.lateral%d" % i)
+                return cat
+
+            if laterals:
+                Ho, Wo = (s.H - 1) // 2 + 1, (s.W - 1) // 2 + 1
+                x = fuse_lateral(0, s.C, (s.T, Ho, Wo))
+                self.maxpool(s, *pool, y=x.slice(0, s.C))
+            else:
+                x = self.maxpool(s, *pool)
+            for si, name in enumerate(stages):
+                blocks = list(getattr(slow, name))
+                for bi, blk in enumerate(blocks):
+                    label = "slow.%s.%d" % (name, bi)
+                    if laterals and bi == len(blocks) - 1 and si < 3:
+                        Ho, Wo = out_hw(blk, x)
+                        cout = blk.out_channels
+                        nxt = fuse_lateral(si + 1, cout, (x.T, Ho, Wo))
+                        self._block(arch, blk, x, label, out=nxt.slice(0, cout))
+                        x = nxt
+                    else:
+                        x = self._block(arch, blk, x, label)
+            slow_feat = x
+        if mode != "sf":
+            self.feat = slow_feat if mode == "s" else fast_feat
+            self.pooled = torch.empty((N, self.feat.C), device=self.dev, dtype=torch.float32)
+            return
+        # two-pathway head: cat([avgpool(slow), avgpool(fast)]) -> dropout (identity) -> last_linear
+        self.feat = slow_feat
+        cs, cf = slow_feat.C, fast_feat.C
+        ps = torch.empty((N, cs), device=self.dev, dtype=torch.float32)
+        pf = torch.empty((N, cf), device=self.dev, dtype=torch.float32)
+        self.pooled = torch.empty((N, cs + cf), device=self.dev, dtype=torch.float32)
+        lib, pooled = self.lib, self.pooled
+
+        def head(engine, model):
+            st = _stream()
+            for f_, p_ in ((slow_feat, ps), (fast_feat, pf)):
+                check(lib.ptx_global_avgpool(_ptr(f_.t), _ptr(p_), f_.N, f_.C, f_.S, f_.ld, 0, st), "ptx_global_avgpool")
+            check(lib.ptx_copy2d(_ptr(ps), _ptr(pooled), N, cs, cs, cs + cf, st), "ptx_copy2d")
+            check(lib.ptx_copy2d(_ptr(pf), _ptr(pooled, cs), N, cf, cf, cs + cf, st), "ptx_copy2d")
+            out = engine._head(model, _ptr(pooled), N, cs + cf, self.dev)
+            return out if out is not None else model.head_module(pooled.clone())
+        self.head = head
+
     # ---------------------------------------------------------------- running
+    def run_head(self, engine, model):
+        """feature map -> logits: the default global-average-pool + classifier, or the plan's own tail."""
+        if self.head is not None:
+            return self.head(engine, model)
+        f = self.feat
+        check(self.lib.ptx_global_avgpool(_ptr(f.t), _ptr(self.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
+              "ptx_global_avgpool")
+        out = engine._head(model, _ptr(self.pooled), f.N, f.C, self.dev)
+        if out is None:     # user-supplied head module (Identity, Dropout, custom nn.Module): theirs to run
+            out = model.head_module(self.pooled.clone())
+        return out
+
     def refresh_weights(self):
         keep = []
         for p in self.packs:
@@ -460,10 +605,13 @@ class Plan:
 
 class RawInput:
     """Shape of the user's NCDHW (or NCHW, T == 1) input; its pointer is bound at run time."""
-    __slots__ = ("N", "C", "T", "H", "W")
+    __slots__ = ("N", "C", "T", "H", "W", "t_step", "T_full", "norm")
 
-    def __init__(self, N, C_, T, H, W):
+    def __init__(self, N, C_, T, H, W, t_step=1, T_full=None, norm=None):
         self.N, self.C, self.T, self.H, self.W = N, C_, T, H, W
+        self.t_step = int(t_step)                       # every t_step-th frame of a T_full-frame clip
+        self.T_full = T if T_full is None else T_full
+        self.norm = norm                                # NormDesc: the input is uint8 [N,T,H,W,C] frames
 
 
 def _foldable(conv, x):
@@ -528,13 +676,16 @@ class Engine:
     def _signature(model):
         return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
 
-    def plan_for(self, model, x):
-        key = (tuple(x.shape), x.device.index, id(model))
+    def plan_for(self, model, x, shape=None, norm=None):
+        """shape / norm: the NCDHW view and NormDesc of a uint8-frames input (forward_frames)."""
+        shape = tuple(x.shape) if shape is None else tuple(shape)
+        nkey = None if norm is None else (tuple(norm.mean), tuple(norm.std), norm.swap_rb, norm.to_255)
+        key = (shape, x.device.index, id(model), nkey)
         with self._lock:
             plan = self._plans.get(key)
             fresh = plan is None
             if fresh:
-                plan = Plan(self, model, x.shape, x.device)
+                plan = Plan(self, model, shape, x.device, norm)
                 self._plans[key] = plan
             if fresh or self.check_weights:
                 sig = self._signature(model)
@@ -618,7 +769,7 @@ class Engine:
         if self.auto_tune and not plan.tuned:
             plan.tuned = True
             if any(json.dumps(s.d.key()) not in _tuned_table() for s in plan.conv_steps):
-                self.autotune(model, x, iters=2, only_untuned=True)
+                self.autotune(model, x, iters=2, only_untuned=True, plan=plan)
 
     def _forward_graph(self, model, plan, x):
         """Capture (once) and replay forward() as a hipGraph.  The input is staged into a static
@@ -640,13 +791,8 @@ class Engine:
         return g["out"].clone()
 
     def _forward_eager(self, model, plan, x):
-        f = plan.run_features(x)
-        check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
-              "ptx_global_avgpool")
-        out = self._head(model, _ptr(plan.pooled), f.N, f.C, x.device)
-        if out is None:
-            out = model.head_module(plan.pooled.clone())
-        return out
+        plan.run_features(x)
+        return plan.run_head(self, model)
 
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""
@@ -660,23 +806,61 @@ class Engine:
             self._maybe_tune(model, plan, x)
             if self.use_graph:
                 return self._forward_graph(model, plan, x)
-            f = plan.run_features(x)
-            check(_lib.lib().ptx_global_avgpool(_ptr(f.t), _ptr(plan.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
-                  "ptx_global_avgpool")
-            out = self._head(model, _ptr(plan.pooled), f.N, f.C, x.device)
-            if out is None:
-                out = model.head_module(plan.pooled.clone())
+            out = self._forward_eager(model, plan, x)
         return out
 
     # ------------------------------------------------------------------------------------
-    def autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False):
+    def forward_frames(self, model, frames, opts=None):
+        """Decoded uint8 frames [N,T,H,W,C] (NHWC for 2-D models) -> logits.  The tensor half of the
+        reference's TransformImage (ToTensor, ToSpaceBGR, ToRange255, Normalize; transforms/utils.py:72-75)
+        is fused into the stem's fold kernel: no fp32 NCDHW clip is ever materialised.  `opts`: anything
+        with mean / std / input_space / input_range (default: the model's own pretrained settings)."""
+        opts = model if opts is None else opts
+        get = (lambda k: opts[k]) if isinstance(opts, dict) else (lambda k: getattr(opts, k))
+        try:
+            norm = NormDesc.make(get("mean"), get("std"), get("input_space"), get("input_range"))
+        except (AttributeError, KeyError):
+            raise PtxError("forward_frames: no mean/std/input_space/input_range on the model (they exist only for "
+                           "pretrained models, torchvision_models.py:162-166): pass opts=pretrained_settings[...]")
+        if model.training:
+            raise PtxError("pretorched-x_amd is a forward-only (inference) engine: call model.eval() first")
+        dims = model.arch.dims
+        if not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dtype != torch.uint8:
+            raise PtxError("forward_frames: frames must be a uint8 CUDA tensor")
+        if frames.dim() != dims + 2:
+            raise PtxError("forward_frames: expected %s, got shape %s" % (
+                "[N,T,H,W,C]" if dims == 3 else "[N,H,W,C]", tuple(frames.shape)))
+        if frames.shape[-1] != 3:
+            raise PtxError("forward_frames: the stems take 3 channels")
+        frames = frames.contiguous()
+        if dims == 3:
+            N, T, H, W, Cc = frames.shape
+            shape = (N, Cc, T, H, W)
+        else:
+            N, H, W, Cc = frames.shape
+            shape = (N, Cc, H, W)
+        key = ("maxb", shape[1:], id(model))
+        with self._lock:
+            mb = self._sig.get(key)
+            if mb is None:
+                mb = self._sig[key] = self.max_batch(model, shape[1:])
+        if N > mb:
+            return torch.cat([self.forward_frames(model, frames[i:i + mb], opts) for i in range(0, N, mb)], 0)
+        with torch.cuda.device(frames.device):
+            plan = self.plan_for(model, frames, shape=shape, norm=norm)
+            self._maybe_tune(model, plan, frames)
+            return self._forward_eager(model, plan, frames)
+
+    def autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False, plan=None):
         """Time every compiled tile configuration (x a few split-K factors) for each distinct conv
         problem of the plan with HIP events and keep the fastest."""
-        self._validate(model, x, model.arch.dims)
+        if plan is None:
+            self._validate(model, x, model.arch.dims)
         lib = _lib.lib()
         table = _tuned_table()
         with torch.cuda.device(x.device):
-            plan = self.plan_for(model, x.contiguous())
+            if plan is None:
+                plan = self.plan_for(model, x.contiguous())
             plan.tuned = True
             plan.run_features(x.contiguous())      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
@@ -692,6 +876,7 @@ class Engine:
                 best = None
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
                 M = stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo
+                ncol = _r4(stp.d.Co)                          # columns written (ldy is only the row stride)
                 for cfg in range(ncfg):
                     name = lib.ptx_conv3d_config_name(cfg).decode()
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
@@ -699,13 +884,13 @@ class Engine:
                         continue
                     if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
                         continue
-                    if bn_ > 64 and stp.d.ldy <= 64:
+                    if bn_ > 64 and ncol <= 64:
                         continue
-                    if bn_ % 48 == 0 and stp.d.ldy % 48 != 0:     # 48/96-wide tiles: (2+1)D widths only
+                    if bn_ % 48 == 0 and ncol % 48 != 0:          # 48/96-wide tiles: (2+1)D widths only
                         continue
                     if bm >= 128 and M < 8192:
                         continue
-                    blocks = ((M + bm - 1) // bm) * ((stp.d.ldy + bn_ - 1) // bn_)
+                    blocks = ((M + bm - 1) // bm) * ((ncol + bn_ - 1) // bn_)
                     splits = [1]
                     if blocks < 512:
                         splits += [s for s in (2, 3, 4, 6, 8) if steps_k // s >= 4 and blocks * s <= 2048]

@@ -204,6 +204,12 @@ class VideoResNet(nn.Module):
     def forward(self, input):
         return self._engine.forward(self, input)
 
+    def forward_frames(self, frames, opts=None):
+        """Decoded uint8 frames [B,T,H,W,3] ([B,H,W,3] for the 2-D nets) -> logits: the tensor half of the
+        reference's TransformImage (transforms/utils.py:72-75) is fused into the stem's fold kernel.
+        opts: mean/std/input_space/input_range holder; default: this model's pretrained settings."""
+        return self._engine.forward_frames(self, frames, opts)
+
     def engine(self):
         return self._engine
 

@@ -56,6 +56,8 @@ GOLDEN_CASES = {
     "nonlocalresnet3d50_cfg3": ("nonlocalresnet3d50", dict(pretrained=None)),
 }
 TRN_CASES = ("trn_htrn_small", "trn_mstrn_small", "trn_trn_b1")
+SLOWFAST_CASES = ("slowfast50_sf_small", "slowfast50_s_small", "slowfast50_f_small", "slowfast18_sf_small",
+                  "slowfast50_sf_full")
 FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3")
 
 
@@ -82,3 +84,16 @@ def golden_trn(ptx, case):
     model = ptx.TRN(pretrained=None, **kw)
     model.load_state_dict(synth_state_dict(model.state_dict(), int(blob["w_seed"])))
     return kw, model, golden_input(blob), blob
+
+
+def golden_slowfast(ptx, case):
+    """(product model on CPU with the fixture's weights, state_dict, input, blob, oracle args)."""
+    import json
+    from pretorched_x_amd.testing import synth_state_dict
+    blob = load_golden(case)
+    fac, mode, kw = str(blob["factory"]), str(blob["mode"]), json.loads(str(blob["kwargs"]))
+    model = getattr(ptx.slowfast, fac)(mode=mode, **kw)
+    sd = synth_state_dict(model.state_dict(), int(blob["w_seed"]))
+    model.load_state_dict(sd)
+    block, layers = {"resnet50": ("bottleneck", [3, 4, 6, 3]), "resnet18": ("basic", [2, 2, 2, 2])}[fac]
+    return model, sd, golden_input(blob), blob, (block, layers, mode.lower())

@@ -94,6 +94,35 @@ TRN_CASES = {
 }
 
 
+# SlowFast (slowfast.py): name -> (factory, mode, kwargs, input shape)
+SLOWFAST_CASES = {
+    "slowfast50_sf_small": ("resnet50", "SF", dict(num_classes=51), (2, 3, 32, 64, 64)),
+    "slowfast50_s_small": ("resnet50", "S", dict(num_classes=51), (2, 3, 32, 64, 64)),
+    "slowfast50_f_small": ("resnet50", "F", dict(num_classes=51), (2, 3, 32, 64, 64)),
+    "slowfast18_sf_small": ("resnet18", "SF", dict(num_classes=51), (3, 3, 32, 48, 80)),
+    "slowfast50_sf_full": ("resnet50", "SF", dict(num_classes=400), (2, 3, 64, 224, 224)),
+}
+
+
+def make_slowfast(ref, keys_out, only):
+    for case, (fac, mode, kw, shape) in SLOWFAST_CASES.items():
+        if only and case not in only and "slowfast" not in only:
+            continue
+        model = getattr(ref.slowfast, fac)(mode=mode, **kw)
+        model.eval()
+        sd = synth_state_dict(model.state_dict(), W_SEED)
+        model.load_state_dict(sd)
+        keys_out[case] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(X_SEED))
+        with torch.no_grad():
+            logits = model(x)
+        np.savez_compressed(os.path.join(OUT, case + ".npz"), logits=logits.numpy(), shape=np.array(shape),
+                            w_seed=W_SEED, x_seed=X_SEED, factory=np.array(fac), mode=np.array(mode),
+                            kwargs=np.array(json.dumps(kw)))
+        print("%-28s logits %s max|.|=%.3f argmax=%s" % (case, tuple(logits.shape), logits.abs().max().item(),
+                                                        logits.argmax(1).tolist()))
+
+
 def build_ref_trn(ref, trn, **kw):
     """The reference TRN (trn.py:194-244) cannot be constructed without a download: it reads
     base_model.mean/std (set only by load_pretrained).  Here `pretrainedmodels.__dict__[arch]`
@@ -179,6 +208,8 @@ def main():
 
     if not only or "trn" in only:
         make_trn(ref, trn, keys_out)
+    if not only or any(c.startswith("slowfast") for c in only):
+        make_slowfast(ref, keys_out, only)
     json.dump(keys_out, open(keys_path, "w"))
 
 

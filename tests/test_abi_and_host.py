@@ -36,14 +36,19 @@ def test_struct_layouts_match_header(ptx):
             decl = decl.strip()
             if not decl:
                 continue
-            names = decl.replace("uint32_t", "").replace("int32_t", "")
-            out += [n.strip() for n in names.split(",") if n.strip()]
+            names = decl.replace("uint32_t", "").replace("int32_t", "").replace("float", "")
+            out += [re.sub(r"\[\d+\]", "", n).strip() for n in names.split(",") if n.strip()]
         return out
 
     assert fields_of("ptx_conv3d_desc") == [f for f, _ in L.ConvDesc._fields_]
     assert fields_of("ptx_pack_desc") == [f for f, _ in L.PackDesc._fields_]
     assert fields_of("ptx_pool3d_desc") == [f for f, _ in L.PoolDesc._fields_]
+    assert fields_of("ptx_norm_desc") == [f for f, _ in L.NormDesc._fields_]
     assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
+    assert C.sizeof(L.PoolDesc) == 4 * len(L.PoolDesc._fields_)
+    assert C.sizeof(L.NormDesc) == 4 * 10
+    nd = L.NormDesc.make([0.485, 0.456, 0.406], [0.229, 0.224, 0.225], "BGR", [0, 255])
+    assert nd.swap_rb == 1 and nd.to_255 == 1 and abs(nd.std[2] - 0.225) < 1e-7 and nd.std[3] == 1.0
 
 
 def test_host_side_validation_without_gpu(ptx):
@@ -210,3 +215,31 @@ def test_shard_bounds():
             assert [b - a for a, b in chunks] == want[:world]
             assert chunks[0][0] == 0 and chunks[-1][1] == total
             assert all(chunks[i][1] == chunks[i + 1][0] for i in range(world - 1))
+
+
+def test_slowfast_plan_wiring_without_gpu(ptx):
+    """Dry plan (meta device) of SlowFast-50: lateral convs and the stages' last convs write channel
+    slices of one concatenated tensor (no torch.cat), both stems read strided frames."""
+    m = ptx.slowfast.resnet50(num_classes=7)
+    plan = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
+    steps = {s.label: s for s in plan.conv_steps}
+    assert len(plan.conv_steps) == 102
+    for lat, (co, ld) in {"fast.lateral0": (16, 80), "fast.lateral1": (64, 320), "fast.lateral2": (128, 640),
+                          "fast.lateral3": (256, 1280)}.items():
+        d = steps[lat].d
+        assert (d.Co, d.ldy, d.kT, d.sT, d.pT, d.To) == (co, ld, 5, 8, 2, 4)
+    assert steps["slow.res2.2.conv3"].d.ldy == 320 and steps["slow.res3.3.conv3"].d.ldy == 640
+    assert steps["slow.res5.2.conv3"].d.ldy == 2048
+    d = steps["slow.res2.0.conv3+downsample"].d            # stage entry reads the 80-channel concat
+    assert (d.x2_C, d.x2_sT, d.x2_sH, d.x2_sW) == (80, 1, 1, 1)
+    d = steps["slow.res3.0.conv3+downsample"].d
+    assert (d.x2_C, d.x2_sT, d.x2_sH, d.x2_sW) == (320, 1, 2, 2)
+    assert tuple(plan.pooled.shape) == (2, 2304)
+    assert steps["fast.conv1"].d.Ti == 32 and steps["slow.conv1"].d.Ti == 4
+    # pathway-only modes and the basic-block variant compile too
+    for fac, mode, n in ((ptx.slowfast.resnet50, "S", 49), (ptx.slowfast.resnet50, "F", 49), (ptx.slowfast.resnet18, "SF", 45)):
+        mm = fac(mode=mode, num_classes=3)
+        assert len(mm.engine().dry_plan(mm, (1, 3, 32, 64, 64)).conv_steps) == n
+    m8 = ptx.slowfast.resnet50(num_classes=5, slow_stride=8)
+    with pytest.raises(ptx.PtxError):
+        m8.engine().dry_plan(m8, (1, 3, 32, 64, 64))

@@ -422,3 +422,134 @@ def test_error_paths_on_device(ptx):
     st = lib.ptx_conv3d_fwd(C.byref(d), _p(x, 1), _p(x), None, None, _p(x, 4096), None, 0, 2, 1, _st())
     assert st == 1 and b"aligned" in lib.ptx_last_error()
     torch.cuda.synchronize()
+
+
+def test_conv_output_channel_slice(ptx):
+    """A conv writing a channel slice of a wider tensor (row stride ldy > Co): the in-place form of
+    torch.cat(dim=1) (slowfast.py:145-151) -- neighbours untouched, also through split-K."""
+    L, lib = ptx._lib, _lib(ptx)
+    N, T, H, W, Ci, Co, c0, total = 2, 3, 9, 10, 32, 16, 64, 96
+    x, w = rnd(N, Ci, T, H, W, seed=70), rnd(Co, Ci, 5, 1, 1, seed=71, scale=0.1)
+    want = F.conv3d(x, w, None, (2, 1, 1), (2, 0, 0))
+    To = want.shape[2]
+    pd = L.PackDesc(Co, Ci, 5, 1, 1, Ci, 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(128, device=DEV)
+    wd = w.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, None, None, None, None, C.c_float(0), _p(wp), _p(bp),
+                                     _st()), "pack")
+    xd = to_cl(x)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, Ci
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = To, H, W, Co, total
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 5, 1, 1, 2, 1, 1, 2, 0, 0
+    d.Kc, d.Co_pad = Ci, 128
+    ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 4)
+    assert ws_bytes == 4 * N * To * H * W * Co * 4            # dense [M][Co] slabs, not [M][ldy]
+    ws = torch.empty(ws_bytes // 4, device=DEV)
+    for cfg, split in ((-1, 0), (28, 1), (30, 4), (0, 2)):
+        cat = torch.full((N, To, H, W, total), 7.0, device=DEV)
+        L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(cat, c0), _p(ws), ws_bytes, cfg, split,
+                                   _st()), "conv slice")
+        torch.cuda.synchronize()
+        got = cat.cpu()
+        close(got[..., c0:c0 + Co].permute(0, 4, 1, 2, 3), want)
+        assert bool((got[..., :c0] == 7.0).all()) and bool((got[..., c0 + Co:] == 7.0).all()), (cfg, split)
+
+
+def test_fold_strided_and_frames_u8(ptx):
+    """ptx_fold_kw_strided on `input[:, :, ::step]` == fold of the materialised slice (bit-equal);
+    ptx_fold_kw_frames_u8 / ptx_frames_u8_to_ncdhw == TransformImage's tensor half (utils.py:72-75)
+    followed by the fold, bit-equal to the CPU fp32 arithmetic."""
+    from oracle import functional as OF
+    L, lib = ptx._lib, _lib(ptx)
+    N, T, H, W, step = 2, 11, 13, 18, 4
+    Wo = (W + 6 - 7) // 2 + 1
+    x = rnd(N, 3, T, H, W, seed=80)
+    xs = x[:, :, ::step].contiguous()
+    Ts = xs.shape[2]
+    a = torch.full((N, Ts, H, Wo, 24), float("nan"), device=DEV)
+    b = torch.full((N, Ts, H, Wo, 24), float("nan"), device=DEV)
+    xd, xsd = x.to(DEV), xs.to(DEV)
+    L.check(lib.ptx_fold_kw_ncdhw(_p(xsd), _p(a), N, 3, Ts, H, W, 7, 2, 3, Wo, 24, _st()), "fold")
+    L.check(lib.ptx_fold_kw_strided(_p(xd), _p(b), N, 3, Ts, H, W, 3 * T * H * W, T * H * W, step * H * W, 7, 2, 3, Wo,
+                                    24, _st()), "fold strided")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # reference of the fold itself: y[n,t,h,wo,kw*3+c] = x[n,c,t,h,wo*2-3+kw]
+    xp = F.pad(xs, (3, 3))
+    ref = torch.zeros(N, Ts, H, Wo, 24)
+    for kw in range(7):
+        ref[..., kw * 3:kw * 3 + 3] = xp[:, :, :, :, kw:kw + 2 * Wo:2][..., :Wo].permute(0, 2, 3, 4, 1)
+    assert torch.equal(a.cpu(), ref)
+    g = torch.Generator().manual_seed(81)
+    frames = torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g)
+    fd = frames.to(DEV)
+    for space, rng_ in (("RGB", [0, 1]), ("BGR", [0, 255])):
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        if rng_[1] == 255:
+            mean, std = [104.0, 117.0, 123.0], [1.0, 57.0, 58.5]
+        nd = L.NormDesc.make(mean, std, space, rng_)
+        want = OF.transform_frames(frames, mean, std, space, rng_)
+        y = torch.full((N, 3, T, H, W), float("nan"), device=DEV)
+        L.check(lib.ptx_frames_u8_to_ncdhw(C.c_void_p(fd.data_ptr()), _p(y), N, T, H, W, 3, C.byref(nd), _st()), "u8")
+        torch.cuda.synchronize()
+        assert torch.equal(y.cpu(), want), space                 # same fp32 ops in the same order
+        got = ptx.transforms.FramesToTensor(dict(mean=mean, std=std, input_space=space, input_range=rng_))(fd)
+        assert torch.equal(got.cpu(), want)
+        wd = want[:, :, ::step].contiguous().to(DEV)
+        L.check(lib.ptx_fold_kw_ncdhw(_p(wd), _p(a), N, 3, Ts, H, W, 7, 2, 3, Wo, 24, _st()), "fold")
+        L.check(lib.ptx_fold_kw_frames_u8(C.c_void_p(fd.data_ptr()), _p(b), N, 3, Ts, H, W, step, T, 7, 2, 3, Wo, 24,
+                                          C.byref(nd), _st()), "fold u8")
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), space
+
+
+def test_maxpool_same_slices_copy_and_window_mean(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    # TF-"SAME" pooling with zero-valued padding (F.pad + MaxPool3d), output into a channel slice
+    for (N, T, H, W, Cc, k, s) in [(2, 5, 14, 14, 24, (1, 3, 3), (1, 2, 2)), (1, 7, 9, 11, 16, (3, 3, 3), (2, 2, 2)),
+                                   (2, 4, 7, 7, 32, (2, 2, 2), (2, 2, 2)), (1, 4, 6, 6, 12, (3, 3, 3), (1, 1, 1))]:
+        x = rnd(N, Cc, T, H, W, seed=90) - 0.5
+        out = [-(-i // st) for i, st in zip((T, H, W), s)]
+        tot = [max((o - 1) * st + kk - i, 0) for o, st, kk, i in zip(out, s, k, (T, H, W))]
+        fr = [t // 2 for t in tot]
+        xp = F.pad(x, (fr[2], tot[2] - fr[2], fr[1], tot[1] - fr[1], fr[0], tot[0] - fr[0]))
+        want = F.max_pool3d(xp, k, s)
+        assert list(want.shape[2:]) == out
+        xd = to_cl(x)
+        total, c0 = Cc + 40, 8
+        cat = torch.full((N, *out, total), 3.0, device=DEV)
+        d = L.PoolDesc(N, T, H, W, Cc, xd.shape[-1], *out, *k, *s, *fr, total, L.PTX_POOL_SAME | L.PTX_POOL_PAD_ZERO)
+        L.check(lib.ptx_maxpool3d_fwd(C.byref(d), _p(xd), _p(cat, c0), _st()), "maxpool same")
+        torch.cuda.synchronize()
+        got = cat.cpu()
+        assert torch.equal(got[..., c0:c0 + Cc].permute(0, 4, 1, 2, 3), want)
+        assert bool((got[..., :c0] == 3.0).all()) and bool((got[..., c0 + Cc:] == 3.0).all())
+    # regular pooling into a slice through the sliding-window kernel (slowfast.py:123 + :145)
+    x = rnd(2, 64, 2, 20, 20, seed=91)
+    want = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    xd = to_cl(x)
+    cat = torch.full((2, 2, 10, 10, 80), 3.0, device=DEV)
+    d = L.PoolDesc(2, 2, 20, 20, 64, 64, 2, 10, 10, 1, 3, 3, 1, 2, 2, 0, 1, 1, 80, 0)
+    L.check(lib.ptx_maxpool3d_fwd(C.byref(d), _p(xd), _p(cat), _st()), "maxpool slice")
+    torch.cuda.synchronize()
+    assert torch.equal(cat.cpu()[..., :64].permute(0, 4, 1, 2, 3), want) and bool((cat[..., 64:] == 3.0).all())
+    # copy2d: place [rows, cols] into a column window
+    src = rnd(7, 24, seed=92).to(DEV)
+    dst = torch.zeros(7, 40, device=DEV)
+    L.check(lib.ptx_copy2d(_p(src), _p(dst, 12), 7, 24, 24, 40, _st()), "copy2d")
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, 12:36], src) and bool((dst[:, :12] == 0).all()) and bool((dst[:, 36:] == 0).all())
+    # window mean: avg_pool over time (k=2, s=1) and mean over all steps
+    x = rnd(3, 8, 20, seed=93)
+    xd = x.to(DEV)
+    y = torch.empty(3, 7, 20, device=DEV)
+    L.check(lib.ptx_window_mean(_p(xd), _p(y), 3, 8, 20, 2, 1, _st()), "window_mean")
+    z = torch.empty(3, 1, 20, device=DEV)
+    L.check(lib.ptx_window_mean(_p(xd), _p(z), 3, 8, 20, 8, 1, _st()), "window_mean all")
+    torch.cuda.synchronize()
+    close(y.cpu(), (x[:, :-1] + x[:, 1:]) / 2, tol=1e-6)
+    close(z.cpu()[:, 0], x.mean(1), tol=1e-6)
+    assert lib.ptx_window_mean(_p(xd), _p(z), 3, 8, 20, 9, 1, _st()) == 1
+    assert lib.ptx_copy2d(_p(src), _p(dst), 7, 22, 24, 40, _st()) == 1

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, TRN_CASES, golden_input, golden_recipe, golden_trn, load_golden
+from conftest import (GOLDEN_CASES, SLOWFAST_CASES, TRN_CASES, golden_input, golden_recipe, golden_slowfast,
+                      golden_trn, load_golden)
 from oracle import functional as OF
 from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
@@ -305,3 +306,65 @@ def test_trn_user_head_and_errors(ptx):
         model(x)                                            # CPU tensor: no fallback
     with pytest.raises(ValueError):
         ptx.TRN(5, consensus="nope", pretrained=None)
+
+
+@pytest.mark.parametrize("case", SLOWFAST_CASES)
+def test_slowfast_parity(ptx, case):
+    """SlowFast / SlowOnly / FastOnly (slowfast.py) on the GPU against the real reference's logits
+    (golden) and, for the small cases, the oracle in the same run.  Frame subsampling is a stride of
+    the fold kernel; the lateral concats are channel-slice writes."""
+    model, sd, x, blob, (block, layers, mode) = golden_slowfast(ptx, case)
+    model = model.to(DEV).eval()
+    out = model(x.to(DEV))
+    torch.cuda.synchronize()
+    want = torch.from_numpy(blob["logits"])
+    err = _check(out, want, case + " logits vs golden")
+    assert torch.equal(out.cpu().argmax(1), want.argmax(1))
+    if not case.endswith("_full"):
+        _check(out, OF.slowfast_forward(sd, x, block, layers, mode), case + " logits vs oracle")
+    again = model(x.to(DEV))
+    assert torch.equal(out, again)                       # deterministic
+    print("%s max|dlogits| = %.3e (max|logit| %.2f)" % (case, err, want.abs().max().item()))
+
+
+def test_slowfast_errors(ptx):
+    # the lateral convs stride time by 8: with slow_stride != 8 * fast_stride the lateral features do not
+    # line up with the slow pathway (torch.cat fails upstream)
+    m = ptx.slowfast.resnet50(num_classes=5, slow_stride=8).to(DEV)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 32, 64, 64, device=DEV))
+    with pytest.raises(TypeError):
+        ptx.slowfast.resnet50(mode="nope")
+
+
+def test_forward_frames_fused_preprocessing(ptx):
+    """uint8 frames -> logits with TransformImage's tensor half (transforms/utils.py:72-75) fused into
+    the stem's fold kernel == the same model on the CPU-normalised fp32 clip."""
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (2, 8, 64, 64, 3), dtype=torch.uint8, generator=g)
+    opts = ptx.pretrained_settings["resnet3d50"]["moments"]
+    clip = OF.transform_frames(frames, opts["mean"], opts["std"], opts["input_space"], opts["input_range"])
+    model, sd = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), 1234)
+    want = OF.forward(OF.ARCHS["resnet3d50"], sd, clip)
+    a = model(clip.to(DEV))
+    b = model.forward_frames(frames.to(DEV), opts)
+    _check(a, want, "fp32 clip vs oracle")
+    _check(b, want, "uint8 frames vs oracle")
+    assert (a - b).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    with pytest.raises(Exception):
+        model.forward_frames(frames.to(DEV))            # pretrained=None models carry no mean/std
+    with pytest.raises(Exception):
+        model.forward_frames(frames, opts)              # CPU tensor
+    # BGR / 0-255 settings and a two-pathway model (both stems read the same uint8 frames at their own stride)
+    opts2 = dict(mean=[104.0, 117.0, 123.0], std=[58.0, 57.0, 57.5], input_space="BGR", input_range=[0, 255])
+    frames2 = torch.randint(0, 256, (2, 32, 64, 64, 3), dtype=torch.uint8, generator=g)
+    sf, sd2, _, _, (block, layers, mode) = golden_slowfast(ptx, "slowfast50_sf_small")
+    sf = sf.to(DEV).eval()
+    clip2 = OF.transform_frames(frames2, **opts2)
+    _check(sf.forward_frames(frames2.to(DEV), opts2), OF.slowfast_forward(sd2, clip2, block, layers, mode),
+           "slowfast uint8 frames vs oracle")
+    # 2-D model: [N,H,W,3]
+    m2, sdr = _build(ptx, "resnet18", dict(num_classes=10, pretrained=None), 7)
+    img = torch.randint(0, 256, (3, 96, 80, 3), dtype=torch.uint8, generator=g)
+    clip3 = OF.transform_frames(img.unsqueeze(1), opts["mean"], opts["std"])[:, :, 0]
+    _check(m2.forward_frames(img.to(DEV), opts), OF.forward(OF.ARCHS["resnet18"], sdr, clip3), "2-D uint8 frames")

@@ -7,7 +7,8 @@ import torch
 import json
 import os
 
-from conftest import GOLDEN, GOLDEN_CASES, TRN_CASES, golden_input, golden_recipe, golden_trn, load_golden
+from conftest import (GOLDEN, GOLDEN_CASES, SLOWFAST_CASES, TRN_CASES, golden_input, golden_recipe, golden_slowfast,
+                      golden_trn, load_golden)
 from oracle import functional as OF
 from oracle import ref_shim, tv_standin
 from pretorched_x_amd.testing import synth_state_dict
@@ -99,6 +100,34 @@ def test_oracle_trn_wrapper_golden(ptx, case):
         want = torch.from_numpy(blob[name])
         assert got.shape == want.shape, name
         assert (got - want).abs().max().item() <= GOLDEN_TOL * max(1.0, want.abs().max().item()), name
+
+
+@pytest.mark.parametrize("case", [c for c in SLOWFAST_CASES if not c.endswith("_full")])
+def test_oracle_slowfast_golden(ptx, case):
+    """slowfast.py: state_dict ABI equal to the reference model's, oracle equal to its logits."""
+    model, sd, x, blob, (block, layers, mode) = golden_slowfast(ptx, case)
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))[case]
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == keys
+    out = OF.slowfast_forward(sd, x, block, layers, mode)
+    want = torch.from_numpy(blob["logits"])
+    assert out.shape == want.shape
+    assert (out - want).abs().max().item() <= GOLDEN_TOL * max(1.0, want.abs().max().item())
+    assert torch.equal(out.argmax(1), want.argmax(1))
+
+
+@needs_ref
+@pytest.mark.parametrize("fac,block,layers", [("resnet50", "bottleneck", [3, 4, 6, 3]), ("resnet18", "basic", [2, 2, 2, 2])])
+def test_oracle_slowfast_bit_equal_to_reference(fac, block, layers):
+    ref = ref_shim.import_reference()
+    x = torch.randn(1, 3, 32, 48, 48, generator=torch.Generator().manual_seed(1))
+    for mode in ("SF", "S", "F"):
+        m = getattr(ref.slowfast, fac)(mode=mode, num_classes=9)
+        m.eval()
+        sd = synth_state_dict(m.state_dict(), 3)
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            want = m(x)
+        assert torch.equal(OF.slowfast_forward(sd, x, block, layers, mode.lower()), want), (fac, mode)
 
 
 @needs_ref
