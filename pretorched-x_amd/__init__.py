@@ -21,6 +21,7 @@ from . import _lib
 from ._lib import PtxError
 from .engine import Engine, relation_mlp
 from . import transforms  # noqa: F401
+from .i3d import InceptionI3d, i3d  # noqa: F401
 from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
 from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation,
                   Relation, VideoResNet, factored_mid_channels)
@@ -247,4 +248,4 @@ def trn(num_classes=339, num_segments=8, consensus="MSTRN", arch="resnet50", pre
 model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
                "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
-               "resnet101", "resnet152", "trn"]
+               "resnet101", "resnet152", "trn", "i3d"]

@@ -781,13 +781,18 @@ static int validate_desc(const ptx_conv3d_desc* d) {
     if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < (d->Co + 3) / 4 * 4)
         return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d Co=%d",
                     d->Kc, d->Co_pad, d->Ci, d->Co);
-    // output extent must match the conv arithmetic
-    const int to = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1;
-    const int ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1;
-    const int wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
-    if (to != d->To || ho != d->Ho || wo != d->Wo)
-        return fail(PTX_ERR_INVALID, "conv3d: output extent (%d,%d,%d) != expected (%d,%d,%d)", d->To, d->Ho,
-                    d->Wo, to, ho, wo);
+    // output extent must match the conv arithmetic: symmetric padding p, or TF-"SAME" (out = ceil(in/stride),
+    // p = the FRONT pad floor(total/2); the back pad is implied -- out-of-range taps read zero either way)
+    auto extent_ok = [](int in, int out, int k, int s, int p) {
+        if (out == (in + 2 * p - k) / s + 1) return true;
+        const int same = (in + s - 1) / s;
+        const int total = std::max((same - 1) * s + k - in, 0);
+        return out == same && p == total / 2;
+    };
+    if (!extent_ok(d->Ti, d->To, d->kT, d->sT, d->pT) || !extent_ok(d->Hi, d->Ho, d->kH, d->sH, d->pH) ||
+        !extent_ok(d->Wi, d->Wo, d->kW, d->sW, d->pW))
+        return fail(PTX_ERR_INVALID, "conv3d: output extent (%d,%d,%d) matches neither symmetric padding (%d,%d,%d) "
+                    "nor SAME geometry", d->To, d->Ho, d->Wo, d->pT, d->pH, d->pW);
     if ((int64_t)d->N * d->To * d->Ho * d->Wo > 0x7fffffffLL || (int64_t)d->N * d->Ti * d->Hi * d->Wi > 0x7fffffffLL)
         return fail(PTX_ERR_INVALID, "conv3d: more than 2^31 positions");
     if ((d->flags & PTX_EPI_RES_ADD) && (d->flags & PTX_EPI_RES_PADA))

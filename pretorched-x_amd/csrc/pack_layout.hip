@@ -2,6 +2,7 @@
 // All of these are HBM-bound byte movers: coalesced 16-byte accesses on the channels-last side,
 // LDS tile transposes where both sides cannot be contiguous at once.
 #include "ptx_common.h"
+#include <algorithm>
 
 namespace ptx {
 
@@ -345,7 +346,12 @@ static int check_fold_args(const void* x, const void* y, int N, int C, int T, in
     if (N <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || kW <= 0 || sW <= 0 || pW < 0 || Wo <= 0)
         return fail(PTX_ERR_INVALID, "fold_kw: non-positive extent");
     if (ld < kW * C || ld % 4) return fail(PTX_ERR_INVALID, "fold_kw: ld=%d must cover kW*C=%d and be a multiple of 4", ld, kW * C);
-    if (Wo != (W + 2 * pW - kW) / sW + 1) return fail(PTX_ERR_INVALID, "fold_kw: Wo mismatch");
+    {
+        const int same = (W + sW - 1) / sW;              // TF-"SAME": pW is the front pad floor(total/2)
+        const int total = std::max((same - 1) * sW + kW - W, 0);
+        if (Wo != (W + 2 * pW - kW) / sW + 1 && !(Wo == same && pW == total / 2))
+            return fail(PTX_ERR_INVALID, "fold_kw: Wo mismatch");
+    }
     if ((uintptr_t)y & 15) return fail(PTX_ERR_INVALID, "fold_kw: misaligned output");
     if (ld / 4 > 256 || (size_t)C * W * sizeof(float) > 64 * 1024)
         return fail(PTX_ERR_UNSUPPORTED, "fold_kw: row of %d x %d floats does not fit the LDS staging buffer", C, W);

@@ -114,6 +114,13 @@ def _t3(v):
     return (int(v),) * 3 if isinstance(v, int) else tuple(int(i) for i in v)
 
 
+def _same_geometry(dims, k, s):
+    """TF-"SAME" output extents and FRONT pads (the back pad is total - front; zeros either way)."""
+    out = tuple(-(-i // st) for i, st in zip(dims, s))
+    front = tuple(max((o - 1) * st + kk - i, 0) // 2 for o, st, kk, i in zip(out, s, k, dims))
+    return out, front
+
+
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
@@ -259,15 +266,23 @@ class Plan:
         return a
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
-             label="conv", y=None, x2=None, x2_stride=1):
+             label="conv", y=None, x2=None, x2_stride=1, same=False):
         kT, kH, kW = pk.k_eff
         sT, sH, sW = stride
+        if same:        # TF-"SAME": out = ceil(in/stride), `padding` is ignored, front pad = total // 2
+            (To, Ho, Wo), padding = _same_geometry((x.T, x.H, x.W), (kT, kH, kW), stride)
         pT, pH, pW = padding
-        To = (x.T + 2 * pT - kT) // sT + 1
-        Ho = (x.H + 2 * pH - kH) // sH + 1
-        Wo = (x.W + 2 * pW - kW) // sW + 1
+        if not same:
+            To = (x.T + 2 * pT - kT) // sT + 1
+            Ho = (x.H + 2 * pH - kH) // sH + 1
+            Wo = (x.W + 2 * pW - kW) // sW + 1
         if y is None:
             y = self.act(x.N, To, Ho, Wo, pk.Co)
+        if (y.N, y.T, y.H, y.W, y.C) != (x.N, To, Ho, Wo, pk.Co):
+            raise PtxError("%s: output target %s does not match the conv result %s" % (
+                label, (y.N, y.T, y.H, y.W, y.C), (x.N, To, Ho, Wo, pk.Co)))
+        if y.ld != _r4(pk.Co) and pk.Co % 4:
+            raise PtxError("%s: a channel-slice output needs Co %% 4 == 0" % label)
         flags = PTX_EPI_RELU if relu else 0
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
@@ -325,17 +340,25 @@ class Plan:
             return self.conv(mid, self.pack(conv.temporal_conv, bn), st_, pt, relu=relu, res=res,
                              res_kind=res_kind, res_stride=res_stride, label=label + ".temporal", y=y)
         k, s, p = _geom(conv)
+        same = bool(getattr(conv, "tf_same", False))       # I3D's Unit3D: explicit "SAME" padding
         fold = _foldable(conv, x)
         if fold:
-            x = self.fold_input(x, conv)
+            if same:    # the fold consumes the W axis with its own SAME front pad; T/H stay SAME in the conv
+                _, pf = _same_geometry((x.T, x.H, x.W), k, s)
+                x = self.fold_input(x, conv, same_pad=pf[2])
+            else:
+                x = self.fold_input(x, conv)
             s, p = (s[0], s[1], 1), (p[0], p[1], 0)
         return self.conv(x, self.pack(conv, bn, fold), s, p, relu=relu, res=res, res_kind=res_kind,
-                         res_stride=res_stride, label=label, y=y)
+                         res_stride=res_stride, label=label, y=y, same=same)
 
-    def fold_input(self, raw, conv):
-        """raw: RawInput (NCDHW user tensor).  Emits ptx_fold_kw_ncdhw."""
+    def fold_input(self, raw, conv, same_pad=None):
+        """raw: RawInput (NCDHW user tensor or uint8 frames).  Emits the fold kernel."""
         (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
-        Wo = (raw.W + 2 * pW - kW) // sW + 1
+        if same_pad is not None:
+            pW, Wo = same_pad, -(-raw.W // sW)
+        else:
+            Wo = (raw.W + 2 * pW - kW) // sW + 1
         ld = max(_r4(kW * raw.C), 24) if kW * raw.C <= 24 else _r4(kW * raw.C)
         # C = live folded columns (kW * Cin = 21 for the RGB stem); the kernel drops the MFMAs that
         # would only multiply the zero pad columns [C, ld)
@@ -370,7 +393,7 @@ class Plan:
         self.steps.append(step)
         return y
 
-    def maxpool(self, x, k, s, p, y=None, same=False):
+    def maxpool(self, x, k, s, p=None, y=None, same=False):
         """max_pool3d.  same=True: TF-"SAME" geometry (out = ceil(in/stride), front pad = total//2) with
         zero-valued padding -- F.pad followed by an unpadded MaxPool3d, as I3D ports do."""
         if same:
@@ -576,11 +599,81 @@ class Plan:
             return out if out is not None else model.head_module(pooled.clone())
         self.head = head
 
+    # ---------------------------------------------------------------- I3D (Inception-v1 3-D)
+    def _build_i3d(self, model):
+        N, Cin, T, H, W = self.shape
+        one = (1, 1, 1)
+
+        def unit(x, u, label, y=None):
+            conv = u.conv3d
+            k, s, _ = _geom(conv)
+            bn = u.bn if u.has_bn else None
+            if isinstance(x, RawInput):
+                return self.conv_bn(x, conv, bn, relu=True, label=label)
+            return self.conv(x, self.pack(conv, bn), s, (0, 0, 0), relu=u.has_bn, label=label, y=y, same=True)
+
+        raw = RawInput(N, Cin, T, H, W, norm=self.norm)
+        x = unit(raw, model.Conv3d_1a_7x7, "Conv3d_1a_7x7")
+        x = self.maxpool(x, (1, 3, 3), (1, 2, 2), None, same=True)
+        x = unit(x, model.Conv3d_2b_1x1, "Conv3d_2b_1x1")
+        x = unit(x, model.Conv3d_2c_3x3, "Conv3d_2c_3x3")
+        x = self.maxpool(x, (1, 3, 3), (1, 2, 2), None, same=True)
+        for entry in model.layout:
+            name = entry[0]
+            if name.startswith("pool"):
+                x = self.maxpool(x, entry[1], entry[2], None, same=True)
+                continue
+            m = getattr(model, name)
+            out = self.act(x.N, x.T, x.H, x.W, m.out_channels)
+            c1, c2, c3 = m.splits[0], m.splits[0] + m.splits[1], m.splits[0] + m.splits[1] + m.splits[2]
+            # the four branches write their channel slices of the module output: no torch.cat
+            unit(x, m.b0, name + ".b0", y=out.slice(0, m.splits[0]))
+            unit(unit(x, m.b1a, name + ".b1a"), m.b1b, name + ".b1b", y=out.slice(c1, m.splits[1]))
+            unit(unit(x, m.b2a, name + ".b2a"), m.b2b, name + ".b2b", y=out.slice(c2, m.splits[2]))
+            pooled = self.maxpool(x, (3, 3, 3), one, None, same=True)
+            unit(pooled, m.b3b, name + ".b3b", y=out.slice(c3, m.splits[3]))
+            x = out
+        self.feat = x
+        # head: avg_pool3d([2,7,7], stride 1) -> dropout (identity) -> 1x1x1 conv with bias -> squeeze ->
+        # mean over the remaining time steps
+        if (x.H, x.W) != (7, 7) or x.T < 2:
+            self.head = None
+            self.pooled = None
+            self.head_error = ("I3D head: AvgPool3d([2,7,7]) needs a [T>=2,7,7] Mixed_5c map (224x224 input, >=16 "
+                               "frames); got [%d,%d,%d]" % (x.T, x.H, x.W))
+            return
+        Tf, Cf = x.T, x.C
+        frame_mean = torch.empty((N * Tf, Cf), device=self.dev, dtype=torch.float32)
+        win = torch.empty((N * (Tf - 1), Cf), device=self.dev, dtype=torch.float32)
+        self.pooled = win
+        lib = self.lib
+
+        def head(engine, model):
+            st = _stream()
+            conv = model.head_module
+            if not isinstance(conv, nn.Conv3d):
+                raise PtxError("I3D: model.logits.conv3d must be a 1x1x1 Conv3d")
+            ncls = conv.out_channels
+            check(lib.ptx_global_avgpool(_ptr(x.t), _ptr(frame_mean), N * Tf, Cf, x.H * x.W, x.ld, 0, st),
+                  "ptx_global_avgpool")
+            check(lib.ptx_window_mean(_ptr(frame_mean), _ptr(win), N, Tf, Cf, 2, 1, st), "ptx_window_mean")
+            w = conv.weight.detach().reshape(ncls, Cf).contiguous()
+            b = conv.bias.detach().contiguous() if conv.bias is not None else None
+            per_frame = torch.empty((N * (Tf - 1), ncls), device=self.dev, dtype=torch.float32)
+            check(lib.ptx_linear_fwd(_ptr(win), _ptr(w), _ptr(b) if b is not None else C.c_void_p(0), _ptr(per_frame),
+                                     N * (Tf - 1), Cf, ncls, Cf, ncls, 0, st), "ptx_linear_fwd")
+            out = torch.empty((N, ncls), device=self.dev, dtype=torch.float32)
+            check(lib.ptx_window_mean(_ptr(per_frame), _ptr(out), N, Tf - 1, ncls, Tf - 1, 1, st), "ptx_window_mean")
+            return out
+        self.head = head
+
     # ---------------------------------------------------------------- running
     def run_head(self, engine, model):
         """feature map -> logits: the default global-average-pool + classifier, or the plan's own tail."""
         if self.head is not None:
             return self.head(engine, model)
+        if getattr(self, "head_error", None):
+            raise PtxError(self.head_error)
         f = self.feat
         check(self.lib.ptx_global_avgpool(_ptr(f.t), _ptr(self.pooled), f.N, f.C, f.S, f.ld, 0, _stream()),
               "ptx_global_avgpool")

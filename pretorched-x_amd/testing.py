@@ -20,6 +20,11 @@ LAST_BN_DAMP = 0.8
 NL_BN_DAMP = 0.2
 
 
+# I3D (Inception stacks, no residual paths): fan_in filters + mildly damped Unit3D BNs keep
+# max|logit| ~ 16 at 16x224x224 with an fp32 noise floor of ~6e-6 (calibrated in round 1)
+I3D_RECIPE = dict(unit_bn_damp=0.9, conv_fan="in")
+
+
 def _gen(seed, key):
     g = torch.Generator()
     g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
@@ -35,15 +40,18 @@ def _is_closing_bn(prefix, keys):
     return False
 
 
-def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=NL_BN_DAMP, inner_bn_damp=1.0):
+def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=NL_BN_DAMP, inner_bn_damp=1.0,
+                     unit_bn_damp=1.0, conv_fan="out"):
     """template: mapping key -> tensor (only shape/dtype are used). Returns an OrderedDict of
     fresh CPU fp32 tensors with the same keys/shapes.
 
     The damping factors scale BN gammas so that logits of deep random-weight networks stay in the
     calibrated 10-30 range (SURVEY.md 8d "re-calibrate per model"): `last_bn_damp` for the BN that
     closes a residual branch, `nl_bn_damp` for the non-local block's output BN (`W.1`),
-    `inner_bn_damp` for the BN inside a (2+1)D factored conv pair (`*.bn`).  Fixtures record the
-    values they were generated with."""
+    `inner_bn_damp` for the BN inside a (2+1)D factored conv pair (`*.bn`), `unit_bn_damp` for the BN
+    of an I3D Unit3D (`*.bn` next to `*.conv3d`).  `conv_fan`: 'out' = the reference's kaiming-normal
+    fan_out (resnet3D.py:198); 'in' = fan_in, for Inception stacks whose 1x1x1 reductions (192 -> 16)
+    would otherwise amplify 2*Cin/Cout per layer.  Fixtures record the values they were generated with."""
     keys = set(template.keys())
     out = OrderedDict()
     for key, ref in template.items():
@@ -59,6 +67,8 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
                 v = v * nl_bn_damp
             elif prefix.endswith(".bn") and (prefix[:-3] + ".spatial_conv.weight") in keys:
                 v = v * inner_bn_damp
+            elif prefix.endswith(".bn") and (prefix[:-3] + ".conv3d.weight") in keys:
+                v = v * unit_bn_damp
             elif _is_closing_bn(prefix, keys):
                 v = v * last_bn_damp
             out[key] = v
@@ -69,10 +79,10 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
         elif leaf == "running_var":
             out[key] = torch.rand(shape, generator=g) + 0.5
         elif leaf == "weight" and len(shape) >= 3:          # conv: kaiming-normal, fan_out
-            fan_out = shape[0]
+            fan = shape[0] if conv_fan == "out" else shape[1]
             for k in shape[2:]:
-                fan_out *= k
-            out[key] = torch.randn(shape, generator=g) * (2.0 / fan_out) ** 0.5
+                fan *= k
+            out[key] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
         elif leaf == "weight" and len(shape) == 2:          # linear
             bound = 1.0 / shape[1] ** 0.5
             out[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound

@@ -368,3 +368,29 @@ def test_forward_frames_fused_preprocessing(ptx):
     img = torch.randint(0, 256, (3, 96, 80, 3), dtype=torch.uint8, generator=g)
     clip3 = OF.transform_frames(img.unsqueeze(1), opts["mean"], opts["std"])[:, :, 0]
     _check(m2.forward_frames(img.to(DEV), opts), OF.forward(OF.ARCHS["resnet18"], sdr, clip3), "2-D uint8 frames")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 224, 224), (2, 3, 64, 224, 224)])
+def test_i3d_parity(ptx, shape):
+    """I3D (BASELINE.json config 4; 2 clips per GPU at 8 GPUs) against the stand-in CPU oracle
+    (**parity unpinned**: the reference snapshot has no I3D source)."""
+    from oracle import i3d_standin as I3
+    from pretorched_x_amd.testing import I3D_RECIPE
+    model = ptx.i3d(400)
+    sd = synth_state_dict(model.state_dict(), 1234, **I3D_RECIPE)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(99))
+    out = model(x.to(DEV))
+    feats = model.features(x.to(DEV))
+    torch.cuda.synchronize()
+    want = I3.forward(sd, x)
+    err = _check(out, want, "i3d logits vs oracle")
+    assert torch.equal(out.cpu().argmax(1), want.argmax(1))
+    _check(feats, I3.features(sd, x), "i3d Mixed_5c vs oracle")
+    print("i3d %s max|dlogits| = %.3e (max|logit| %.2f)" % (shape, err, want.abs().max().item()))
+    if shape[2] == 16:
+        with pytest.raises(Exception):
+            model(torch.zeros(1, 3, 16, 112, 112, device=DEV))      # AvgPool3d([2,7,7]) needs a 7x7 map
+        model.replace_logits(17)
+        assert tuple(model(x.to(DEV)).shape) == (2, 17)

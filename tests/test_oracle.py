@@ -223,3 +223,37 @@ def test_resnet18_standin_through_reference_wrapper():
     x = torch.randn(1, 3, 96, 96, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         assert torch.equal(OF.forward(OF.ARCHS["resnet18"], sd, x), model(x))
+
+
+def test_i3d_standin_and_plan(ptx):
+    """I3D (BASELINE.json config 4): no reference source exists in the snapshot, so the stand-in oracle
+    is **parity unpinned**; here: published shape facts, the port's state_dict key names, agreement
+    of the engine's dry plan with the oracle's geometry, and fp32 conditioning of the synthetic recipe."""
+    from oracle import i3d_standin as I3
+    from pretorched_x_amd.testing import I3D_RECIPE
+    m = ptx.i3d(400)
+    sd = synth_state_dict(m.state_dict(), 1234, **I3D_RECIPE)
+    n_params = sum(v.numel() for k, v in sd.items() if not k.endswith("num_batches_tracked") and "running" not in k)
+    assert abs(n_params - 12.7e6) < 0.1e6                       # ~12.3 M backbone + 0.41 M classifier
+    assert "Mixed_4f.b2b.conv3d.weight" in sd and "logits.conv3d.bias" in sd and "Conv3d_1a_7x7.bn.running_var" in sd
+    assert tuple(sd["Mixed_5c.b0.conv3d.weight"].shape) == (384, 832, 1, 1, 1)
+    x = torch.randn(1, 3, 16, 224, 224, generator=torch.Generator().manual_seed(99))
+    f = I3.features(sd, x)
+    assert tuple(f.shape) == (1, 1024, 2, 7, 7)
+    y = I3.forward(sd, x)
+    assert tuple(y.shape) == (1, 400) and 5 < y.abs().max().item() < 40
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    assert (y.double() - I3.forward(sd64, x.double())).abs().max().item() < 1e-4
+    plan = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
+    assert len(plan.conv_steps) == 57
+    assert (plan.feat.T, plan.feat.H, plan.feat.W, plan.feat.C) == (8, 7, 7, 1024)
+    gmac = sum(s.macs for s in plan.conv_steps) / 2 / 1e9
+    assert 105 < gmac < 115                                     # literature: ~108 G multiply-adds per 64x224x224 clip
+    stem = plan.conv_steps[0].d
+    assert (stem.To, stem.Ho, stem.Wo, stem.pT, stem.pH, stem.kT, stem.kH, stem.kW) == (32, 112, 112, 2, 2, 7, 7, 1)
+    # branch outputs are channel slices of the module output (no torch.cat)
+    lab = {s.label: s.d for s in plan.conv_steps}
+    assert (lab["Mixed_3b.b0"].ldy, lab["Mixed_3b.b1b"].ldy, lab["Mixed_3b.b3b"].ldy) == (256, 256, 256)
+    assert lab["Mixed_3b.b1a"].ldy == 96
+    with pytest.raises(ValueError):
+        ptx.i3d(pretrained="kinetics")
