@@ -214,6 +214,24 @@ int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C, int64_t S
 int ptx_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K,
                    int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream);
 
+/* TRN relation MLPs over frame subsets (trn.py:39-45 inside MultiScaleRelation.forward :101-110) without
+ * materialising the gathered inputs.  x: per-frame features [B][T][frame_len] (video stride ldx).
+ * A descriptor names n_sets frame subsets of n_frames frames each; output row r*B + b is
+ *   y[r*B + b][j] = act_out( sum_k act_in(concat_f x[b][idx[r][f]][:])[k] * w[j][k] + b[j] ),  K = n_frames*frame_len
+ * so the subsets that share one Relation's weights (same scale) run as ONE launch reading w once. */
+#define PTX_REL_MAX_SETS 8
+#define PTX_REL_MAX_FRAMES 16
+typedef struct ptx_relation_desc {
+    int32_t B, n_sets, n_frames, frame_len;
+    int32_t idx[PTX_REL_MAX_SETS][PTX_REL_MAX_FRAMES];
+} ptx_relation_desc;
+int ptx_relation_linear_fwd(const ptx_relation_desc* desc, const float* x, int32_t ldx, const float* w, const float* b,
+                            float* y, int32_t Nout, int32_t ldy, uint32_t flags, ptx_stream_t stream);
+/* Second Linear of those relations, summed over the subsets (trn.py:110 `stack(output).sum(0)`), by
+ * linearity:  y[b][j] (+)= sum_k (sum_r x[r*B + b][k]) * w[j][k] + n_sets * b[j]     (flags: EPI_ACCUM, EPI_RELU) */
+int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float* y, int32_t B, int32_t n_sets,
+                          int32_t K, int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * Non-local block pieces (nonlocalnet.py:143-166).
  * ------------------------------------------------------------------------------------------ */

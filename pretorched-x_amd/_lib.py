@@ -63,6 +63,13 @@ class NormDesc(C.Structure):
 
 
 PTX_POOL_SAME, PTX_POOL_PAD_ZERO = 1, 2
+PTX_REL_MAX_SETS, PTX_REL_MAX_FRAMES = 8, 16
+
+
+class RelationDesc(C.Structure):
+    """ptx_relation_desc: frame subsets of one TRN relation scale (reference trn.py:101-110)."""
+    _fields_ = [("B", C.c_int32), ("n_sets", C.c_int32), ("n_frames", C.c_int32), ("frame_len", C.c_int32),
+                ("idx", (C.c_int32 * PTX_REL_MAX_FRAMES) * PTX_REL_MAX_SETS)]
 
 
 _P = C.c_void_p
@@ -95,6 +102,8 @@ SIGNATURES = {
     "ptx_window_mean": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ptx_global_avgpool": (C.c_int, [_P, _P, _I, _I, _L, _I, _I, _P]),
     "ptx_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _U, _P]),
+    "ptx_relation_linear_fwd": (C.c_int, [C.POINTER(RelationDesc), _P, _I, _P, _P, _P, _I, _I, _U, _P]),
+    "ptx_linear_setsum_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P]),
     "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),
     "ptx_softmax_rows": (C.c_int, [_P, _L, _I, _I, _I, _P]),
     "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -203,6 +203,148 @@ __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// skinny GEMM (M <= 8 rows per pass, weight-bandwidth bound): a 256-thread workgroup owns FB = 4
+// output features and the whole K extent.  Every thread streams float4 chunks of the FB weight rows
+// (coalesced: consecutive lanes -> consecutive 16-byte pieces of a row) against the MR = 8 input rows
+// (L2 resident, shared by all workgroups), holding FB x MR partial sums; the 32 sums are combined
+// across the wave with a 32-shuffle reduce-scatter butterfly and across the 4 waves through LDS.
+// N/FB workgroups cover the chip with many 16-byte weight loads in flight per CU, which is what an
+// HBM-bound GEMV needs (the one-wave-per-feature kernel above reached 0.45 TB/s of weight traffic, this
+// one 1.5 TB/s; the remaining gap is L2 traffic of the input rows, re-read once per workgroup).
+//
+// Input modes (SkinnyArgs::mode):
+//   0 dense      x_eff[m][k] = x[m*ldx + k]
+//   1 gather     row m = r*B + b reads the frames idx[r][0..n_seg) of video b:  x[b*ldx + idx[r][k / F]*F + k % F]
+//   2 set-sum    x_eff[b][k] = sum_r x[(r*B + b)*ldx + k]           (bias is scaled by n_sets)
+// ---------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+    const float* x;
+    const float* w;
+    const float* b;
+    float* y;
+    int M, K, Nout, ldx, ldy;
+    unsigned flags;
+    int mode, B, n_sets, seg_len, n_seg;
+    float bias_scale;
+    int idx[PTX_REL_MAX_SETS][PTX_REL_MAX_FRAMES];
+};
+
+constexpr int kSkMR = 8;
+
+// FB features per workgroup, NT threads: long K -> 256 threads x 4 features; short K / few features ->
+// one-wave workgroups and 2 features, so that the grid still covers the chip.
+template <int kSkFB, int kSkNT>
+__global__ void __launch_bounds__(kSkNT) skinny_linear_kernel(const SkinnyArgs p, int row_tiles) {
+    __shared__ int sidx[PTX_REL_MAX_SETS * PTX_REL_MAX_FRAMES];
+    __shared__ float red[kSkNT / 64][kSkFB * kSkMR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = blockIdx.x % row_tiles;             // row tile fastest: neighbours share the weight rows in L2
+    const int j0 = (blockIdx.x / row_tiles) * kSkFB;
+    const int m0 = rt * kSkMR;
+    if (p.mode == 1) {
+        for (int i = tid; i < PTX_REL_MAX_SETS * PTX_REL_MAX_FRAMES; i += kSkNT)
+            sidx[i] = p.idx[i / PTX_REL_MAX_FRAMES][i % PTX_REL_MAX_FRAMES];
+        __syncthreads();
+    }
+    const bool relu_in = (p.flags & PTX_PRO_RELU) != 0;
+    // per-row base offsets (elements) and subset ids
+    int xoff[kSkMR], rset[kSkMR];
+    bool rok[kSkMR];
+#pragma unroll
+    for (int m = 0; m < kSkMR; ++m) {
+        const int row = m0 + m;
+        rok[m] = row < p.M;
+        const int rr = rok[m] ? row : 0;
+        if (p.mode == 1) {
+            rset[m] = rr / p.B;
+            xoff[m] = (rr % p.B) * p.ldx;
+        } else {
+            rset[m] = 0;
+            xoff[m] = rr * p.ldx;
+        }
+    }
+    const float* wr[kSkFB];
+#pragma unroll
+    for (int f = 0; f < kSkFB; ++f) wr[f] = p.w + (size_t)min(j0 + f, p.Nout - 1) * p.K;
+    float acc[kSkFB * kSkMR];
+#pragma unroll
+    for (int i = 0; i < kSkFB * kSkMR; ++i) acc[i] = 0.f;
+
+    const int seg_chunks = p.seg_len / 4;
+    const size_t set_stride = (size_t)p.B * p.ldx;
+    for (int seg = 0; seg < p.n_seg; ++seg) {
+        int foff[kSkMR];
+#pragma unroll
+        for (int m = 0; m < kSkMR; ++m)
+            foff[m] = xoff[m] + (p.mode == 1 ? sidx[rset[m] * PTX_REL_MAX_FRAMES + seg] * p.seg_len : seg * p.seg_len);
+        const int wcol = seg * p.seg_len;
+#pragma unroll 2
+        for (int c = tid; c < seg_chunks; c += kSkNT) {
+            const int k = c * 4;
+            f32x4 wv[kSkFB];
+#pragma unroll
+            for (int f = 0; f < kSkFB; ++f) wv[f] = *reinterpret_cast<const f32x4*>(wr[f] + wcol + k);
+#pragma unroll
+            for (int m = 0; m < kSkMR; ++m) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + foff[m] + k);
+                if (p.mode == 2)
+                    for (int r = 1; r < p.n_sets; ++r) xv += *reinterpret_cast<const f32x4*>(p.x + r * set_stride + foff[m] + k);
+                if (relu_in) {
+                    xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f);
+                    xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f);
+                }
+#pragma unroll
+                for (int f = 0; f < kSkFB; ++f) {
+                    float a = acc[f * kSkMR + m];
+                    a = fmaf(xv.x, wv[f].x, a);
+                    a = fmaf(xv.y, wv[f].y, a);
+                    a = fmaf(xv.z, wv[f].z, a);
+                    a = fmaf(xv.w, wv[f].w, a);
+                    acc[f * kSkMR + m] = a;
+                }
+            }
+        }
+    }
+    // reduce-scatter butterfly over NV = FB*MR values: after log2(NV) halving steps lane l holds the sum
+    // (over the lanes that differ from it in the exchanged bits) of value v(l); the remaining lane bits
+    // are folded with plain xor-shuffles
+    constexpr int NV = kSkFB * kSkMR;                 // 16 or 32
+    constexpr int STEPS = NV == 32 ? 5 : 4;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int half = (NV / 2) >> s, off = 32 >> s;
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = up ? acc[i] : acc[i + half];
+            const float keep = up ? acc[i + half] : acc[i];
+            acc[i] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+#pragma unroll
+    for (int off = (32 >> STEPS); off > 0; off >>= 1) acc[0] += __shfl_xor(acc[0], off, 64);
+    int v = 0;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) v += ((lane >> (5 - s)) & 1) * ((NV / 2) >> s);
+    if ((lane & ((64 >> STEPS) - 1)) == 0) red[wave][v] = acc[0];
+    __syncthreads();
+    if (tid < kSkFB * kSkMR) {
+        float sum = red[0][tid];
+#pragma unroll
+        for (int wv_ = 1; wv_ < kSkNT / 64; ++wv_) sum += red[wv_][tid];
+        const int f = tid / kSkMR, m = tid % kSkMR;
+        const int j = j0 + f, row = m0 + m;
+        if (j < p.Nout && row < p.M) {
+            float o = sum + (p.b ? p.bias_scale * p.b[j] : 0.f);
+            float* dst = p.y + (size_t)row * p.ldy + j;
+            if (p.flags & PTX_EPI_ACCUM) o += *dst;
+            if (p.flags & PTX_EPI_RELU) o = fmaxf(o, 0.f);
+            *dst = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // in-place row softmax (or 1/cols scaling): ONE WAVEFRONT PER ROW, the row held in registers,
 // max / sum reduced with wave shuffles only -- no LDS, no barrier (4 rows per workgroup).
 // ---------------------------------------------------------------------------------------------
@@ -359,10 +501,86 @@ extern "C" int ptx_global_avgpool(const float* x, float* y, int32_t N, int32_t C
     return hip_check(hipGetLastError(), "avgpool launch");
 }
 
+static int launch_skinny(SkinnyArgs& a, hipStream_t st) {
+    const int row_tiles = cdiv(a.M, kSkMR);
+    static int force_fb = -1, force_nt = -1;             // PTX_SKINNY="FB,NT": tuning switch
+    if (force_fb < 0) {
+        force_fb = force_nt = 0;
+        if (const char* e = getenv("PTX_SKINNY")) sscanf(e, "%d,%d", &force_fb, &force_nt);
+    }
+    // measured on MI355X (scripts/gpu_trn_micro.py): 2 features x 256 threads wins for every head-sized
+    // problem (1.5 TB/s of weight traffic at K = 16384; the L2 re-reads of the shared input rows bound it);
+    // with many row tiles one-wave workgroups give the scheduler more independent work
+    int nt = row_tiles >= 4 ? 64 : 256;
+    int fb = 2;
+    if (force_fb) fb = force_fb;
+    if (force_nt) nt = force_nt;
+    const long long blocks = (long long)row_tiles * cdiv(a.Nout, fb);
+    if (blocks > 0x7fffffffLL) return fail(PTX_ERR_UNSUPPORTED, "linear: grid too large");
+    const dim3 grid((unsigned)blocks);
+    if (fb == 4 && nt == 256) hipLaunchKernelGGL((skinny_linear_kernel<4, 256>), grid, dim3(256), 0, st, a, row_tiles);
+    else if (fb == 4) hipLaunchKernelGGL((skinny_linear_kernel<4, 64>), grid, dim3(64), 0, st, a, row_tiles);
+    else if (nt == 256) hipLaunchKernelGGL((skinny_linear_kernel<2, 256>), grid, dim3(256), 0, st, a, row_tiles);
+    else hipLaunchKernelGGL((skinny_linear_kernel<2, 64>), grid, dim3(64), 0, st, a, row_tiles);
+    return hip_check(hipGetLastError(), "linear launch");
+}
+
+extern "C" int ptx_relation_linear_fwd(const ptx_relation_desc* d, const float* x, int32_t ldx, const float* w,
+                                       const float* b, float* y, int32_t Nout, int32_t ldy, uint32_t flags,
+                                       ptx_stream_t stream) {
+    if (!d || !x || !w || !y) return fail(PTX_ERR_INVALID, "relation_linear: null pointer");
+    if (d->B <= 0 || d->n_sets <= 0 || d->n_sets > PTX_REL_MAX_SETS || d->n_frames <= 0 ||
+        d->n_frames > PTX_REL_MAX_FRAMES || d->frame_len <= 0 || d->frame_len % 4)
+        return fail(PTX_ERR_INVALID, "relation_linear: need 1..%d subsets of 1..%d frames, frame_len %% 4 == 0",
+                    PTX_REL_MAX_SETS, PTX_REL_MAX_FRAMES);
+    if (Nout <= 0 || ldy < Nout || ldx % 4) return fail(PTX_ERR_INVALID, "relation_linear: bad extents");
+    int max_idx = 0;
+    for (int r = 0; r < d->n_sets; ++r)
+        for (int f = 0; f < d->n_frames; ++f) {
+            if (d->idx[r][f] < 0) return fail(PTX_ERR_INVALID, "relation_linear: negative frame index");
+            max_idx = std::max(max_idx, (int)d->idx[r][f]);
+        }
+    if ((int64_t)(max_idx + 1) * d->frame_len > ldx)
+        return fail(PTX_ERR_INVALID, "relation_linear: frame index %d outside a video of %d floats", max_idx, ldx);
+    if (((uintptr_t)x | (uintptr_t)w) & 15) return fail(PTX_ERR_INVALID, "relation_linear: misaligned pointer");
+    if ((int64_t)d->B * ldx > 0x7fffffffLL) return fail(PTX_ERR_UNSUPPORTED, "relation_linear: input too large");
+    SkinnyArgs a{};
+    a.x = x; a.w = w; a.b = b; a.y = y;
+    a.M = d->n_sets * d->B; a.K = d->n_frames * d->frame_len; a.Nout = Nout; a.ldx = ldx; a.ldy = ldy;
+    a.flags = flags; a.mode = 1; a.B = d->B; a.n_sets = d->n_sets; a.seg_len = d->frame_len; a.n_seg = d->n_frames;
+    a.bias_scale = 1.f;
+    for (int r = 0; r < PTX_REL_MAX_SETS; ++r)
+        for (int f = 0; f < PTX_REL_MAX_FRAMES; ++f) a.idx[r][f] = d->idx[r][f];
+    return launch_skinny(a, (hipStream_t)stream);
+}
+
+extern "C" int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float* y, int32_t B,
+                                     int32_t n_sets, int32_t K, int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags,
+                                     ptx_stream_t stream) {
+    if (!x || !w || !y) return fail(PTX_ERR_INVALID, "linear_setsum: null pointer");
+    if (B <= 0 || n_sets <= 0 || K <= 0 || K % 4 || Nout <= 0 || ldx < K || ldx % 4 || ldy < Nout)
+        return fail(PTX_ERR_INVALID, "linear_setsum: bad extents (K and ldx must be multiples of 4)");
+    if (((uintptr_t)x | (uintptr_t)w) & 15) return fail(PTX_ERR_INVALID, "linear_setsum: misaligned pointer");
+    if ((int64_t)n_sets * B * ldx > 0x7fffffffLL) return fail(PTX_ERR_UNSUPPORTED, "linear_setsum: input too large");
+    SkinnyArgs a{};
+    a.x = x; a.w = w; a.b = b; a.y = y;
+    a.M = B; a.K = K; a.Nout = Nout; a.ldx = ldx; a.ldy = ldy;
+    a.flags = flags; a.mode = 2; a.B = B; a.n_sets = n_sets; a.seg_len = K; a.n_seg = 1;
+    a.bias_scale = (float)n_sets;
+    return launch_skinny(a, (hipStream_t)stream);
+}
+
 extern "C" int ptx_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K,
                               int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream) {
     if (!x || !w || !y) return fail(PTX_ERR_INVALID, "linear: null pointer");
     if (M <= 0 || K <= 0 || Nout <= 0 || ldx < K || ldy < Nout) return fail(PTX_ERR_INVALID, "linear: bad extents");
+    if (K % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0) && (int64_t)M * ldx <= 0x7fffffffLL) {
+        SkinnyArgs a{};
+        a.x = x; a.w = w; a.b = b; a.y = y;
+        a.M = M; a.K = K; a.Nout = Nout; a.ldx = ldx; a.ldy = ldy;
+        a.flags = flags; a.mode = 0; a.B = M; a.n_sets = 1; a.seg_len = K; a.n_seg = 1; a.bias_scale = 1.f;
+        return launch_skinny(a, (hipStream_t)stream);
+    }
     constexpr int MR = 8;
     if (cdiv(M, MR) > 65535) return fail(PTX_ERR_UNSUPPORTED, "linear: M too large for the small-M kernel");
     dim3 grid((unsigned)cdiv(Nout, 4), (unsigned)cdiv(M, MR));

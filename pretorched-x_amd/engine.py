@@ -1069,6 +1069,33 @@ def linear(x, lin, flags=0):
     return out.view(tuple(x.shape[:-1]) + (lin.out_features,))
 
 
+def relation_scale(x, subsets, lin1, lin2, out=None, accumulate=False):
+    """All frame subsets of ONE relation scale in two launches (reference trn.py:101-110 runs one MLP per
+    subset): launch 1 gathers the frames inside the kernel and reads W1 once for every subset, launch 2
+    applies W2 to the sum of the hidden vectors (linearity of `stack(output).sum(0)`) and accumulates
+    into `out`.  x: [B, T, F] fp32 CUDA; subsets: tuples of frame indices, all of one length."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise PtxError("relation_scale: input must be a float32 CUDA tensor (no CPU fallback)")
+    B, T, F_ = x.shape
+    d = _lib.RelationDesc()
+    d.B, d.n_sets, d.n_frames, d.frame_len = B, len(subsets), len(subsets[0]), F_
+    for r, sub in enumerate(subsets):
+        for f, i in enumerate(sub):
+            d.idx[r][f] = int(i)
+    lib = _lib.lib()
+    hid_n, out_n = lin1.out_features, lin2.out_features
+    with torch.cuda.device(x.device):
+        hid = torch.empty((len(subsets) * B, hid_n), device=x.device, dtype=torch.float32)
+        res = out if out is not None else torch.empty((B, out_n), device=x.device, dtype=torch.float32)
+        w1, b1 = lin1.weight.detach().contiguous(), lin1.bias.detach().contiguous()
+        w2, b2 = lin2.weight.detach().contiguous(), lin2.bias.detach().contiguous()
+        check(lib.ptx_relation_linear_fwd(C.byref(d), _ptr(x), T * F_, _ptr(w1), _ptr(b1), _ptr(hid), hid_n, hid_n,
+                                          PTX_PRO_RELU | PTX_EPI_RELU, _stream()), "relation.linear1")
+        check(lib.ptx_linear_setsum_fwd(_ptr(hid), _ptr(w2), _ptr(b2), _ptr(res), B, len(subsets), hid_n, out_n, hid_n,
+                                        out_n, PTX_EPI_ACCUM if accumulate else 0, _stream()), "relation.linear2")
+    return res
+
+
 def relation_mlp(flat, lin1, lin2, out=None, accumulate=False):
     if not flat.is_cuda or flat.dtype != torch.float32:
         raise PtxError("relation_mlp: input must be a float32 CUDA tensor (no CPU fallback)")

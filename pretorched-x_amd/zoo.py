@@ -266,15 +266,23 @@ class MultiScaleRelation(nn.Module):
 
     def forward(self, input):
         import numpy as np
-        from .engine import relation_mlp
+        from ._lib import PTX_REL_MAX_FRAMES, PTX_REL_MAX_SETS
+        from .engine import relation_mlp, relation_scale
+        x = input.contiguous().view(-1, self.num_input, self.in_features)        # [B, T, F]
+        grouped = (self.in_features % 4 == 0 and self.num_input <= PTX_REL_MAX_FRAMES
+                   and max(self.subsample_scales) <= PTX_REL_MAX_SETS)
         total = None
         for si in range(len(self.scales)):
             rel = self.relations[si]
             picks = np.random.choice(len(self.relations_scales[si]), self.subsample_scales[si], replace=False)
-            for idx in picks:
-                sub = input[..., self.relations_scales[si][idx], :]          # frame gather: plumbing
-                flat = sub.contiguous().view(-1, rel.num_inputs * rel.in_features)
-                # the sum over relations (trn.py:110) is fused into the second Linear's epilogue
+            subsets = [self.relations_scales[si][idx] for idx in picks]
+            if grouped:
+                # every subset of this scale in two launches: frames are gathered inside the kernel, W1 is
+                # read once, W2 acts on the summed hidden vectors (trn.py:110 by linearity)
+                total = relation_scale(x, subsets, rel.relate[1], rel.relate[3], out=total, accumulate=total is not None)
+                continue
+            for sub_idx in subsets:
+                flat = x[:, sub_idx, :].contiguous().view(-1, rel.num_inputs * rel.in_features)
                 total = relation_mlp(flat, rel.relate[1], rel.relate[3], out=total, accumulate=total is not None)
         return total.view(input.size(0), -1, self.out_features)
 

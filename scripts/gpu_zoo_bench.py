@@ -1,0 +1,66 @@
+"""Throughput of every model family behind the engine beyond the headline config (bench.py covers
+resnet3d50 / config 2): config 3 and its parents, SlowFast, I3D (config 4 share of one GPU), TRN, 2-D.
+Algorithmic FLOPs = 2 x the MACs of the compiled plan's conv launches (padding taps counted) + heads
+ignored; wall-clock with the queue drained on both sides.  Writes gpurun_out/zoo_bench.json."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import pretorched_x_amd as ptx  # noqa: E402
+from pretorched_x_amd.testing import I3D_RECIPE, synth_state_dict  # noqa: E402
+
+CASES = [
+    # name, builder, recipe, input shape, clips per step
+    ("nonlocal_r2plus1d50 (cfg3)", lambda: ptx.nonlocal_r2plus1d50(339), dict(inner_bn_damp=0.9, nl_bn_damp=0.05), (8, 3, 32, 112, 112)),
+    ("r2plus1d50", lambda: ptx.r2plus1d50(400), dict(inner_bn_damp=0.9), (8, 3, 32, 112, 112)),
+    ("nonlocalresnet3d50", lambda: ptx.nonlocalresnet3d50(pretrained=None), dict(last_bn_damp=0.65, nl_bn_damp=0.05), (8, 3, 32, 112, 112)),
+    ("slowfast resnet50 SF", lambda: ptx.slowfast.resnet50(num_classes=400), {}, (8, 3, 64, 224, 224)),
+    ("slowfast resnet50 S", lambda: ptx.slowfast.resnet50(mode="S", num_classes=400), {}, (8, 3, 64, 224, 224)),
+    ("slowfast resnet50 F", lambda: ptx.slowfast.resnet50(mode="F", num_classes=400), {}, (8, 3, 64, 224, 224)),
+    ("i3d (cfg4 per-GPU share)", lambda: ptx.i3d(400), I3D_RECIPE, (2, 3, 64, 224, 224)),
+    ("i3d batch 8", lambda: ptx.i3d(400), I3D_RECIPE, (8, 3, 64, 224, 224)),
+    ("resnet3d101", lambda: ptx.resnet3d101(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
+    ("resnet3d18", lambda: ptx.resnet3d18(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
+    ("resnet50 2-D", lambda: ptx.resnet50(num_classes=1000, pretrained=None), dict(last_bn_damp=0.7), (64, 3, 224, 224)),
+    ("TRN resnet50 x8 frames", lambda: ptx.TRN(339, num_segments=8, consensus="MSTRN", pretrained=None), dict(last_bn_damp=0.7), (8, 8, 3, 224, 224)),
+]
+only = sys.argv[1:]
+rows = []
+for name, build, recipe, shape in CASES:
+    if only and not any(o in name for o in only):
+        continue
+    torch.manual_seed(0)
+    m = build()
+    m.load_state_dict(synth_state_dict(m.state_dict(), 1234, **recipe))
+    m = m.cuda().eval()
+    x = torch.randn(*shape, device="cuda")
+    t0 = time.time()
+    y = m(x)                                  # compiles the plan and times untuned tile choices
+    torch.cuda.synchronize()
+    t_first = time.time() - t0
+    for _ in range(3):
+        m(x)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        y = m(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    eng = (m.base_model if hasattr(m, "base_model") else m).engine()
+    plans = list(eng._plans.values())
+    gflop = sum(2e-9 * s.macs for p in plans for s in p.conv_steps)
+    rows.append(dict(model=name, input=list(shape), ms_per_step=round(ms, 3), units_per_s=round(shape[0] * 1e3 / ms, 1),
+                     gflop_per_step=round(gflop, 1), tflops=round(gflop / ms, 1), frac_fp32_mfma=round(gflop / ms / 157.3, 3),
+                     conv_launches=sum(len(p.conv_steps) for p in plans), first_call_s=round(t_first, 1),
+                     finite=bool(torch.isfinite(y).all())))
+    print("%-28s %-22s %9.3f ms  %8.1f /s  %8.1f GFLOP  %6.1f TF (%4.1f%%)  launches %d  first call %.0f s" % (
+        name, "x".join(map(str, shape)), ms, shape[0] * 1e3 / ms, gflop, gflop / ms, gflop / ms / 1.573,
+        rows[-1]["conv_launches"], t_first), flush=True)
+    del m, x, y
+    torch.cuda.empty_cache()
+json.dump(dict(peak_tflops=157.3, note="clips (videos / images for TRN / 2-D) per second on one MI355X, fp32 MFMA; "
+               "FLOPs = 2 x MACs of the plan's conv launches", rows=rows), open("gpurun_out/zoo_bench.json", "w"), indent=1)

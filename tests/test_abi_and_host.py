@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(ptx):
             if not decl:
                 continue
             names = decl.replace("uint32_t", "").replace("int32_t", "").replace("float", "")
-            out += [re.sub(r"\[\d+\]", "", n).strip() for n in names.split(",") if n.strip()]
+            out += [re.sub(r"\[\w+\]", "", n).strip() for n in names.split(",") if n.strip()]
         return out
 
     assert fields_of("ptx_conv3d_desc") == [f for f, _ in L.ConvDesc._fields_]
@@ -47,6 +47,9 @@ def test_struct_layouts_match_header(ptx):
     assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
     assert C.sizeof(L.PoolDesc) == 4 * len(L.PoolDesc._fields_)
     assert C.sizeof(L.NormDesc) == 4 * 10
+    assert fields_of("ptx_relation_desc") == [f for f, _ in L.RelationDesc._fields_]
+    assert C.sizeof(L.RelationDesc) == 4 * (4 + L.PTX_REL_MAX_SETS * L.PTX_REL_MAX_FRAMES)
+    assert "#define PTX_REL_MAX_SETS %d" % L.PTX_REL_MAX_SETS in text and "#define PTX_REL_MAX_FRAMES %d" % L.PTX_REL_MAX_FRAMES in text
     nd = L.NormDesc.make([0.485, 0.456, 0.406], [0.229, 0.224, 0.225], "BGR", [0, 255])
     assert nd.swap_rb == 1 and nd.to_255 == 1 and abs(nd.std[2] - 0.225) < 1e-7 and nd.std[3] == 1.0
 

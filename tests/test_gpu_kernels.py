@@ -553,3 +553,52 @@ def test_maxpool_same_slices_copy_and_window_mean(ptx):
     close(z.cpu()[:, 0], x.mean(1), tol=1e-6)
     assert lib.ptx_window_mean(_p(xd), _p(z), 3, 8, 20, 9, 1, _st()) == 1
     assert lib.ptx_copy2d(_p(src), _p(dst), 7, 22, 24, 40, _st()) == 1
+
+
+def test_skinny_linear_gather_and_setsum(ptx):
+    """The weight-bandwidth-bound small-M GEMM (classifier heads, TRN MLPs): dense, in-kernel frame
+    gather (trn.py:104-108) and the set-summed second Linear (trn.py:110 by linearity)."""
+    L, lib = ptx._lib, _lib(ptx)
+    for (M, K, N, flags) in [(8, 2048, 339, 0), (3, 512, 10, L.PTX_EPI_RELU), (24, 1024, 64, L.PTX_PRO_RELU),
+                             (1, 16384, 1024, L.PTX_PRO_RELU | L.PTX_EPI_RELU), (13, 36, 7, 0), (5, 30, 9, 0)]:
+        x, w, b = rnd(M, K, seed=100), rnd(N, K, seed=101, scale=K ** -0.5), rnd(N, seed=102)
+        xi = F.relu(x) if flags & L.PTX_PRO_RELU else x
+        want = xi @ w.t() + b
+        want = F.relu(want) if flags & L.PTX_EPI_RELU else want
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        y = torch.full((M, N + 3), 5.0, device=DEV)
+        L.check(lib.ptx_linear_fwd(_p(xd), _p(wd), _p(bd), _p(y), M, K, N, K, N + 3, flags, _st()), "linear")
+        L.check(lib.ptx_linear_fwd(_p(xd), _p(wd), None, _p(y), M, K, N, K, N + 3, (flags & L.PTX_PRO_RELU) | L.PTX_EPI_ACCUM,
+                                   _st()), "linear accum")
+        torch.cuda.synchronize()
+        close(y[:, :N].cpu(), want + xi @ w.t(), tol=2e-5)
+        assert bool((y[:, N:] == 5.0).all())
+    # frame gather: 3 subsets of 4 frames out of 8, B = 5 videos
+    B, T, Fd, hid = 5, 8, 64, 48
+    x, w, b = rnd(B, T, Fd, seed=103), rnd(hid, 4 * Fd, seed=104, scale=0.06), rnd(hid, seed=105)
+    subsets = [(0, 2, 3, 7), (1, 2, 5, 6), (0, 1, 2, 3)]
+    d = L.RelationDesc()
+    d.B, d.n_sets, d.n_frames, d.frame_len = B, 3, 4, Fd
+    for r, sub in enumerate(subsets):
+        for f, i in enumerate(sub):
+            d.idx[r][f] = i
+    want = torch.cat([F.relu(F.relu(x[:, list(sub)].reshape(B, -1)) @ w.t() + b) for sub in subsets], 0)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    h = torch.empty(3 * B, hid, device=DEV)
+    L.check(lib.ptx_relation_linear_fwd(C.byref(d), _p(xd), T * Fd, _p(wd), _p(bd), _p(h), hid, hid,
+                                        L.PTX_PRO_RELU | L.PTX_EPI_RELU, _st()), "relation linear")
+    torch.cuda.synchronize()
+    close(h.cpu(), want, tol=2e-5)
+    # second Linear over the summed subsets == sum of per-subset Linears
+    w2, b2 = rnd(20, hid, seed=106, scale=0.1), rnd(20, seed=107)
+    want2 = sum(want[r * B:(r + 1) * B] @ w2.t() + b2 for r in range(3))
+    w2d, b2d = w2.to(DEV), b2.to(DEV)
+    out = torch.ones(B, 20, device=DEV)
+    L.check(lib.ptx_linear_setsum_fwd(_p(h), _p(w2d), _p(b2d), _p(out), B, 3, hid, 20, hid, 20, L.PTX_EPI_ACCUM, _st()),
+            "setsum")
+    torch.cuda.synchronize()
+    close(out.cpu(), want2 + 1.0, tol=2e-5)
+    d.idx[2][3] = 8                                             # frame outside the video
+    assert lib.ptx_relation_linear_fwd(C.byref(d), _p(xd), T * Fd, _p(wd), _p(bd), _p(h), hid, hid, 0, _st()) == 1
+    d.n_sets = 9
+    assert lib.ptx_relation_linear_fwd(C.byref(d), _p(xd), T * Fd, _p(wd), _p(bd), _p(h), hid, hid, 0, _st()) == 1
