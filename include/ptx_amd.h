@@ -43,6 +43,9 @@ typedef void* ptx_stream_t; /* hipStream_t */
 #define PTX_EPI_RES_ADD 2u   /* + residual, same shape as y   (resnet3D.py:141 `out += residual`) */
 #define PTX_EPI_RES_PADA 4u  /* + shortcut-A residual: strided subsample of `res`, zero channels
                                 above res_C              (resnet3D.py:65-74, nonlocalnet.py:322) */
+#define PTX_EPI_RES_UP 64u   /* with RES_PADA: the residual is nearest-UPsampled (index = out >> res_s*, res_s* =
+                                log2 factor) and channel-truncated (res_C >= Co): the BigGAN-deep GBlock
+                                skip `up(x[:, :out_channels])`                                            */
 #define PTX_PRO_RELU 8u      /* ptx_linear_fwd only: ReLU on the input while loading (trn.py:39-45) */
 #define PTX_EPI_ACCUM 16u    /* ptx_linear_fwd only: y += result (trn.py:110 stack(...).sum(0))   */
 
@@ -196,6 +199,22 @@ typedef struct ptx_pool3d_desc {
 } ptx_pool3d_desc;
 /* max_pool3d with -inf padding (resnet3D.py:156: MaxPool3d k3 s2 p1; slowfast.py:123 (1,3,3)) */
 int ptx_maxpool3d_fwd(const ptx_pool3d_desc* desc, const float* x, float* y, ptx_stream_t stream);
+/* Class-conditional BatchNorm folded to a per-sample affine (BigGAN `ccbn`: F.batch_norm with the stored
+ * statistics, then * (1 + gain(y)) + bias(y)):
+ *   scale[n][c] = m[n][c] / sqrt(var[c] + eps),  shift[n][c] = bias[n][c] - mean[c] * scale[n][c]
+ * with m = 1 + gain[n][c] (plus_one != 0) or gain[n][c] itself (plain BN: pass gamma with ld_gain = 0).
+ * gain / bias rows have stride ld_gain / ld_bias (0 = one row shared by every sample); scale / shift rows
+ * have stride ld_out. */
+int ptx_cbn_fold(const float* gain, const float* bias, const float* mean, const float* var, float eps,
+                 float* scale, float* shift, int32_t N, int32_t C, int32_t ld_gain, int32_t ld_bias,
+                 int32_t ld_out, int32_t plus_one, ptx_stream_t stream);
+/* y[n][h][w][c] = act(x[n][h/up][w/up][c] * scale[n][c] + shift[n][c]): the generator's
+ * cBN -> ReLU -> nearest-upsample stage in one HBM pass (x NHWC row stride ldx, y row stride ldy;
+ * scale/shift rows have stride ld_scale, so every cBN of the network can share one folded table).
+ * act: 0 none, 1 ReLU, 2 tanh (output layer).  scale/shift may be NULL (identity affine). */
+int ptx_affine_act_upsample(const float* x, float* y, const float* scale, const float* shift, int32_t ld_scale,
+                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, int32_t up,
+                            int32_t act, ptx_stream_t stream);
 /* y[r][0..cols) = x[r][0..cols) for r < rows (row strides ldx / ldy, all multiples of 4): places a
  * tensor into a channel slice of another -- torch.cat(dim=1) plumbing (slowfast.py:145, 395) */
 int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,

@@ -21,6 +21,7 @@ from . import _lib
 from ._lib import PtxError
 from .engine import Engine, relation_mlp
 from . import transforms  # noqa: F401
+from .biggan import BigGANDeepGenerator, biggan_deep  # noqa: F401
 from .i3d import InceptionI3d, i3d  # noqa: F401
 from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
 from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation,

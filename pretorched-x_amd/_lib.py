@@ -17,6 +17,7 @@ PTX_EPI_RES_ADD = 2
 PTX_EPI_RES_PADA = 4
 PTX_PRO_RELU = 8
 PTX_EPI_ACCUM = 16
+PTX_EPI_RES_UP = 64
 
 
 class PtxError(RuntimeError):
@@ -98,6 +99,8 @@ SIGNATURES = {
     "ptx_frames_u8_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
     "ptx_fold_kw_frames_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
     "ptx_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "ptx_cbn_fold": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ptx_affine_act_upsample": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ptx_copy2d": (C.c_int, [_P, _P, _L, _I, _L, _L, _P]),
     "ptx_window_mean": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ptx_global_avgpool": (C.c_int, [_P, _P, _I, _I, _L, _I, _I, _P]),

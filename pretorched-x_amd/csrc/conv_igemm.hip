@@ -101,15 +101,17 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     if (p.flags & PTX_EPI_RES_ADD) {
         v += p.res[(size_t)m * p.ldr + co];
     } else if (p.flags & PTX_EPI_RES_PADA) {
-        if (co < p.res_C) {
+        if (co < ((p.flags & PTX_EPI_RES_UP) ? p.Co : p.res_C)) {
             const int wo = m % p.Wo;
             int t = m / p.Wo;
             const int ho = t % p.Ho;
             t /= p.Ho;
             const int to = t % p.To;
             const int n = t / p.To;
-            const size_t pos = (((size_t)n * p.res_T + to * p.res_sT) * p.res_H + ho * p.res_sH) * p.res_W +
-                               wo * p.res_sW;
+            const bool up = (p.flags & PTX_EPI_RES_UP) != 0;
+            const int rt = up ? to >> p.res_sT : to * p.res_sT, rh = up ? ho >> p.res_sH : ho * p.res_sH,
+                      rw = up ? wo >> p.res_sW : wo * p.res_sW;
+            const size_t pos = (((size_t)n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw;
             v += p.res[pos * p.ldr + co];
         }
     }
@@ -589,6 +591,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const unsigned ldo = to_partial ? (unsigned)p.ncol : (unsigned)p.ldy;
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);
     const bool res_pada = !to_partial && (p.flags & PTX_EPI_RES_PADA);
+    const bool res_up = (p.flags & PTX_EPI_RES_UP) != 0;
     const bool relu = !to_partial && (p.flags & PTX_EPI_RELU);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -603,15 +606,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int r = 0; r < MF::NACC; ++r) {
                 const int m = mrow + MF::row(r, lane);
                 float v = acc[i][j][r] + bv + rv[i][j][r];
-                if (res_pada && co < p.res_C && m < p.M) {     // shortcut A (BasicBlock / NL nets only)
+                if (res_pada && co < (res_up ? p.Co : p.res_C) && m < p.M) {     // shortcut A (BasicBlock / NL nets only)
                     const int wo = m % p.Wo;
                     int t = m / p.Wo;
                     const int ho = t % p.Ho;
                     t /= p.Ho;
                     const int to = t % p.To;
                     const int n = t / p.To;
-                    const size_t pos = (((size_t)n * p.res_T + to * p.res_sT) * p.res_H + ho * p.res_sH) * p.res_W +
-                                       wo * p.res_sW;
+                    const int rt = res_up ? to >> p.res_sT : to * p.res_sT, rh = res_up ? ho >> p.res_sH : ho * p.res_sH,
+                              rw = res_up ? wo >> p.res_sW : wo * p.res_sW;
+                    const size_t pos = (((size_t)n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw;
                     v += p.res[pos * p.ldr + co];
                 }
                 v = relu ? fmaxf(v, 0.f) : v;
@@ -935,10 +939,20 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
         if (d->ldr < (d->Co + 3) / 4 * 4)
             return fail(PTX_ERR_INVALID, "conv3d: residual stride %d does not cover Co=%d", d->ldr, d->Co);
     }
+    if ((d->flags & PTX_EPI_RES_UP) && !(d->flags & PTX_EPI_RES_PADA))
+        return fail(PTX_ERR_INVALID, "conv3d: RES_UP modifies RES_PADA");
     if (d->flags & PTX_EPI_RES_PADA) {
-        if (d->res_C > d->ldr || d->res_C > d->Co || (d->To - 1) * d->res_sT >= d->res_T ||
-            (d->Ho - 1) * d->res_sH >= d->res_H || (d->Wo - 1) * d->res_sW >= d->res_W)
+        if (d->flags & PTX_EPI_RES_UP) {      // upsampled, channel-truncated skip: res has >= Co channels;
+                                              // res_s* hold log2 of the upsampling factor (0..4)
+            if (d->res_sT < 0 || d->res_sH < 0 || d->res_sW < 0 || d->res_sT > 4 || d->res_sH > 4 || d->res_sW > 4)
+                return fail(PTX_ERR_INVALID, "conv3d: RES_UP takes log2 factors 0..4 in res_s*");
+            if (d->res_C > d->ldr || d->res_C < d->Co || ((d->To - 1) >> d->res_sT) >= d->res_T ||
+                ((d->Ho - 1) >> d->res_sH) >= d->res_H || ((d->Wo - 1) >> d->res_sW) >= d->res_W)
+                return fail(PTX_ERR_INVALID, "conv3d: upsampled residual geometry out of range");
+        } else if (d->res_C > d->ldr || d->res_C > d->Co || (d->To - 1) * d->res_sT >= d->res_T ||
+                   (d->Ho - 1) * d->res_sH >= d->res_H || (d->Wo - 1) * d->res_sW >= d->res_W) {
             return fail(PTX_ERR_INVALID, "conv3d: shortcut-A residual geometry out of range");
+        }
     }
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.y = y;

@@ -399,6 +399,53 @@ __global__ void __launch_bounds__(256) copy2d_kernel(const float* __restrict__ x
     }
 }
 
+__global__ void __launch_bounds__(256) cbn_fold_kernel(const float* __restrict__ gain, const float* __restrict__ bias,
+                                                       const float* __restrict__ mean, const float* __restrict__ var,
+                                                       float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                       int N, int C, int ld_gain, int ld_bias, int ld_out,
+                                                       int plus_one) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float g = gain ? gain[(size_t)n * ld_gain + c] : 0.f;
+    const float m = plus_one ? 1.f + g : g;
+    const float s = m / sqrtf(var[c] + eps);
+    scale[(size_t)n * ld_out + c] = s;
+    shift[(size_t)n * ld_out + c] = (bias ? bias[(size_t)n * ld_bias + c] : 0.f) - mean[c] * s;
+}
+
+__global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int lds_,
+                                                                  size_t total4, int H, int W, int C, int ldx, int ldy,
+                                                                  int up, int relu) {
+    const int c4 = (C + 3) / 4;
+    const int Ho = H * up, Wo = W * up;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % c4);
+        size_t pos = i / c4;
+        const int wo = (int)(pos % Wo);
+        size_t r = pos / Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ho / up) * W + wo / up) * ldx + q * 4);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = q * 4 + e;
+            if (c < C) {
+                if (scale) o[e] = fmaf(o[e], scale[(size_t)n * lds_ + c], shift[(size_t)n * lds_ + c]);
+                if (relu == 1) o[e] = fmaxf(o[e], 0.f);
+                else if (relu == 2) o[e] = tanhf(o[e]);
+            } else {
+                o[e] = 0.f;
+            }
+        }
+        f32x4 w4 = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(y + pos * ldy + q * 4) = w4;
+    }
+}
+
 __global__ void __launch_bounds__(256) window_mean_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total,
                                                           int T, int To, int inner, int k, int stride) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -459,6 +506,36 @@ extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float
     const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (c4 / 4);
     hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, *d, x, y, total4);
     return hip_check(hipGetLastError(), "maxpool3d launch");
+}
+
+extern "C" int ptx_cbn_fold(const float* gain, const float* bias, const float* mean, const float* var, float eps,
+                            float* scale, float* shift, int32_t N, int32_t C, int32_t ld_gain, int32_t ld_bias,
+                            int32_t ld_out, int32_t plus_one, ptx_stream_t stream) {
+    if (!mean || !var || !scale || !shift) return fail(PTX_ERR_INVALID, "cbn_fold: null pointer");
+    if (N <= 0 || C <= 0 || ld_gain < 0 || ld_bias < 0 || ld_out < C || (gain && ld_gain != 0 && ld_gain < C) ||
+        (bias && ld_bias != 0 && ld_bias < C))
+        return fail(PTX_ERR_INVALID, "cbn_fold: bad extents");
+    if (!gain && !plus_one) return fail(PTX_ERR_INVALID, "cbn_fold: gain == NULL needs plus_one (scale 1)");
+    hipLaunchKernelGGL(cbn_fold_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, gain, bias,
+                       mean, var, eps, scale, shift, N, C, ld_gain, ld_bias, ld_out, plus_one);
+    return hip_check(hipGetLastError(), "cbn_fold launch");
+}
+
+extern "C" int ptx_affine_act_upsample(const float* x, float* y, const float* scale, const float* shift,
+                                       int32_t ld_scale, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                                       int32_t ldy, int32_t up, int32_t relu, ptx_stream_t stream) {
+    if (!x || !y || ((scale == nullptr) != (shift == nullptr)))
+        return fail(PTX_ERR_INVALID, "affine_act_upsample: null pointer (scale and shift go together)");
+    if (relu < 0 || relu > 2) return fail(PTX_ERR_INVALID, "affine_act_upsample: act must be 0, 1 or 2");
+    const int c4 = (C + 3) / 4 * 4;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || up < 1 || up > 8 || ldx < c4 || ldy < c4 || ldx % 4 || ldy % 4 ||
+        (scale && ld_scale < C))
+        return fail(PTX_ERR_INVALID, "affine_act_upsample: bad extents");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "affine_act_upsample: misaligned pointer");
+    const size_t total4 = (size_t)N * H * up * W * up * (c4 / 4);
+    hipLaunchKernelGGL(affine_act_upsample_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, scale,
+                       shift, ld_scale, total4, H, W, C, ldx, ldy, up, relu);
+    return hip_check(hipGetLastError(), "affine_act_upsample launch");
 }
 
 extern "C" int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,

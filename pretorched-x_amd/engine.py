@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
-                   PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
+                   PTX_EPI_RES_UP, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None
@@ -124,9 +124,10 @@ def _same_geometry(dims, k, s):
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
-    def __init__(self, dev, convs, bn, fold_kw=False):
+    def __init__(self, dev, convs, bn, fold_kw=False, scale=None):
         self.convs = list(convs)     # >1: concatenated along Co (non-local g/theta/phi)
         self.bn = bn
+        self.scale = scale           # scalar Parameter multiplying the filter (self-attention gamma)
         c0 = self.convs[0]
         (kT, kH, kW), _, _ = _geom(c0)
         self.Co = sum(c.out_channels for c in self.convs)
@@ -164,6 +165,11 @@ class Packed:
             keep += ts
             args = [_ptr(t) for t in ts]
             eps = float(bn.eps)
+        elif self.scale is not None:     # w * gamma through the BN-fold path: gamma / sqrt(1 + 0), beta = mean = 0
+            one = torch.ones(self.Co, device=w.device, dtype=torch.float32)
+            ts = [one * self.scale.detach().reshape(()), torch.zeros_like(one), torch.zeros_like(one), one]
+            keep += ts
+            args = [_ptr(t) for t in ts]
         check(_lib.lib().ptx_pack_conv_weight(C.byref(self.d), _ptr(w), _ptr(cb) if cb is not None else null,
                                               args[0], args[1], args[2], args[3], C.c_float(eps),
                                               _ptr(self.w), _ptr(self.b), _stream()), "ptx_pack_conv_weight")
@@ -221,6 +227,8 @@ class Plan:
         self.shape = tuple(shape)        # always the NCDHW / NCHW view of the input
         self.norm = norm                 # NormDesc when the input is uint8 frames (Engine.forward_frames)
         self.head = None                 # custom classifier tail (two-pathway / per-frame heads)
+        self.refreshers = []             # extra weight-derived tables rebuilt with the packed filters
+        self.in_ptr2 = C.c_void_p(0)     # second input (BigGAN: class embedding)
         self.lib = _lib.lib()
         self.steps = []          # callables(stream)
         self.conv_steps = []
@@ -242,12 +250,12 @@ class Plan:
                 self.ws_ptr = _ptr(self.ws)
 
     # ---------------------------------------------------------------- building blocks
-    def pack(self, convs, bn, fold_kw=False):
+    def pack(self, convs, bn, fold_kw=False, scale=None):
         if not isinstance(convs, (list, tuple)):
             convs = [convs]
-        key = (tuple(id(c) for c in convs), id(bn), fold_kw)
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw, id(scale))
         if key not in self._pack_cache:
-            p = Packed(self.dev, convs, bn, fold_kw)
+            p = Packed(self.dev, convs, bn, fold_kw, scale)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]
@@ -297,6 +305,10 @@ class Plan:
                 flags |= PTX_EPI_RES_PADA
                 d.res_C, d.res_T, d.res_H, d.res_W = res.C, res.T, res.H, res.W
                 d.res_sT = d.res_sH = d.res_sW = int(res_stride)
+            elif res_kind == "up":           # nearest-upsampled, channel-truncated skip; res_stride = log2 factors
+                flags |= PTX_EPI_RES_PADA | PTX_EPI_RES_UP
+                d.res_C, d.res_T, d.res_H, d.res_W = res.C, res.T, res.H, res.W
+                d.res_sT, d.res_sH, d.res_sW = _t3(res_stride)
             else:
                 flags |= PTX_EPI_RES_ADD
                 assert (res.N, res.T, res.H, res.W, res.C) == (y.N, y.T, y.H, y.W, y.C), "residual shape"
@@ -448,6 +460,8 @@ class Plan:
     # ---------------------------------------------------------------- network
     def _build(self, model):
         kind = getattr(model, "plan_kind", "resnet")
+        if kind == "biggan":
+            return self._build_biggan(model)
         if kind == "slowfast":
             return self._build_slowfast(model)
         if kind == "i3d":
@@ -667,6 +681,129 @@ class Plan:
             return out
         self.head = head
 
+    # ---------------------------------------------------------------- BigGAN-deep generator
+    def _build_biggan(self, model):
+        N = self.shape[0]
+        lib, dev = self.lib, self.dev
+        cond_dim, sdim, eps = model.cond_dim, model.shared_dim, float(model.bn_eps)
+        f32 = dict(device=dev, dtype=torch.float32)
+        cond = torch.empty((N, cond_dim), **f32)
+        # every conditional BN of the network, in execution order -> one [sum C] table
+        ccbns = []
+        for stage in model.blocks:
+            for blk in stage:
+                if blk.kind == "gblock":
+                    ccbns += [blk.bn1, blk.bn2, blk.bn3, blk.bn4]
+        offs, tot = {}, 0
+        for bn in ccbns:
+            offs[id(bn)] = tot
+            tot += bn.channels
+        wg, wb = torch.empty((tot, cond_dim), **f32), torch.empty((tot, cond_dim), **f32)
+        mean_all, var_all = torch.empty(tot, **f32), torch.empty(tot, **f32)
+        gain_all, bias_all = torch.empty((N, tot), **f32), torch.empty((N, tot), **f32)
+        scale_all, shift_all = torch.empty((N, tot), **f32), torch.empty((N, tot), **f32)
+        obn = model.output_layer[0]
+        oscale, oshift = torch.empty((N, obn.channels), **f32), torch.empty((N, obn.channels), **f32)
+        bw = model.bottom_width
+        c0 = model.linear.out_features // (bw * bw)
+        w0, b0 = torch.empty((bw * bw * c0, cond_dim), **f32), torch.empty(bw * bw * c0, **f32)
+        self.keepalive += [cond, wg, wb, mean_all, var_all, gain_all, bias_all, scale_all, shift_all, oscale, oshift, w0, b0]
+
+        def refresh_tables():
+            # weight relayout only (concatenation / row permutation), rebuilt when a parameter changes
+            for bn in ccbns:
+                o, c = offs[id(bn)], bn.channels
+                wg[o:o + c].copy_(bn.gain.weight.detach())
+                wb[o:o + c].copy_(bn.bias.weight.detach())
+                mean_all[o:o + c].copy_(bn.stored_mean)
+                var_all[o:o + c].copy_(bn.stored_var)
+            # first Linear emits NCHW-ordered features (c, h, w); permute its rows so it writes NHWC directly
+            w0.copy_(model.linear.weight.detach().view(c0, bw, bw, cond_dim).permute(1, 2, 0, 3).reshape(-1, cond_dim))
+            b0.copy_(model.linear.bias.detach().view(c0, bw, bw).permute(1, 2, 0).reshape(-1))
+        if torch.device(dev).type != "meta":
+            self.refreshers.append(refresh_tables)
+
+        def prologue(st, self=self):
+            # y = cat([shared(labels), z], 1); all cBN gains/biases in two GEMVs; fold with the stored statistics
+            check(lib.ptx_copy2d(self.in_ptr2, _ptr(cond), N, sdim, sdim, cond_dim, st), "cond.y")
+            check(lib.ptx_copy2d(self.in_ptr, _ptr(cond, sdim), N, cond_dim - sdim, cond_dim - sdim, cond_dim, st), "cond.z")
+            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(wg), None, _ptr(gain_all), N, cond_dim, tot, cond_dim, tot, 0, st), "cbn.gain")
+            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(wb), None, _ptr(bias_all), N, cond_dim, tot, cond_dim, tot, 0, st), "cbn.bias")
+            check(lib.ptx_cbn_fold(_ptr(gain_all), _ptr(bias_all), _ptr(mean_all), _ptr(var_all), C.c_float(eps),
+                                   _ptr(scale_all), _ptr(shift_all), N, tot, tot, tot, tot, 1, st), "cbn.fold")
+            check(lib.ptx_cbn_fold(_ptr(obn.gain.detach()), _ptr(obn.bias.detach()), _ptr(obn.stored_mean),
+                                   _ptr(obn.stored_var), C.c_float(eps), _ptr(oscale), _ptr(oshift), N, obn.channels, 0, 0,
+                                   obn.channels, 0, st), "bn.fold")
+        self.steps.append(prologue)
+
+        h = self.act(N, 1, bw, bw, c0)
+
+        def first_linear(st, hp=_ptr(h.t)):
+            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(w0), _ptr(b0), hp, N, cond_dim, bw * bw * c0, cond_dim, bw * bw * c0,
+                                     0, st), "linear")
+        self.steps.append(first_linear)
+
+        def affine(x, sc, sh, ld_s, up, act=1):
+            y = self.act(N, 1, x.H * up, x.W * up, x.C)
+            xp, yp, H_, W_, C_, ldx, ldy = _ptr(x.t), _ptr(y.t), x.H, x.W, x.C, x.ld, y.ld
+
+            def step(st):
+                check(lib.ptx_affine_act_upsample(xp, yp, sc, sh, ld_s, N, H_, W_, C_, ldx, ldy, up, act, st),
+                      "ptx_affine_act_upsample")
+            self.steps.append(step)
+            return y
+
+        def cbn(x, bn, up=1):
+            o = offs[id(bn)]
+            return affine(x, _ptr(scale_all, o), _ptr(shift_all, o), tot, up)
+
+        one, zero = (1, 1, 1), (0, 0, 0)
+        for si, stage in enumerate(model.blocks):
+            for bi, blk in enumerate(stage):
+                name = "blocks.%d.%d" % (si, bi)
+                if blk.kind == "gblock":
+                    up = 2 if blk.upsample else 1
+                    t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None), one, zero, label=name + ".conv1")
+                    t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None), one, (0, 1, 1), label=name + ".conv2")
+                    t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None), one, (0, 1, 1), label=name + ".conv3")
+                    if up == 1 and blk.in_channels == blk.out_channels:
+                        h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, label=name + ".conv4")
+                    else:   # skip = upsample(x[:, :Cout]) gathered in the epilogue
+                        h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, res_kind="up",
+                                      res_stride=(0, up // 2, up // 2), label=name + ".conv4")
+                else:
+                    h = self._biggan_attention(h, blk, name)
+        a = affine(h, _ptr(oscale), _ptr(oshift), obn.channels, 1)
+        img = self.conv(a, self.pack(model.output_layer[2], None), one, (0, 1, 1), label="output_layer.2")
+        self.feat = affine(img, None, None, 0, 1, act=2)            # tanh
+        self.pooled = None
+
+    def _biggan_attention(self, x, att, name):
+        """layers.Attention: theta^T phi over 2x2-max-pooled keys, softmax, values g, output conv * gamma + x."""
+        lib = self.lib
+        N, HW = x.N, x.H * x.W
+        c8, c2 = att.ch // 8, att.ch // 2
+        one, zero = (1, 1, 1), (0, 0, 0)
+        tpg = self.conv(x, self.pack([att.theta, att.phi, att.g], None), one, zero, label=name + ".theta_phi_g")
+        phi = self.maxpool(tpg.slice(c8, c8), (1, 2, 2), (1, 2, 2), (0, 0, 0))
+        g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
+        S4 = HW // 4
+        ldf = _r4(S4)
+        f = torch.empty((N, HW, ldf), device=self.dev, dtype=torch.float32)
+        gT = torch.empty((N, c2, ldf), device=self.dev, dtype=torch.float32)
+        yatt = self.act(N, 1, x.H, x.W, c2)
+        self.keepalive += [f, gT]
+        th, ph, gp, fp, gtp, yp = _ptr(tpg.t), _ptr(phi.t), _ptr(g.t), _ptr(f), _ptr(gT), _ptr(yatt.t)
+        ld3, ldp, ldg, yld = tpg.ld, phi.ld, g.ld, yatt.ld
+
+        def step(st):
+            check(lib.ptx_bgemm_nt(th, ph, fp, N, HW, S4, c8, ld3, ldp, ldf, HW * ld3, S4 * ldp, HW * ldf, st), "attn f")
+            check(lib.ptx_softmax_rows(fp, N * HW, S4, ldf, 0, st), "attn softmax")
+            check(lib.ptx_transpose_last2(gp, gtp, N, S4, c2, ldg, ldf, st), "attn g^T")
+            check(lib.ptx_bgemm_nt(fp, gtp, yp, N, HW, c2, S4, ldf, ldf, yld, HW * ldf, c2 * ldf, HW * yld, st), "attn y")
+        self.steps.append(step)
+        return self.conv(yatt, self.pack(att.o, None, scale=att.gamma), one, zero, res=x, label=name + ".o")
+
     # ---------------------------------------------------------------- running
     def run_head(self, engine, model):
         """feature map -> logits: the default global-average-pool + classifier, or the plan's own tail."""
@@ -686,6 +823,8 @@ class Plan:
         keep = []
         for p in self.packs:
             keep.append(p.refresh())
+        for fn in self.refreshers:
+            fn()
         return keep
 
     def run_features(self, x):
@@ -903,6 +1042,36 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------
+    def generate(self, model, z, y):
+        """BigGAN-deep generator: z [B,dim_z], y [B,shared_dim] (= model.shared(labels)) -> images [B,3,R,R]."""
+        if model.training:
+            raise PtxError("pretorched-x_amd is a forward-only (inference) engine: call model.eval() first")
+        for t, d, nm in ((z, model.dim_z, "z"), (y, model.shared_dim, "y")):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+                raise PtxError("generate: %s must be a float32 CUDA tensor (no CPU fallback)" % nm)
+            if t.dim() != 2 or t.shape[1] != d:
+                raise PtxError("generate: %s must be [B, %d], got %s" % (nm, d, tuple(t.shape)))
+        if z.shape[0] != y.shape[0] or z.device != y.device:
+            raise PtxError("generate: z and y must share batch size and device")
+        z, y = z.contiguous(), y.contiguous()
+        N = z.shape[0]
+        key = ("maxb", ("biggan",), id(model))
+        with self._lock:
+            mb = self._sig.get(key)
+            if mb is None:
+                one = Plan(self, model, (1, model.dim_z), torch.device("meta"))
+                mb = self._sig[key] = max(1, int(self.LIMIT_BYTES // max(a.t.numel() * 4 for a in one.acts)))
+        if N > mb:
+            return torch.cat([self.generate(model, z[i:i + mb], y[i:i + mb]) for i in range(0, N, mb)], 0)
+        with torch.cuda.device(z.device):
+            plan = self.plan_for(model, z)
+            plan.in_ptr2 = _ptr(y)
+            self._maybe_tune(model, plan, z)
+            f = plan.run_features(z)
+            out = torch.empty((N, 3, f.H, f.W), device=z.device, dtype=torch.float32)
+            check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), N, 3, f.H * f.W, f.ld, _stream()), "ptx_ndhwc_to_ncdhw")
+        return out
+
     def forward_frames(self, model, frames, opts=None):
         """Decoded uint8 frames [N,T,H,W,C] (NHWC for 2-D models) -> logits.  The tensor half of the
         reference's TransformImage (ToTensor, ToSpaceBGR, ToRange255, Normalize; transforms/utils.py:72-75)

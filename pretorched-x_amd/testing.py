@@ -25,6 +25,11 @@ NL_BN_DAMP = 0.2
 I3D_RECIPE = dict(unit_bn_damp=0.9, conv_fan="in")
 
 
+# BigGAN-deep generator (pre-activation residual stack, no BN after the closing convs): fan_in filters,
+# closing convs x0.2 -> pre-tanh std ~0.9, max ~4 at 256x256, fp32 noise floor ~4e-6
+BIGGAN_RECIPE = dict(conv_fan="in", closing_conv_damp=0.2)
+
+
 def _gen(seed, key):
     g = torch.Generator()
     g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
@@ -41,7 +46,7 @@ def _is_closing_bn(prefix, keys):
 
 
 def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=NL_BN_DAMP, inner_bn_damp=1.0,
-                     unit_bn_damp=1.0, conv_fan="out"):
+                     unit_bn_damp=1.0, conv_fan="out", closing_conv_damp=1.0):
     """template: mapping key -> tensor (only shape/dtype are used). Returns an OrderedDict of
     fresh CPU fp32 tensors with the same keys/shapes.
 
@@ -51,7 +56,8 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
     `inner_bn_damp` for the BN inside a (2+1)D factored conv pair (`*.bn`), `unit_bn_damp` for the BN
     of an I3D Unit3D (`*.bn` next to `*.conv3d`).  `conv_fan`: 'out' = the reference's kaiming-normal
     fan_out (resnet3D.py:198); 'in' = fan_in, for Inception stacks whose 1x1x1 reductions (192 -> 16)
-    would otherwise amplify 2*Cin/Cout per layer.  Fixtures record the values they were generated with."""
+    would otherwise amplify 2*Cin/Cout per layer; `closing_conv_damp` scales the filters
+    that close a BigGAN-deep residual branch (`conv4`, attention `o`), which has no BN after them.  Fixtures record the values they were generated with."""
     keys = set(template.keys())
     out = OrderedDict()
     for key, ref in template.items():
@@ -74,15 +80,21 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
             out[key] = v
         elif is_bn and leaf == "bias":
             out[key] = torch.randn(shape, generator=g) * 0.1
-        elif leaf == "running_mean":
+        elif leaf in ("running_mean", "stored_mean"):
             out[key] = torch.randn(shape, generator=g) * 0.1
-        elif leaf == "running_var":
+        elif leaf in ("running_var", "stored_var"):
             out[key] = torch.rand(shape, generator=g) + 0.5
+        elif leaf == "gain":                                # BigGAN's plain output BN: gamma
+            out[key] = torch.rand(shape, generator=g) + 0.5
+        elif leaf == "gamma":                               # attention mixing scalar (init 0 upstream)
+            out[key] = torch.full(shape, 0.5)
         elif leaf == "weight" and len(shape) >= 3:          # conv: kaiming-normal, fan_out
             fan = shape[0] if conv_fan == "out" else shape[1]
             for k in shape[2:]:
                 fan *= k
             out[key] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
+            if prefix.endswith(".conv4") or prefix.endswith(".o"):      # closes a BigGAN residual / attention branch
+                out[key] = out[key] * closing_conv_damp
         elif leaf == "weight" and len(shape) == 2:          # linear
             bound = 1.0 / shape[1] ** 0.5
             out[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound

@@ -602,3 +602,65 @@ def test_skinny_linear_gather_and_setsum(ptx):
     assert lib.ptx_relation_linear_fwd(C.byref(d), _p(xd), T * Fd, _p(wd), _p(bd), _p(h), hid, hid, 0, _st()) == 1
     d.n_sets = 9
     assert lib.ptx_relation_linear_fwd(C.byref(d), _p(xd), T * Fd, _p(wd), _p(bd), _p(h), hid, hid, 0, _st()) == 1
+
+
+def test_cbn_fold_affine_upsample_and_upsampled_skip(ptx):
+    """Generator-stage kernels: class-conditional BN folded to a per-sample affine, cBN+ReLU+nearest
+    upsample in one pass, tanh, and the GBlock skip `upsample(x[:, :Cout])` as a conv-epilogue gather."""
+    L, lib = ptx._lib, _lib(ptx)
+    N, H, W, Cc, tot, off = 3, 5, 6, 10, 32, 12
+    x = rnd(N, Cc, 1, H, W, seed=110)
+    gain, bias = rnd(N, tot, seed=111, scale=0.3), rnd(N, tot, seed=112, scale=0.3)
+    mean, var = rnd(tot, seed=113, scale=0.2), torch.rand(tot, generator=torch.Generator().manual_seed(114)) + 0.5
+    gd, bd, md, vd = gain.to(DEV), bias.to(DEV), mean.to(DEV), var.to(DEV)
+    sc, sh = torch.empty(N, tot, device=DEV), torch.empty(N, tot, device=DEV)
+    L.check(lib.ptx_cbn_fold(_p(gd), _p(bd), _p(md), _p(vd), C.c_float(1e-5), _p(sc), _p(sh), N, tot, tot, tot, tot, 1, _st()), "fold")
+    xd = to_cl(x)
+    for up, act in ((1, 1), (2, 1), (2, 0), (1, 2)):
+        y = torch.full((N, 1, H * up, W * up, xd.shape[-1]), float("nan"), device=DEV)
+        L.check(lib.ptx_affine_act_upsample(_p(xd), _p(y), _p(sc, off), _p(sh, off), tot, N, H, W, Cc, xd.shape[-1],
+                                            y.shape[-1], up, act, _st()), "affine")
+        torch.cuda.synchronize()
+        g_, b_ = gain[:, off:off + Cc], bias[:, off:off + Cc]
+        ref = F.batch_norm(x[:, :, 0], mean[off:off + Cc], var[off:off + Cc], None, None, False, 0.1, 1e-5)
+        ref = ref * (1 + g_)[:, :, None, None] + b_[:, :, None, None]
+        ref = F.relu(ref) if act == 1 else (torch.tanh(ref) if act == 2 else ref)
+        ref = F.interpolate(ref, scale_factor=up) if up > 1 else ref
+        close(from_cl(y, Cc)[:, :, 0], ref, tol=1e-5)
+        assert bool((y[..., Cc:] == 0).all())
+    # plain BN (gamma/beta shared by all samples): gain row stride 0, no "+1"
+    gam, bet = rnd(Cc, seed=115) + 2, rnd(Cc, seed=116)
+    gmd, btd = gam.to(DEV), bet.to(DEV)
+    s2, h2 = torch.empty(N, Cc, device=DEV), torch.empty(N, Cc, device=DEV)
+    L.check(lib.ptx_cbn_fold(_p(gmd), _p(btd), _p(md), _p(vd), C.c_float(1e-5), _p(s2), _p(h2), N, Cc, 0, 0, Cc, 0, _st()), "bn fold")
+    y = torch.empty(N, 1, H, W, xd.shape[-1], device=DEV)
+    L.check(lib.ptx_affine_act_upsample(_p(xd), _p(y), _p(s2), _p(h2), Cc, N, H, W, Cc, xd.shape[-1], y.shape[-1], 1, 0, _st()), "bn")
+    torch.cuda.synchronize()
+    close(from_cl(y, Cc)[:, :, 0], F.batch_norm(x[:, :, 0], mean[:Cc], var[:Cc], gam, bet, False, 0.1, 1e-5), tol=1e-5)
+    # 1x1 conv at 2x resolution + upsampled, channel-truncated skip
+    Ci, Co, Cs = 8, 12, 20
+    a, w, b = rnd(N, Ci, 1, 2 * H, 2 * W, seed=117), rnd(Co, Ci, 1, 1, 1, seed=118, scale=0.3), rnd(Co, seed=119)
+    skip = rnd(N, Cs, 1, H, W, seed=120)
+    want = F.conv3d(a, w, b) + F.interpolate(skip[:, :Co, 0], scale_factor=2)[:, :, None]
+    pd = L.PackDesc(Co, Ci, 1, 1, 1, Ci, 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(128, device=DEV)
+    wd, bdv = w.to(DEV), b.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bdv), None, None, None, None, C.c_float(0), _p(wp), _p(bp), _st()), "pack")
+    ad, sd_ = to_cl(a), to_cl(skip)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, 2 * H, 2 * W, Ci, Ci
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, 2 * H, 2 * W, Co, Co
+    d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+    d.Kc, d.Co_pad = Ci, 128
+    d.flags = L.PTX_EPI_RES_PADA | L.PTX_EPI_RES_UP
+    d.ldr, d.res_C, d.res_T, d.res_H, d.res_W, d.res_sT, d.res_sH, d.res_sW = Cs, Cs, 1, H, W, 0, 1, 1
+    ws = torch.empty(4 * N * 4 * H * W * Co, device=DEV)
+    for cfg, split in ((-1, 0), (28, 1), (30, 2)):
+        yd = torch.full((N, 1, 2 * H, 2 * W, Co), float("nan"), device=DEV)
+        L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(ad), _p(wp), _p(bp), _p(sd_), _p(yd), _p(ws), ws.numel() * 4, cfg, split,
+                                   _st()), "conv up-skip")
+        torch.cuda.synchronize()
+        close(from_cl(yd, Co), want)
+    d.res_sH = 5
+    assert lib.ptx_conv3d_fwd(C.byref(d), _p(ad), _p(wp), _p(bp), _p(sd_), _p(yd), None, 0, -1, 1, _st()) == 1

@@ -394,3 +394,28 @@ def test_i3d_parity(ptx, shape):
             model(torch.zeros(1, 3, 16, 112, 112, device=DEV))      # AvgPool3d([2,7,7]) needs a 7x7 map
         model.replace_logits(17)
         assert tuple(model(x.to(DEV)).shape) == (2, 17)
+
+
+@pytest.mark.parametrize("res,ch,batch", [(256, 128, 3), (128, 32, 4), (32, 16, 5)])
+def test_biggan_generator_parity(ptx, res, ch, batch):
+    """BigGAN-deep generator (BASELINE.json config 5, fp32 path) against the stand-in CPU oracle
+    (**parity unpinned**: the reference snapshot has no BigGAN source)."""
+    from oracle import biggan_standin as BG
+    from pretorched_x_amd.testing import BIGGAN_RECIPE
+    G = ptx.biggan_deep(res, ch=ch)
+    sd = synth_state_dict(G.state_dict(), 1234, **BIGGAN_RECIPE)
+    G.load_state_dict(sd)
+    G = G.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(batch, 128, generator=g)
+    lab = torch.randint(0, 1000, (batch,), generator=g)
+    img = G(z.to(DEV), G.shared(lab.to(DEV)))
+    torch.cuda.synchronize()
+    want = BG.forward(sd, z, sd["shared.weight"][lab])
+    assert tuple(img.shape) == (batch, 3, res, res)
+    err = (img.cpu() - want).abs().max().item()
+    assert err <= 1e-3, "max abs err %.3e" % err
+    assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))     # deterministic
+    print("biggan-deep-%d max|d image| = %.3e (pre-tanh range ~%.1f)" % (res, err, BG.pre_tanh(sd, z, sd["shared.weight"][lab]).abs().max().item()))
+    with pytest.raises(Exception):
+        G(z, G.shared(lab.to(DEV)).cpu())                            # CPU tensors: no fallback

@@ -257,3 +257,40 @@ def test_i3d_standin_and_plan(ptx):
     assert lab["Mixed_3b.b1a"].ldy == 96
     with pytest.raises(ValueError):
         ptx.i3d(pretrained="kinetics")
+
+
+def test_biggan_standin_and_plan(ptx):
+    """BigGAN-deep-256 generator (BASELINE.json config 5): no reference source exists in the snapshot, so
+    the stand-in oracle is **parity unpinned**; here: published shape facts, the authors' state_dict key
+    names, the engine's dry plan, and fp32 conditioning of the synthetic recipe."""
+    from oracle import biggan_standin as BG
+    from pretorched_x_amd.testing import BIGGAN_RECIPE
+    G = ptx.biggan_deep(256)
+    sd = synth_state_dict(G.state_dict(), 1234, **BIGGAN_RECIPE)
+    assert abs(sum(p.numel() for p in G.parameters()) - 55.7e6) < 0.3e6
+    for k, shp in (("shared.weight", (1000, 128)), ("linear.weight", (4 * 4 * 16 * 128, 256)),
+                   ("blocks.0.0.conv1.weight", (512, 2048, 1, 1)), ("blocks.0.1.bn2.gain.weight", (512, 256)),
+                   ("blocks.3.2.theta.weight", (64, 512, 1, 1)), ("blocks.3.2.gamma", ()),
+                   ("blocks.5.1.conv4.weight", (128, 64, 1, 1)), ("output_layer.0.stored_var", (128,)),
+                   ("output_layer.2.weight", (3, 128, 3, 3))):
+        assert tuple(sd[k].shape) == shp, k
+    G.load_state_dict(dict(sd, **{"blocks.0.0.conv1.u0": torch.zeros(1, 512), "blocks.0.0.conv1.sv0": torch.zeros(1)}))
+    g = torch.Generator().manual_seed(3)
+    z, lab = torch.randn(2, 128, generator=g), torch.tensor([3, 977])
+    yemb = sd["shared.weight"][lab]
+    pre = BG.pre_tanh(sd, z, yemb)
+    assert tuple(pre.shape) == (2, 3, 256, 256) and 1.0 < pre.abs().max().item() < 20.0
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    assert (pre.double() - BG.pre_tanh(sd64, z.double(), yemb.double())).abs().max().item() < 1e-4
+    plan = G.engine().dry_plan(G, (4, 128))
+    assert len(plan.conv_steps) == 12 * 4 + 2 + 1                   # 12 GBlocks, attention (qkv + o), output conv
+    assert (plan.feat.H, plan.feat.W, plan.feat.C) == (256, 256, 3)
+    lab_ = {s.label: s.d for s in plan.conv_steps}
+    d = lab_["blocks.0.1.conv4"]                                    # upsampling block: skip gathered in the epilogue
+    assert d.flags & ptx._lib.PTX_EPI_RES_UP and (d.res_sT, d.res_sH, d.res_sW) == (0, 1, 1) and d.res_C == 2048
+    assert (d.Ho, d.Wo, d.res_H, d.res_W, d.Co) == (8, 8, 4, 4, 2048)
+    d = lab_["blocks.5.1.conv4"]
+    assert d.res_C == 256 and d.Co == 128 and d.Ho == 256           # channel-truncated skip
+    assert lab_["blocks.0.0.conv4"].flags & ptx._lib.PTX_EPI_RES_ADD
+    with pytest.raises(ValueError):
+        ptx.biggan_deep(pretrained="imagenet")
