@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, ".")
 import pretorched_x_amd as ptx  # noqa: E402
-from pretorched_x_amd.testing import I3D_RECIPE, synth_state_dict  # noqa: E402
+from pretorched_x_amd.testing import BIGGAN_RECIPE, I3D_RECIPE, synth_state_dict  # noqa: E402
 
 CASES = [
     # name, builder, recipe, input shape, clips per step
@@ -25,6 +25,7 @@ CASES = [
     ("resnet3d101", lambda: ptx.resnet3d101(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
     ("resnet3d18", lambda: ptx.resnet3d18(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
     ("resnet50 2-D", lambda: ptx.resnet50(num_classes=1000, pretrained=None), dict(last_bn_damp=0.7), (64, 3, 224, 224)),
+    ("biggan-deep-256 G (cfg5, fp32)", lambda: ptx.biggan_deep(256), BIGGAN_RECIPE, (64, 128)),
     ("TRN resnet50 x8 frames", lambda: ptx.TRN(339, num_segments=8, consensus="MSTRN", pretrained=None), dict(last_bn_damp=0.7), (8, 8, 3, 224, 224)),
 ]
 only = sys.argv[1:]
@@ -37,6 +38,10 @@ for name, build, recipe, shape in CASES:
     m.load_state_dict(synth_state_dict(m.state_dict(), 1234, **recipe))
     m = m.cuda().eval()
     x = torch.randn(*shape, device="cuda")
+    if name.startswith("biggan"):             # generator: (z, shared(labels)) -> images
+        yemb = m.shared(torch.randint(0, 1000, (shape[0],), device="cuda"))
+        gen, m_call = m, None
+        m = type("G", (), {"__call__": lambda self, z: gen(z, yemb), "engine": gen.engine})()
     t0 = time.time()
     y = m(x)                                  # compiles the plan and times untuned tile choices
     torch.cuda.synchronize()
