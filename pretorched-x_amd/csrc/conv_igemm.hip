@@ -683,20 +683,157 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA, NSTAGE>(a, grid, st);
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct (VALU) convolution for NARROW outputs (Co <= 16: SlowFast's fast pathway, lateral convs,
+// Inception reduction branches).  On the MFMA tiles above an 8-channel output wastes 3/4 .. 7/8 of
+// every 32- or 64-wide N tile; the fp32 vector ALUs have half the matrix peak but waste nothing:
+// one lane owns P consecutive output positions x CO channels in registers, streams its input
+// pixels with 16-byte buffer loads (out-of-image taps read zero) and multiplies them with filter
+// taps that are UNIFORM across the wave -- the filter never touches LDS or a VGPR-indexed load.
+// Same operands (NDHWC input, K-major packed filter with BN folded) and the same epilogue as the
+// implicit-GEMM kernel, so it is just another tile configuration for the tuner.
+// ------------------------------------------------------------------------------------------
+// wait for the scalar loads issued by inline asm; the in/out operands tie every consumer to this point
+template <int CO> __device__ __forceinline__ void sload_fence(f32x4 (&w)[CO]);
+template <> __device__ __forceinline__ void sload_fence<8>(f32x4 (&w)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]));
+}
+template <> __device__ __forceinline__ void sload_fence<16>(f32x4 (&w)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]),
+                   "+s"(w[8]), "+s"(w[9]), "+s"(w[10]), "+s"(w[11]), "+s"(w[12]), "+s"(w[13]), "+s"(w[14]), "+s"(w[15]));
+}
+
+template <int CO, int P>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs p, const float* __restrict__ wq,
+                                                          const float* __restrict__ bias, int segs_per_row,
+                                                          long long total_segs, int seg_tiles) {
+    const int st = blockIdx.x % seg_tiles, nt = blockIdx.x / seg_tiles;
+    const int n0 = nt * CO;
+    const long long seg = (long long)st * 256 + threadIdx.x;
+    const bool seg_ok = seg < total_segs;
+    const long long sg = seg_ok ? seg : 0;
+    const int ws = (int)(sg % segs_per_row);
+    long long r = sg / segs_per_row;
+    const int ho = (int)(r % p.Ho);
+    r /= p.Ho;
+    const int to = (int)(r % p.To);
+    const int n = (int)(r / p.To);
+    const int wo0 = ws * P;
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    float acc[P][CO];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[j][c] = 0.f;
+    const int kext = (p.k_live + 3) & ~3;                 // live K columns per tap, rounded to the 16-byte loads
+    for (int kt = 0; kt < p.kT; ++kt) {
+        const int ti = to * p.sT - p.pT + kt;
+        const bool t_ok = seg_ok && ti >= 0 && ti < p.Ti;
+        for (int kh = 0; kh < p.kH; ++kh) {
+            const int hi = ho * p.sH - p.pH + kh;
+            const bool h_ok = t_ok && hi >= 0 && hi < p.Hi;
+            const unsigned rowpos = (unsigned)((n * p.Ti + ti) * p.Hi + hi) * (unsigned)p.Wi;
+            for (int kw = 0; kw < p.kW; ++kw) {
+                const int tap = (kt * p.kH + kh) * p.kW + kw;
+                unsigned off[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int wi = (wo0 + j) * p.sW - p.pW + kw;
+                    const bool ok = h_ok && wi >= 0 && wi < p.Wi && (wo0 + j) < p.Wo;
+                    off[j] = ok ? (rowpos + (unsigned)wi) * (unsigned)p.ldx * 4u : kOOB;
+                }
+                // filter taps are wave-uniform: fetch them with SCALAR loads (s_load_dwordx4 -> SGPRs).  As vector
+                // loads of one address they made the kernel texture-addresser bound (6 ms for the fast stem).
+                const float* wt = wq + ((size_t)tap * p.w_rows + n0) * p.ldw;      // uniform
+                for (int k = 0; k < kext; k += 4) {
+                    f32x4 a[P];
+#pragma unroll
+                    for (int j = 0; j < P; ++j)
+                        a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             rsrc_x, off[j] == kOOB ? kOOB : off[j] + (unsigned)k * 4u, 0, 0));
+                    f32x4 wreg[CO];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const unsigned boff = __builtin_amdgcn_readfirstlane((unsigned)(c * p.ldw + k) * 4u);
+                        asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(wreg[c]) : "s"(wt), "s"(boff));
+                    }
+                    sload_fence<CO>(wreg);
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const f32x4 wv = wreg[c];
+#pragma unroll
+                        for (int j = 0; j < P; ++j) {
+                            float v = acc[j][c];
+                            v = fmaf(a[j].x, wv.x, v);
+                            v = fmaf(a[j].y, wv.y, v);
+                            v = fmaf(a[j].z, wv.z, v);
+                            v = fmaf(a[j].w, wv.w, v);
+                            acc[j][c] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!seg_ok) return;
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0, res_add = (p.flags & PTX_EPI_RES_ADD) != 0;
+    const long long m0 = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        if (wo0 + j >= p.Wo) break;
+        float* yrow = p.y + (size_t)(m0 + j) * p.ldy + n0;
+        const float* rrow = res_add ? p.res + (size_t)(m0 + j) * p.ldr + n0 : nullptr;
+#pragma unroll
+        for (int c = 0; c < CO; c += 4) {
+            if (n0 + c >= p.ncol) break;
+            f32x4 o = {acc[j][c], acc[j][c + 1], acc[j][c + 2], acc[j][c + 3]};
+            if (bias) o += *reinterpret_cast<const f32x4*>(bias + n0 + c);
+            if (res_add) o += *reinterpret_cast<const f32x4*>(rrow + c);
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<f32x4*>(yrow + c) = o;
+        }
+    }
+}
+
+template <int CO, int P>
+static int launch_direct(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if (a.dual || a.bs_x || a.bs_w || a.bs_y || grid.y != 1)
+        return fail(PTX_ERR_UNSUPPORTED, "direct conv: dual-source / batched-GEMM launches use the MFMA tiles");
+    if (a.flags & PTX_EPI_RES_PADA) return fail(PTX_ERR_UNSUPPORTED, "direct conv: shortcut-A / upsampled residuals use the MFMA tiles");
+    if ((a.flags & PTX_EPI_RES_ADD) && (a.ldr % 4 || ((uintptr_t)a.res & 15)))
+        return fail(PTX_ERR_UNSUPPORTED, "direct conv: misaligned residual");
+    if (a.ldy % 4 || a.ldw % 4) return fail(PTX_ERR_UNSUPPORTED, "direct conv: misaligned rows");
+    const int segs_per_row = cdiv(a.Wo, P);
+    const long long total = (long long)a.N * a.To * a.Ho * segs_per_row;
+    const long long seg_tiles = (total + 255) / 256;
+    const long long blocks = seg_tiles * cdiv(a.ncol, CO);
+    if (blocks > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "direct conv: grid too large");
+    hipLaunchKernelGGL((conv_direct_kernel<CO, P>), dim3((unsigned)blocks), dim3(256), 0, st, a, a.w, a.bias, segs_per_row,
+                       total, (int)seg_tiles);
+    return hip_check(hipGetLastError(), "conv_direct launch");
+}
+
 struct ConvConfig {
     int BM, BN, BK, WM, WN, MT;
     const char* name;
     launch_fn launch;
+    bool direct;      // VALU kernel: no split-K, own grid
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false }
 #define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false }
 #define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false }
 #define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false }
+
+#define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
+    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -766,6 +903,20 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_DMA(64, 128, 64, 2, 2, 32),   // 58
     PTX_CFG_DMA(32, 128, 64, 2, 2, 16),   // 59
     PTX_CFG_DMA(128, 64, 64, 4, 2, 32),   // 60
+    // direct VALU kernels for narrow outputs: <rows per workgroup> x <channels> x <K granule>; the "x24" names are
+    // offered to the kW-folded stems (K chunk 24), the "x4" names to everything else
+    PTX_CFG_DIRECT(1024, 8, 24, 8, 4),    // 61 fast-pathway stem (3 -> 8): 4 positions x 8 channels per lane
+    PTX_CFG_DIRECT(512, 8, 24, 8, 2),     // 62
+    PTX_CFG_DIRECT(1024, 8, 4, 8, 4),     // 63
+    PTX_CFG_DIRECT(512, 8, 4, 8, 2),      // 64
+    PTX_CFG_DIRECT(512, 16, 4, 16, 2),    // 65
+    PTX_CFG_DIRECT(256, 16, 4, 16, 1),    // 66
+    PTX_CFG_DIRECT(256, 8, 4, 8, 1),      // 67
+    // 16-wide N tiles on 16x16x4 MFMA for narrow outputs (Co <= 16): 4x less padded work than a 64-wide tile
+    PTX_CFG(256, 16, 32, 8, 1, 16),       // 68
+    PTX_CFG(128, 16, 32, 4, 1, 16),       // 69
+    PTX_CFG(256, 32, 32, 8, 1, 16),       // 70
+    PTX_CFG(128, 32, 32, 4, 1, 16),       // 71
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -881,7 +1032,7 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     const int steps_total = a.kT * a.kH * a.kW * a.kchunks;
     if (split_k < 1) split_k = 1;
     if (split_k > steps_total) split_k = steps_total;
-    if (batch > 1) split_k = 1;
+    if (batch > 1 || c.direct) split_k = 1;
     a.split_k = split_k;
     {
         const uint64_t yb = (uint64_t)a.M * a.ldy * 4ull;

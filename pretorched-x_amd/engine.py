@@ -1142,9 +1142,14 @@ class Engine:
                 for cfg in range(ncfg):
                     name = lib.ptx_conv3d_config_name(cfg).decode()
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
-                    if (bk == 24) != (stp.d.Kc == 24):      # BK = 24 tiles are for the kW-folded stem only
+                    narrow = bn_ <= 32 and bk == 32 and bm >= 128 and not name.endswith("/dma")   # Mx16 / Mx32 tiles
+                    if (bk == 24) != (stp.d.Kc == 24) and not (stp.d.Kc == 24 and narrow):
+                        continue                         # BK = 24 tiles are for the kW-folded stem only
+                    if narrow and ncol > 32:
                         continue
                     if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
+                        continue
+                    if name.endswith("/direct") and ncol > 32:     # VALU kernels: narrow outputs only
                         continue
                     if bn_ > 64 and ncol <= 64:
                         continue

@@ -664,3 +664,55 @@ def test_cbn_fold_affine_upsample_and_upsampled_skip(ptx):
         close(from_cl(yd, Co), want)
     d.res_sH = 5
     assert lib.ptx_conv3d_fwd(C.byref(d), _p(ad), _p(wp), _p(bp), _p(sd_), _p(yd), None, 0, -1, 1, _st()) == 1
+
+
+def test_direct_narrow_conv(ptx):
+    """The VALU direct kernels (narrow outputs: SlowFast fast pathway / lateral convs) against ATen and,
+    bit for bit in k-order terms, within fp32 reorder noise of the MFMA tiles."""
+    lib = _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    direct = [i for i, n in enumerate(names) if n.endswith("/direct") and not n.split("/")[0].endswith("x24")]
+    assert len(direct) >= 4
+    cases = [  # N,T,H,W, Ci,Co, k, s, p
+        (2, 6, 13, 11, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # fast res2 conv2
+        (2, 6, 13, 11, 32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # fast res2 conv1 (head_conv 3)
+        (1, 17, 9, 10, 8, 16, (5, 1, 1), (8, 1, 1), (2, 0, 0)),      # lateral conv
+        (2, 5, 12, 14, 16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # strided
+        (1, 3, 7, 9, 12, 20, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # ragged widths, two channel tiles
+    ]
+    for (N, T, H, W, Ci, Co, k, s, p) in cases:
+        x, w = rnd(N, Ci, T, H, W, seed=130), rnd(Co, Ci, *k, seed=131, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 132)
+        res = None
+        if s == (1, 1, 1):
+            res = rnd(N, Co, T, H, W, seed=133)
+        want = ref_conv(x, w, s, p, bn=bn, relu=True, res=res)
+        for cfg in direct:
+            close(hip_conv(ptx, x, w, s, p, bn=bn, relu=True, res=res, cfg=cfg, split=1), want)
+    # kW-folded stem (3 -> 8, (5,7,7)): the x24 direct kernels on the folded operand
+    L = ptx._lib
+    N, T, H, W = 2, 6, 22, 26
+    x, w = rnd(N, 3, T, H, W, seed=134), rnd(8, 3, 5, 7, 7, seed=135, scale=0.05)
+    bn = make_bn(8, 136)
+    want = ref_conv(x, w, (1, 2, 2), (2, 3, 3), bn=bn, relu=True)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    xd = x.to(DEV)
+    x2 = torch.empty((N, T, H, Wo, 24), device=DEV)
+    L.check(lib.ptx_fold_kw_ncdhw(_p(xd), _p(x2), N, 3, T, H, W, 7, 2, 3, Wo, 24, _st()), "fold")
+    pd = L.PackDesc(8, 3, 5, 7, 7, 24, 128, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(128, device=DEV)
+    ts = [t.to(DEV) for t in bn[:4]]
+    wd = w.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                     C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack")
+    for cfg in [i for i, n in enumerate(names) if n.endswith("x24/direct")] + [16]:
+        yd = torch.full((N, T, Ho, Wo, 8), float("nan"), device=DEV)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, Wo, 21, 24
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = T, Ho, Wo, 8, 8
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 5, 7, 1, 1, 2, 1, 2, 3, 0
+        d.Kc, d.Co_pad, d.flags = 24, 128, L.PTX_EPI_RELU
+        L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(x2), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st()), "conv")
+        torch.cuda.synchronize()
+        close(from_cl(yd, 8), want)
