@@ -67,7 +67,7 @@ typedef struct ptx_conv3d_desc {
     int32_t kT, kH, kW;      /* filter taps                                       */
     int32_t sT, sH, sW;      /* strides                                           */
     int32_t pT, pH, pW;      /* zero padding                                      */
-    int32_t Kc;              /* packed-weight K extent per tap  (>= Ci, multiple of the pack granule) */
+    int32_t Kc;              /* packed-weight K extent per tap  (>= Ci / groups, multiple of 4)       */
     int32_t Co_pad;          /* packed-weight row count per tap (>= Co, multiple of 128)              */
     uint32_t flags;          /* PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_EPI_RES_PADA */
     /* residual operand (PTX_EPI_RES_ADD: ldr only; PTX_EPI_RES_PADA: all fields) */
@@ -75,6 +75,11 @@ typedef struct ptx_conv3d_desc {
     /* second activation source of ptx_conv3d_dual_fwd (ignored by ptx_conv3d_fwd): x2 is NDHWC
      * [N][x2_T][x2_H][x2_W][x2_ld] with x2_C channels, sampled at (to*x2_sT, ho*x2_sH, wo*x2_sW) */
     int32_t x2_C, x2_ld, x2_T, x2_H, x2_W, x2_sT, x2_sH, x2_sW;
+    /* grouped convolution (resnext3D.py:85-92, cardinality 32): 0 or 1 = dense.  Output channel co reads
+     * the input channels [g*Ci/groups, (g+1)*Ci/groups), g = co / (Co/groups); the packed filter has
+     * Kc >= Ci/groups columns per tap (pack it with ptx_pack_desc.Ci = Ci/groups).  Ci/groups must be a
+     * multiple of 4.  Runs on the direct (VALU) tile configurations. */
+    int32_t groups;
 } ptx_conv3d_desc;
 
 /* number of compiled tile configurations, and a printable name "BMxBNxBK/WMxWN/mfmaMT" */

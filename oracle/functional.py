@@ -40,10 +40,15 @@ class ArchCfg:
     nl_mode: str = "embedded_gaussian"
     head: str = "last_linear"      # 'fc' for R2Plus1D (never passes through modify_resnets)
     dims: int = 3                  # 2 for the torchvision-shaped resnet18 plumbing case
+    cardinality: int = 32          # 'resnext' blocks (resnext3D.py:126)
     expansion: int = field(init=False)
 
     def __post_init__(self):
-        self.expansion = 4 if self.block == "bottleneck" else 1
+        self.expansion = {"bottleneck": 4, "resnext": 2}.get(self.block, 1)
+
+    @property
+    def widths(self):
+        return (128, 256, 512, 1024) if self.block == "resnext" else (64, 128, 256, 512)
 
 
 ARCHS = {
@@ -63,6 +68,10 @@ ARCHS = {
     # config-3 composite: (2+1)D bottlenecks + NL blocks, shortcut B
     "nonlocal_r2plus1d50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", conv="2p1d",
                                    nonlocal_layers=[0, 2, 3, 0]),
+    "resnext3d10": ArchCfg("resnext", [1, 1, 1, 1], "B", head="fc"),
+    "resnext3d18": ArchCfg("resnext", [2, 2, 2, 2], "B", head="fc"),
+    "resnext3d50": ArchCfg("resnext", [3, 4, 6, 3], "B", head="fc"),
+    "resnext3d101": ArchCfg("resnext", [3, 4, 23, 3], "B", head="fc"),
     "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
     "resnet34": ArchCfg("basic", [3, 4, 6, 3], "B", dims=2),
     "resnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", dims=2),
@@ -167,7 +176,12 @@ def nonlocal_block(sd, x, p, mode="embedded_gaussian", sub_sample=False, bn_laye
 # --------------------------------------------------------------------------------------------
 def _block(cfg, sd, x, p, planes, stride, has_down, nl):
     residual = x
-    if cfg.block == "bottleneck":
+    if cfg.block == "resnext":       # ResNeXtBottleneck.forward, resnext3D.py:101-121
+        out = F.relu(_bn(sd, _conv(sd, x, p + ".conv1", 1, 0), p + ".bn1"))
+        out = F.conv3d(out, sd[p + ".conv2.weight"], None, _t3(stride), (1, 1, 1), 1, cfg.cardinality)
+        out = F.relu(_bn(sd, out, p + ".bn2"))
+        out = _bn(sd, _conv(sd, out, p + ".conv3", 1, 0), p + ".bn3")
+    elif cfg.block == "bottleneck":
         out = F.relu(_bn(sd, _any_conv(cfg, sd, x, p + ".conv1", 1, 0), p + ".bn1"))
         out = F.relu(_bn(sd, _any_conv(cfg, sd, out, p + ".conv2", stride, 1), p + ".bn2"))
         out = _bn(sd, _any_conv(cfg, sd, out, p + ".conv3", 1, 0), p + ".bn3")
@@ -201,7 +215,7 @@ def features(cfg: ArchCfg, sd, x):
         x = F.relu(_bn(sd, _any_conv(cfg, sd, x, "conv1", (1, 2, 2), (3, 3, 3)), "bn1"))
         x = F.max_pool3d(x, 3, 2, 1)
     inplanes = 64
-    for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), cfg.layers)):
+    for li, (planes, nblocks) in enumerate(zip(cfg.widths, cfg.layers)):
         stride = 1 if li == 0 else 2
         flags = nl_flags(nblocks, cfg.nonlocal_layers[li]) if cfg.nonlocal_layers else [False] * nblocks
         for bi in range(nblocks):

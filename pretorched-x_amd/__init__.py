@@ -205,6 +205,32 @@ r2plus1d34 = _r2plus1d_factory("r2plus1d34")
 r2plus1d50 = _r2plus1d_factory("r2plus1d50")
 
 
+def _resnext3d_factory(name):
+    def factory(**kwargs):
+        """reference resnext3D.py:213-252: `ResNeXt3D(ResNeXtBottleneck, layers, **kwargs)` with
+        shortcut_type='B', cardinality=32, num_classes=400 defaults; no pretrained argument upstream."""
+        shortcut_type = kwargs.pop("shortcut_type", "B")
+        cardinality = kwargs.pop("cardinality", 32)
+        num_classes = kwargs.pop("num_classes", 400)
+        if kwargs:
+            raise TypeError("%s() got unexpected keyword arguments %s" % (name, sorted(kwargs)))
+        key = name if cardinality == 32 else "%s/c%d" % (name, cardinality)
+        if key not in ARCHS:
+            ARCHS[key] = dataclasses.replace(ARCHS[name], cardinality=cardinality)
+        return _build(key, num_classes, shortcut_type)
+    factory.__name__ = name
+    return factory
+
+
+resnext3d10 = _resnext3d_factory("resnext3d10")
+resnext3d18 = _resnext3d_factory("resnext3d18")
+resnext3d34 = _resnext3d_factory("resnext3d34")
+resnext3d50 = _resnext3d_factory("resnext3d50")
+resnext3d101 = _resnext3d_factory("resnext3d101")
+resnext3d152 = _resnext3d_factory("resnext3d152")
+resnext3d200 = _resnext3d_factory("resnext3d200")
+
+
 def nonlocal_r2plus1d50(num_classes=339):
     """BASELINE.json config 3 ("resnet2p1d50 + NLBlock"): no reference model combines (2+1)D convs
     with NL blocks; this is the composition validated in SURVEY.md row A9 (shortcut 'B')."""
@@ -249,4 +275,5 @@ def trn(num_classes=339, num_segments=8, consensus="MSTRN", arch="resnet50", pre
 model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
                "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
-               "resnet101", "resnet152", "trn", "i3d"]
+               "resnet101", "resnet152", "trn", "i3d", "resnext3d10", "resnext3d18", "resnext3d34", "resnext3d50",
+               "resnext3d101", "resnext3d152", "resnext3d200"]

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                [("flags", C.c_uint32)] + \
                [(n, C.c_int32) for n in
                 ("ldr", "res_C", "res_T", "res_H", "res_W", "res_sT", "res_sH", "res_sW",
-                 "x2_C", "x2_ld", "x2_T", "x2_H", "x2_W", "x2_sT", "x2_sH", "x2_sW")]
+                 "x2_C", "x2_ld", "x2_T", "x2_H", "x2_W", "x2_sT", "x2_sH", "x2_sW", "groups")]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

@@ -59,6 +59,7 @@ struct ConvArgs {
     const float* x2;
     int dual, ldx2, kA2, kc1, wcol2, T2, H2, W2, s2T, s2H, s2W;
     unsigned x2_bytes;
+    int groups, cig, cog;  // grouped conv (direct kernels only): input / output channels per group
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -695,6 +696,9 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // wait for the scalar loads issued by inline asm; the in/out operands tie every consumer to this point
 template <int CO> __device__ __forceinline__ void sload_fence(f32x4 (&w)[CO]);
+template <> __device__ __forceinline__ void sload_fence<4>(f32x4 (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]));
+}
 template <> __device__ __forceinline__ void sload_fence<8>(f32x4 (&w)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]));
@@ -711,6 +715,8 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs p, cons
                                                           long long total_segs, int seg_tiles) {
     const int st = blockIdx.x % seg_tiles, nt = blockIdx.x / seg_tiles;
     const int n0 = nt * CO;
+    // grouped conv: this tile's CO output channels lie in one group and read only its input channels
+    const unsigned xcol = p.groups > 1 ? (unsigned)((n0 / p.cog) * p.cig) * 4u : 0u;
     const long long seg = (long long)st * 256 + threadIdx.x;
     const bool seg_ok = seg < total_segs;
     const long long sg = seg_ok ? seg : 0;
@@ -743,7 +749,7 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs p, cons
                 for (int j = 0; j < P; ++j) {
                     const int wi = (wo0 + j) * p.sW - p.pW + kw;
                     const bool ok = h_ok && wi >= 0 && wi < p.Wi && (wo0 + j) < p.Wo;
-                    off[j] = ok ? (rowpos + (unsigned)wi) * (unsigned)p.ldx * 4u : kOOB;
+                    off[j] = ok ? (rowpos + (unsigned)wi) * (unsigned)p.ldx * 4u + xcol : kOOB;
                 }
                 // filter taps are wave-uniform: fetch them with SCALAR loads (s_load_dwordx4 -> SGPRs).  As vector
                 // loads of one address they made the kernel texture-addresser bound (6 ms for the fast stem).
@@ -806,6 +812,9 @@ static int launch_direct(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if ((a.flags & PTX_EPI_RES_ADD) && (a.ldr % 4 || ((uintptr_t)a.res & 15)))
         return fail(PTX_ERR_UNSUPPORTED, "direct conv: misaligned residual");
     if (a.ldy % 4 || a.ldw % 4) return fail(PTX_ERR_UNSUPPORTED, "direct conv: misaligned rows");
+    if (a.groups > 1 && (a.cog % CO || a.cig % 4))
+        return fail(PTX_ERR_UNSUPPORTED, "direct conv: %d-channel tiles do not divide the %d output channels of a group",
+                    CO, a.cog);
     const int segs_per_row = cdiv(a.Wo, P);
     const long long total = (long long)a.N * a.To * a.Ho * segs_per_row;
     const long long seg_tiles = (total + 255) / 256;
@@ -917,6 +926,8 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 16, 32, 4, 1, 16),       // 69
     PTX_CFG(256, 32, 32, 8, 1, 16),       // 70
     PTX_CFG(128, 32, 32, 4, 1, 16),       // 71
+    PTX_CFG_DIRECT(1024, 4, 4, 4, 4),     // 72 group width 4 (ResNeXt3D layer1, cardinality 32)
+    PTX_CFG_DIRECT(512, 4, 4, 4, 2),      // 73
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -933,9 +944,13 @@ static int validate_desc(const ptx_conv3d_desc* d) {
         return fail(PTX_ERR_INVALID, "conv3d: bad filter geometry");
     if (d->kT > 8 || d->kH > 8 || d->kW > 8)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: filter extents above 8 are not supported (%d,%d,%d)", d->kT, d->kH, d->kW);
-    if (d->Kc < d->Ci || d->Kc % 4 || d->Co_pad < (d->Co + 3) / 4 * 4)
-        return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci=%d Co=%d",
-                    d->Kc, d->Co_pad, d->Ci, d->Co);
+    const int groups = d->groups > 1 ? d->groups : 1;
+    if (d->groups < 0 || d->Ci % groups || d->Co % groups || (groups > 1 && (d->Ci / groups) % 4))
+        return fail(PTX_ERR_INVALID, "conv3d: groups=%d must divide Ci=%d and Co=%d, with Ci/groups a multiple of 4",
+                    d->groups, d->Ci, d->Co);
+    if (d->Kc < d->Ci / groups || d->Kc % 4 || d->Co_pad < (d->Co + 3) / 4 * 4)
+        return fail(PTX_ERR_INVALID, "conv3d: packed weight extents Kc=%d Co_pad=%d do not cover Ci/groups=%d Co=%d",
+                    d->Kc, d->Co_pad, d->Ci / groups, d->Co);
     // output extent must match the conv arithmetic: symmetric padding p, or TF-"SAME" (out = ceil(in/stride),
     // p = the FRONT pad floor(total/2); the back pad is implied -- out-of-range taps read zero either way)
     auto extent_ok = [](int in, int out, int k, int s, int p) {
@@ -979,6 +994,10 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     const int taps = d->kT * d->kH * d->kW;
     const int ncol = (d->Co + 3) / 4 * 4;
     int cfg;
+    if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
+        const int cog = d->Co / d->groups;
+        return cog % 16 == 0 ? 65 : cog % 8 == 0 ? 64 : 73;
+    }
     if (d->Kc == 24) {
         cfg = M >= 256 * 1024 ? 16 : 6;            // kW-folded stem: 8-wave 256x64x24 (register staged)
     } else if (ncol % 48 == 0 && ncol % 64 != 0) {
@@ -1012,6 +1031,8 @@ namespace ptx {
 int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
                 hipStream_t st) {
     const ConvConfig& c = kConfigs[config];
+    if (a.groups > 1 && !c.direct)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: grouped convolutions run on the direct tile configurations");
     a.m_tiles = cdiv(a.M, c.BM);
     {
         static int t_inner = -1;
@@ -1122,6 +1143,12 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
                         "(32-bit buffer offsets); split the batch", (unsigned long long)xb, (unsigned long long)wb);
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)wb;
+    }
+    a.groups = d->groups > 1 ? d->groups : 1;
+    a.cig = d->Ci / a.groups; a.cog = d->Co / a.groups;
+    if (a.groups > 1) {
+        if (x2) return fail(PTX_ERR_INVALID, "conv3d_dual: grouped convolutions have one source");
+        a.k_live = a.cig;
     }
     a.ldr = d->ldr; a.res_C = d->res_C; a.res_T = d->res_T; a.res_H = d->res_H; a.res_W = d->res_W;
     a.res_sT = d->res_sT; a.res_sH = d->res_sH; a.res_sW = d->res_sW;

@@ -131,7 +131,10 @@ class Packed:
         c0 = self.convs[0]
         (kT, kH, kW), _, _ = _geom(c0)
         self.Co = sum(c.out_channels for c in self.convs)
-        self.Ci = c0.in_channels
+        self.groups = int(getattr(c0, "groups", 1))
+        if self.groups > 1 and (len(self.convs) > 1 or fold_kw):
+            raise PtxError("grouped convolutions are packed one at a time, unfolded")
+        self.Ci = c0.in_channels // self.groups      # K extent of one filter row (per group)
         self.fold_kw = bool(fold_kw)
         keff = kW * self.Ci if fold_kw else self.Ci
         self.Kc = _r4(keff)
@@ -297,6 +300,9 @@ class Plan:
         d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, y.ld
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
         d.Kc, d.Co_pad = pk.Kc, pk.Co_pad
+        d.groups = getattr(pk, "groups", 1)
+        if d.groups > 1 and (x.C != pk.Ci * d.groups or pk.Ci % 4):
+            raise PtxError("%s: grouped conv needs Ci/groups %% 4 == 0 and a %d-channel input" % (label, pk.Ci * d.groups))
         resptr = C.c_void_p(0)
         if res is not None:
             resptr = _ptr(res.t)
@@ -490,7 +496,7 @@ class Plan:
         """One residual block.  `out`: optional pre-allocated target (a channel slice of the next
         stage's concatenated input, slowfast.py:145-151) for the block's final conv."""
         s = blk.stride
-        fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block == "bottleneck"
+        fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block in ("bottleneck", "resnext")
                 and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.downsample[0], (nn.Conv3d, nn.Conv2d)))
         if fuse:
             # conv3 + bn3 and the shortcut conv + bn share the output tile: one GEMM over the
@@ -511,7 +517,7 @@ class Plan:
             res, kind = x, "padA"
         else:
             res, kind = x, None
-        if arch.block == "bottleneck":
+        if arch.block in ("bottleneck", "resnext"):
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
             o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
@@ -1149,7 +1155,9 @@ class Engine:
                         continue
                     if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
                         continue
-                    if name.endswith("/direct") and ncol > 32:     # VALU kernels: narrow outputs only
+                    if name.endswith("/direct") and ncol > 32 and stp.d.groups <= 1:   # VALU kernels: narrow outputs
+                        continue
+                    if stp.d.groups > 1 and not name.endswith("/direct"):              # grouped: direct tiles only
                         continue
                     if bn_ > 64 and ncol <= 64:
                         continue

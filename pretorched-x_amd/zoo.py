@@ -35,10 +35,16 @@ class Arch:
     nonlocal_layers: Optional[Sequence[int]] = None
     head: str = "last_linear"
     dims: int = 3
+    cardinality: int = 32            # 'resnext' blocks only (resnext3D.py:126)
 
     @property
     def expansion(self):
-        return 4 if self.block == "bottleneck" else 1
+        return {"bottleneck": 4, "resnext": 2}.get(self.block, 1)
+
+    @property
+    def widths(self):
+        """`planes` of the four stages (resnext3D.py:134-137 doubles them)."""
+        return (128, 256, 512, 1024) if self.block == "resnext" else (64, 128, 256, 512)
 
 
 ARCHS = {
@@ -58,6 +64,14 @@ ARCHS = {
     "nonlocal_r2plus1d50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="2p1d", nonlocal_layers=(0, 2, 3, 0)),
     # 2-D torchvision-shaped ResNets (torchvision_models.py:484-536), executed as the T == 1 case;
     # resnet50 is the per-frame backbone of TRN (trn.py:207)
+    # ResNeXt3D (resnext3D.py:213-252): grouped 3x3x3 convs, cardinality 32, keeps `fc`, forward only upstream
+    "resnext3d10": Arch("resnext", (1, 1, 1, 1), "B", head="fc"),
+    "resnext3d18": Arch("resnext", (2, 2, 2, 2), "B", head="fc"),
+    "resnext3d34": Arch("resnext", (3, 4, 6, 3), "B", head="fc"),
+    "resnext3d50": Arch("resnext", (3, 4, 6, 3), "B", head="fc"),
+    "resnext3d101": Arch("resnext", (3, 4, 23, 3), "B", head="fc"),
+    "resnext3d152": Arch("resnext", (3, 8, 36, 3), "B", head="fc"),
+    "resnext3d200": Arch("resnext", (3, 24, 36, 3), "B", head="fc"),
     "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
     "resnet34": Arch("basic", (3, 4, 6, 3), "B", dims=2),
     "resnet50": Arch("bottleneck", (3, 4, 6, 3), "B", dims=2),
@@ -114,7 +128,15 @@ def _nonlocal(channels):
 
 def _block(arch, cin, planes, stride, with_down, with_nl):
     blk = Bag()
-    if arch.block == "bottleneck":
+    if arch.block == "resnext":          # resnext3D.py:76-99
+        mid = arch.cardinality * int(planes / 32)
+        blk.conv1 = nn.Conv3d(cin, mid, 1, bias=False)
+        blk.bn1 = nn.BatchNorm3d(mid)
+        blk.conv2 = nn.Conv3d(mid, mid, 3, stride, 1, groups=arch.cardinality, bias=False)
+        blk.bn2 = nn.BatchNorm3d(mid)
+        blk.conv3 = nn.Conv3d(mid, planes * 2, 1, bias=False)
+        blk.bn3 = nn.BatchNorm3d(planes * 2)
+    elif arch.block == "bottleneck":
         blk.conv1 = _conv(arch, cin, planes, 1)
         blk.bn1 = _bn(arch, planes)
         blk.conv2 = _conv(arch, planes, planes, 3, stride, 1)
@@ -160,7 +182,7 @@ class VideoResNet(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = (nn.MaxPool2d(3, 2, 1) if arch.dims == 2 else nn.MaxPool3d(3, 2, 1))
         cin = 64
-        for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), arch.layers)):
+        for li, (planes, nblocks) in enumerate(zip(arch.widths, arch.layers)):
             stride = 1 if li == 0 else 2
             nl = nl_placement(nblocks, arch.nonlocal_layers[li]) if arch.nonlocal_layers else [False] * nblocks
             blocks = []
@@ -173,10 +195,10 @@ class VideoResNet(nn.Module):
             setattr(self, "layer%d" % (li + 1), nn.ModuleList(blocks))
         self.avgpool = nn.AdaptiveAvgPool2d(1) if arch.dims == 2 else nn.AdaptiveAvgPool3d(1)
         if arch.head == "fc":
-            self.fc = nn.Linear(512 * arch.expansion, num_classes)
+            self.fc = nn.Linear(arch.widths[3] * arch.expansion, num_classes)
         else:
             self.fc = None                       # the reference sets fc=None after the rename
-            self.last_linear = nn.Linear(512 * arch.expansion, num_classes)
+            self.last_linear = nn.Linear(arch.widths[3] * arch.expansion, num_classes)
         self._init_like_reference()
         self.eval()
         self._engine = Engine()

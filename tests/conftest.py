@@ -50,6 +50,9 @@ GOLDEN_CASES = {
     "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "resnet18_cfg1": ("resnet18", dict(num_classes=1000, pretrained=None)),
     "resnet50_2d_small": ("resnet50", dict(num_classes=339, pretrained=None)),
+    "resnext3d50_small": ("resnext3d50", dict(num_classes=400)),
+    "resnext3d10_odd": ("resnext3d10", dict(num_classes=17)),
+    "resnext3d50_full": ("resnext3d50", dict(num_classes=400)),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),

@@ -46,6 +46,9 @@ CASES = {
     "nonlocal_r2plus1d50_small": ("nonlocal_r2plus1d50", (2, 3, 8, 64, 64), dict(num_classes=339)),
     "resnet18_cfg1": ("resnet18", (1, 3, 224, 224), dict(num_classes=1000, pretrained=None)),
     "resnet50_2d_small": ("resnet50", (3, 3, 96, 64), dict(num_classes=339, pretrained=None)),
+    "resnext3d50_small": ("resnext3d50", (2, 3, 8, 64, 64), dict(num_classes=400)),
+    "resnext3d10_odd": ("resnext3d10", (3, 3, 5, 50, 70), dict(num_classes=17)),
+    "resnext3d50_full": ("resnext3d50", (2, 3, 16, 224, 224), dict(num_classes=400)),
     # BASELINE.json config 3 at full size (8 x 3 x 32 x 112 x 112): the composite and its two parents
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=400)),
@@ -59,6 +62,10 @@ RECIPES = {
     "nonlocal_r2plus1d50_cfg3": dict(inner_bn_damp=0.9, nl_bn_damp=0.05),
     "r2plus1d50_cfg3": dict(inner_bn_damp=0.9),
     "resnet50_2d_small": dict(last_bn_damp=0.7),
+    # grouped 3x3x3 convs under fan_out init shrink the signal: un-damp the closing BNs instead
+    "resnext3d50_small": dict(last_bn_damp=2.0),
+    "resnext3d10_odd": dict(last_bn_damp=2.0),
+    "resnext3d50_full": dict(last_bn_damp=2.0),
     "nonlocalresnet3d50_cfg3": dict(last_bn_damp=0.65, nl_bn_damp=0.05),
 }
 
@@ -179,7 +186,7 @@ def main():
             g = torch.Generator().manual_seed(X_SEED)
             x = torch.randn(*shape, generator=g)
         with torch.no_grad():
-            if hasattr(model, "features") and not arch.startswith("r2plus1d"):
+            if hasattr(model, "features") and not arch.startswith("r2plus1d") and not arch.startswith("resnext"):
                 feat = model.features(x)
                 logits = model.logits(feat)
             else:   # R2Plus1D keeps ResNet3D.forward / fc (r2plus1d.py:99-110)

@@ -716,3 +716,46 @@ def test_direct_narrow_conv(ptx):
         L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(x2), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st()), "conv")
         torch.cuda.synchronize()
         close(from_cl(yd, 8), want)
+
+
+def test_grouped_conv(ptx):
+    """Grouped 3x3x3 convolution (ResNeXt3D, cardinality 32: resnext3D.py:85-92) on the direct tiles."""
+    L, lib = ptx._lib, _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    for (N, T, H, W, Cin, Co, G, s) in [(2, 4, 9, 10, 128, 128, 32, (1, 1, 1)), (1, 5, 11, 8, 256, 256, 32, (2, 2, 2)),
+                                       (1, 3, 6, 7, 64, 64, 4, (1, 1, 1)), (1, 2, 5, 5, 256, 512, 16, (1, 2, 2))]:
+        cig = Cin // G
+        x, w = rnd(N, Cin, T, H, W, seed=140), rnd(Co, cig, 3, 3, 3, seed=141, scale=(cig * 27) ** -0.5)
+        bn = make_bn(Co, 142)
+        want = F.relu(F.batch_norm(F.conv3d(x, w, None, s, 1, 1, G), bn[2], bn[3], bn[0], bn[1], False, 0.1, bn[4]))
+        To, Ho, Wo = want.shape[2:]
+        pd = L.PackDesc(Co, cig, 3, 3, 3, _r4(cig), (Co + 127) // 128 * 128, 0)
+        wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(pd.Co_pad, device=DEV)
+        wd = w.to(DEV)
+        ts = [t.to(DEV) for t in bn[:4]]
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                         C.c_float(bn[4]), _p(wp), _p(bp), _st()), "pack")
+        xd = to_cl(x)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Cin, Cin
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, Co
+        d.kT = d.kH = d.kW = 3
+        d.sT, d.sH, d.sW = s
+        d.pT = d.pH = d.pW = 1
+        d.Kc, d.Co_pad, d.flags, d.groups = pd.Kc, pd.Co_pad, L.PTX_EPI_RELU, G
+        ran = 0
+        for cfg in [-1] + [i for i, n in enumerate(names) if n.endswith("/direct") and "x24/" not in n]:
+            yd = torch.full((N, To, Ho, Wo, Co), float("nan"), device=DEV)
+            st = lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st())
+            if st == 2:                                   # tile wider than the group: reported, not computed
+                assert cfg >= 0
+                continue
+            assert st == 0, lib.ptx_last_error()
+            torch.cuda.synchronize()
+            close(from_cl(yd, Co), want)
+            ran += 1
+        assert ran >= 2
+        assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, 28, 1, _st()) == 2   # MFMA tile
+    d.groups = 3
+    assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, -1, 1, _st()) == 1
