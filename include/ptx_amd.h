@@ -78,7 +78,8 @@ typedef struct ptx_conv3d_desc {
     /* grouped convolution (resnext3D.py:85-92, cardinality 32): 0 or 1 = dense.  Output channel co reads
      * the input channels [g*Ci/groups, (g+1)*Ci/groups), g = co / (Co/groups); the packed filter has
      * Kc >= Ci/groups columns per tap (pack it with ptx_pack_desc.Ci = Ci/groups).  Ci/groups must be a
-     * multiple of 4.  Runs on the direct (VALU) tile configurations. */
+     * multiple of 4.  Runs on the direct (VALU) tile configurations, and on MFMA tiles whose N extent divides
+     * Co/groups (the tile then reads only its group's input columns). */
     int32_t groups;
 } ptx_conv3d_desc;
 
@@ -134,6 +135,13 @@ typedef struct ptx_pack_desc {
     /* K-concatenated packing (ptx_conv3d_dual_fwd): row stride of w_packed in floats (0 = Kc), first
      * column written, and whether bias_out is accumulated into instead of overwritten */
     int32_t ld_k, k_off, bias_accumulate;
+    /* Grouped filters packed as block-diagonal SUPER-groups (0 or 1 = off): w is [Co][Ci/sub_groups][taps],
+     * i.e. sub_groups real groups of Ci/sub_groups input channels share one packed row of Ci columns, with
+     * zeros outside a row's own group.  A cardinality-32 conv of group width 4 (resnext3D.py:85-92) becomes
+     * a 32-wide grouped conv (desc.groups = 32/8) that the MFMA tiles can run -- 8x padded work, but
+     * coalesced LDS-staged operands instead of per-lane 16-byte gathers.  co_per_super = output channels
+     * of one super-group (rows [s*co_per_super, (s+1)*co_per_super) share the input columns of super-group s). */
+    int32_t sub_groups, co_per_super;
 } ptx_pack_desc;
 
 size_t ptx_packed_weight_elems(const ptx_pack_desc* desc);

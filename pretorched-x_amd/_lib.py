@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("Co", "Ci", "kT", "kH", "kW", "Kc", "Co_pad", "fold_kw",
-                                         "ld_k", "k_off", "bias_accumulate")]
+                                         "ld_k", "k_off", "bias_accumulate", "sub_groups", "co_per_super")]
 
 
 class PoolDesc(C.Structure):

@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const int zb = blockIdx.y;
     const int zs = blockIdx.z;
 
-    const float* __restrict__ xg = p.x + (size_t)zb * p.bs_x;
+    // grouped conv: this N tile lies inside one group and reads only that group's input columns
+    const float* __restrict__ xg = p.x + (size_t)zb * p.bs_x + (p.groups > 1 ? (n0 / p.cog) * p.cig : 0);
     const float* __restrict__ wg = p.w + (size_t)zb * p.bs_w;
 
     // ---- per-thread operand rows (tap independent, computed once) ----
@@ -996,6 +997,7 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     int cfg;
     if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
         const int cog = d->Co / d->groups;
+        if (cog % 32 == 0) return 37;              // 64x32x32 MFMA tile inside one group
         return cog % 16 == 0 ? 65 : cog % 8 == 0 ? 64 : 73;
     }
     if (d->Kc == 24) {
@@ -1031,8 +1033,8 @@ namespace ptx {
 int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
                 hipStream_t st) {
     const ConvConfig& c = kConfigs[config];
-    if (a.groups > 1 && !c.direct)
-        return fail(PTX_ERR_UNSUPPORTED, "conv3d: grouped convolutions run on the direct tile configurations");
+    if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
     a.m_tiles = cdiv(a.M, c.BM);
     {
         static int t_inner = -1;
@@ -1149,6 +1151,7 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     if (a.groups > 1) {
         if (x2) return fail(PTX_ERR_INVALID, "conv3d_dual: grouped convolutions have one source");
         a.k_live = a.cig;
+        a.kA = a.cig;          // K extent of the A operand per tap: the group's input channels only
     }
     a.ldr = d->ldr; a.res_C = d->res_C; a.res_T = d->res_T; a.res_H = d->res_H; a.res_W = d->res_W;
     a.res_sT = d->res_sT; a.res_sH = d->res_sH; a.res_sW = d->res_sW;

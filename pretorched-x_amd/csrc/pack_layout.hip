@@ -42,9 +42,18 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const
             c = k;
             valid = valid && k < d.Ci;
         }
+        int ci_src = d.Ci;                 // channels per filter row in the source tensor
+        if (d.sub_groups > 1 && valid) {
+            // block-diagonal super-group: row co keeps only the columns of its own real group
+            ci_src = d.Ci / d.sub_groups;
+            const int cog = d.co_per_super / d.sub_groups;      // output channels per real group
+            const int g_row = (co % d.co_per_super) / cog, g_col = c / ci_src;
+            valid = g_row == g_col;
+            c -= g_col * ci_src;
+        }
         float v = 0.f;
         if (valid) {
-            const size_t src = ((((size_t)co * d.Ci + c) * d.kT + kt) * d.kH + kh) * d.kW + kw;
+            const size_t src = ((((size_t)co * ci_src + c) * d.kT + kt) * d.kH + kh) * d.kW + kw;
             v = w[src] * bn_scale(gamma, var, eps, co);
         }
         const size_t ld = d.ld_k > 0 ? (size_t)d.ld_k : (size_t)d.Kc;
@@ -279,6 +288,9 @@ extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, cons
     if (d->ld_k < 0 || d->k_off < 0 || (d->ld_k > 0 && (d->k_off + d->Kc > d->ld_k || d->ld_k % 4 || d->k_off % 4)))
         return fail(PTX_ERR_INVALID, "pack: bad K-concatenation window (ld_k=%d k_off=%d Kc=%d)", d->ld_k, d->k_off, d->Kc);
     if (d->ld_k == 0 && d->k_off != 0) return fail(PTX_ERR_INVALID, "pack: k_off needs ld_k");
+    if (d->sub_groups > 1 && (d->fold_kw || d->Ci % d->sub_groups || d->co_per_super <= 0 ||
+                              d->co_per_super % d->sub_groups || d->Co % d->co_per_super))
+        return fail(PTX_ERR_INVALID, "pack: super-group packing needs sub_groups | Ci, sub_groups | co_per_super | Co, no kW fold");
     const int keff = d->fold_kw ? d->kW * d->Ci : d->Ci;
     if (d->Kc < keff || d->Kc % 4 || d->Co_pad < d->Co || d->Co_pad % 128)
         return fail(PTX_ERR_INVALID, "pack: Kc=%d must cover K=%d (multiple of 4); Co_pad=%d must cover Co=%d (multiple of 128)",

@@ -135,6 +135,16 @@ class Packed:
         if self.groups > 1 and (len(self.convs) > 1 or fold_kw):
             raise PtxError("grouped convolutions are packed one at a time, unfolded")
         self.Ci = c0.in_channels // self.groups      # K extent of one filter row (per group)
+        self.real_ci = self.Ci
+        self.sub_groups = 0
+        cog = c0.out_channels // self.groups
+        SUPER = 32      # narrow groups (width 4/8/16, resnext3D.py:85-92) are packed as block-diagonal 32-wide
+        if (self.groups > 1 and self.Ci == cog and self.Ci < SUPER and SUPER % self.Ci == 0
+                and c0.in_channels % SUPER == 0 and os.environ.get("PTX_SUPERGROUP", "1") != "0"):
+            # super-groups: the MFMA tiles then run them (8x / 4x / 2x padded work, but coalesced operands)
+            self.sub_groups = SUPER // self.Ci
+            self.groups //= self.sub_groups
+            self.Ci = SUPER
         self.fold_kw = bool(fold_kw)
         keff = kW * self.Ci if fold_kw else self.Ci
         self.Kc = _r4(keff)
@@ -142,7 +152,8 @@ class Packed:
             self.Kc = max(self.Kc, 24) if keff <= 24 else self.Kc
         self.Co_pad = _r128(self.Co)
         self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
-        self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw))
+        self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw), 0, 0, 0,
+                          self.sub_groups, self.Ci if self.sub_groups else 0)
         n = _lib.lib().ptx_packed_weight_elems(C.byref(self.d))
         self.w = torch.empty(n, device=dev, dtype=torch.float32)
         self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
@@ -322,7 +333,7 @@ class Plan:
         st = ConvStep()
         st.d, st.x, st.w, st.b, st.res, st.y = d, _ptr(x.t), _ptr(pk.w), _ptr(pk.b), resptr, _ptr(y.t)
         st.plan, st.label = self, label
-        st.macs = x.N * To * Ho * Wo * pk.Co * pk.Ci * pk.d.kT * pk.d.kH * pk.d.kW
+        st.macs = x.N * To * Ho * Wo * pk.Co * getattr(pk, "real_ci", pk.Ci) * pk.d.kT * pk.d.kH * pk.d.kW
         st.x2 = None
         if x2 is not None:                      # K-concatenated second activation source (shortcut B)
             d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = x2.C, x2.ld, x2.T, x2.H, x2.W
@@ -1151,14 +1162,14 @@ class Engine:
                     narrow = bn_ <= 32 and bk == 32 and bm >= 128 and not name.endswith("/dma")   # Mx16 / Mx32 tiles
                     if (bk == 24) != (stp.d.Kc == 24) and not (stp.d.Kc == 24 and narrow):
                         continue                         # BK = 24 tiles are for the kW-folded stem only
-                    if narrow and ncol > 32:
+                    if narrow and ncol > 32 and stp.d.groups <= 1:
                         continue
                     if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
                         continue
                     if name.endswith("/direct") and ncol > 32 and stp.d.groups <= 1:   # VALU kernels: narrow outputs
                         continue
-                    if stp.d.groups > 1 and not name.endswith("/direct"):              # grouped: direct tiles only
-                        continue
+                    if stp.d.groups > 1 and not name.endswith("/direct") and (stp.d.Co // stp.d.groups) % bn_:
+                        continue                         # grouped: direct tiles, or MFMA tiles inside one group
                     if bn_ > 64 and ncol <= 64:
                         continue
                     if bn_ % 48 == 0 and ncol % 48 != 0:          # 48/96-wide tiles: (2+1)D widths only

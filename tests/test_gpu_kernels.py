@@ -759,3 +759,35 @@ def test_grouped_conv(ptx):
         assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, 28, 1, _st()) == 2   # MFMA tile
     d.groups = 3
     assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, -1, 1, _st()) == 1
+    # narrow groups packed as block-diagonal 32-wide super-groups -> MFMA tiles inside one super-group
+    mfma = [i for i, n in enumerate(names) if not n.endswith("/direct") and n.split("x")[1] in ("16", "32")]
+    assert len(mfma) >= 4
+    for (N, T, H, W, Cc, G, s_) in [(2, 4, 9, 10, 128, 32, (1, 1, 1)), (1, 5, 11, 8, 256, 32, (2, 2, 2)), (2, 3, 6, 6, 64, 4, (1, 1, 1))]:
+        gw = Cc // G
+        sub = 32 // gw
+        x, w = rnd(N, Cc, T, H, W, seed=143), rnd(Cc, gw, 3, 3, 3, seed=144, scale=(gw * 27) ** -0.5)
+        bias = rnd(Cc, seed=145)
+        want = F.conv3d(x, w, bias, s_, 1, 1, G)
+        To, Ho, Wo = want.shape[2:]
+        pd = L.PackDesc(Cc, 32, 3, 3, 3, 32, (Cc + 127) // 128 * 128, 0, 0, 0, 0, sub, 32)
+        wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(pd.Co_pad, device=DEV)
+        wd, bd = w.to(DEV), bias.to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0), _p(wp), _p(bp),
+                                         _st()), "pack super-groups")
+        xd = to_cl(x)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Cc, Cc
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Cc, Cc
+        d.kT = d.kH = d.kW = 3
+        d.sT, d.sH, d.sW = s_
+        d.pT = d.pH = d.pW = 1
+        d.Kc, d.Co_pad, d.groups = 32, pd.Co_pad, G // sub
+        ws = torch.empty(4 * N * To * Ho * Wo * Cc, device=DEV)
+        for cfg, split in [(-1, 0)] + [(c, 1) for c in mfma] + [(37, 3), (65, 1)]:
+            yd = torch.full((N, To, Ho, Wo, Cc), float("nan"), device=DEV)
+            L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), _p(ws), ws.numel() * 4, cfg, split,
+                                       _st()), "grouped mfma cfg %d" % cfg)
+            torch.cuda.synchronize()
+            close(from_cl(yd, Cc), want)
+        assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, 28, 1, _st()) == 2   # 64-wide tile
