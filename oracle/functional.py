@@ -41,14 +41,17 @@ class ArchCfg:
     head: str = "last_linear"      # 'fc' for R2Plus1D (never passes through modify_resnets)
     dims: int = 3                  # 2 for the torchvision-shaped resnet18 plumbing case
     cardinality: int = 32          # 'resnext' blocks (resnext3D.py:126)
+    k: int = 1                     # 'wide' blocks (wideresnet3D.py:113)
     expansion: int = field(init=False)
 
     def __post_init__(self):
-        self.expansion = {"bottleneck": 4, "resnext": 2}.get(self.block, 1)
+        self.expansion = {"bottleneck": 4, "resnext": 2, "wide": 2}.get(self.block, 1)
 
     @property
     def widths(self):
-        return (128, 256, 512, 1024) if self.block == "resnext" else (64, 128, 256, 512)
+        if self.block == "resnext":
+            return (128, 256, 512, 1024)
+        return tuple(w * self.k for w in (64, 128, 256, 512)) if self.block == "wide" else (64, 128, 256, 512)
 
 
 ARCHS = {
@@ -72,6 +75,7 @@ ARCHS = {
     "resnext3d18": ArchCfg("resnext", [2, 2, 2, 2], "B", head="fc"),
     "resnext3d50": ArchCfg("resnext", [3, 4, 6, 3], "B", head="fc"),
     "resnext3d101": ArchCfg("resnext", [3, 4, 23, 3], "B", head="fc"),
+    "wideresnet3d50": ArchCfg("wide", [3, 4, 6, 3], "B", head="fc", k=2),
     "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
     "resnet34": ArchCfg("basic", [3, 4, 6, 3], "B", dims=2),
     "resnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", dims=2),
@@ -181,7 +185,7 @@ def _block(cfg, sd, x, p, planes, stride, has_down, nl):
         out = F.conv3d(out, sd[p + ".conv2.weight"], None, _t3(stride), (1, 1, 1), 1, cfg.cardinality)
         out = F.relu(_bn(sd, out, p + ".bn2"))
         out = _bn(sd, _conv(sd, out, p + ".conv3", 1, 0), p + ".bn3")
-    elif cfg.block == "bottleneck":
+    elif cfg.block in ("bottleneck", "wide"):      # WideBottleneck.forward (wideresnet3D.py:86-106) has the same flow
         out = F.relu(_bn(sd, _any_conv(cfg, sd, x, p + ".conv1", 1, 0), p + ".bn1"))
         out = F.relu(_bn(sd, _any_conv(cfg, sd, out, p + ".conv2", stride, 1), p + ".bn2"))
         out = _bn(sd, _any_conv(cfg, sd, out, p + ".conv3", 1, 0), p + ".bn3")

@@ -63,6 +63,14 @@ def import_r2plus1d():
     return importlib.import_module("pretorched.models.r2plus1d")
 
 
+def import_wideresnet3d():
+    """wideresnet3D.py:9 does `from torchvision_models import ...` (absolute)."""
+    ref = import_reference()
+    import importlib
+    sys.modules.setdefault("torchvision_models", ref.models.torchvision_models)
+    return importlib.import_module("pretorched.models.wideresnet3D")
+
+
 def import_trn():
     """trn.py:8 does `import pretrainedmodels` (the upstream name of this package)."""
     ref = import_reference()

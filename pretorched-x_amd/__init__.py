@@ -231,6 +231,21 @@ resnext3d152 = _resnext3d_factory("resnext3d152")
 resnext3d200 = _resnext3d_factory("resnext3d200")
 
 
+def wideresnet3d50(num_classes=400, pretrained="kinetics-400", shortcut_type="B", k=2):
+    """reference wideresnet3D.py:202-210 (module-level upstream; no checkpoint URL is published for it)."""
+    key = "wideresnet3d50" if k == 2 else "wideresnet3d50/k%d" % k
+    if key not in ARCHS:
+        ARCHS[key] = dataclasses.replace(ARCHS["wideresnet3d50"], k=k)
+    model = _build(key, num_classes, shortcut_type)
+    if pretrained is not None:
+        settings = pretrained_settings.get("wideresnet3d50", {}).get(pretrained)
+        if settings is None:
+            raise PtxError("no pretrained weights are published for wideresnet3d50 (the reference's settings table "
+                           "has no entry either)")
+        load_pretrained(model, num_classes, settings)
+    return model
+
+
 def nonlocal_r2plus1d50(num_classes=339):
     """BASELINE.json config 3 ("resnet2p1d50 + NLBlock"): no reference model combines (2+1)D convs
     with NL blocks; this is the composition validated in SURVEY.md row A9 (shortcut 'B')."""
@@ -276,4 +291,4 @@ model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d
                "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
                "resnet101", "resnet152", "trn", "i3d", "resnext3d10", "resnext3d18", "resnext3d34", "resnext3d50",
-               "resnext3d101", "resnext3d152", "resnext3d200"]
+               "resnext3d101", "resnext3d152", "resnext3d200", "wideresnet3d50"]

@@ -12,6 +12,7 @@ Design (MI355X-first, not a translation of the reference's nn.Module graphs):
 
 torch is used for device memory (torch.empty), streams and parameter storage only.
 """
+import collections
 import ctypes as C
 import json
 import os
@@ -507,7 +508,7 @@ class Plan:
         """One residual block.  `out`: optional pre-allocated target (a channel slice of the next
         stage's concatenated input, slowfast.py:145-151) for the block's final conv."""
         s = blk.stride
-        fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block in ("bottleneck", "resnext")
+        fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block in ("bottleneck", "resnext", "wide")
                 and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.downsample[0], (nn.Conv3d, nn.Conv2d)))
         if fuse:
             # conv3 + bn3 and the shortcut conv + bn share the output tile: one GEMM over the
@@ -528,7 +529,7 @@ class Plan:
             res, kind = x, "padA"
         else:
             res, kind = x, None
-        if arch.block in ("bottleneck", "resnext"):
+        if arch.block in ("bottleneck", "resnext", "wide"):
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
             o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
@@ -873,7 +874,10 @@ class Engine:
     caches keyed by device."""
 
     def __init__(self, model=None):
-        self._plans = {}
+        self._plans = collections.OrderedDict()
+        # a plan owns every activation buffer of one (input shape, device): serving with many distinct
+        # shapes must not grow without bound -- least-recently-used plans are dropped beyond this count
+        self.max_plans = int(os.environ.get("PTX_MAX_PLANS", "16"))
         self._lock = threading.RLock()
         self._sig = {}
         self.check_weights = True
@@ -936,6 +940,11 @@ class Engine:
             if fresh:
                 plan = Plan(self, model, shape, x.device, norm)
                 self._plans[key] = plan
+                while len(self._plans) > max(1, self.max_plans):
+                    old, _ = self._plans.popitem(last=False)         # LRU eviction frees the plan's buffers
+                    self._sig.pop(old, None)
+            else:
+                self._plans.move_to_end(key)
             if fresh or self.check_weights:
                 sig = self._signature(model)
                 if fresh or self._sig.get(key) != sig:

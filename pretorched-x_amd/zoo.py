@@ -36,15 +36,18 @@ class Arch:
     head: str = "last_linear"
     dims: int = 3
     cardinality: int = 32            # 'resnext' blocks only (resnext3D.py:126)
+    k: int = 1                       # 'wide' blocks only: width multiplier (wideresnet3D.py:113)
 
     @property
     def expansion(self):
-        return {"bottleneck": 4, "resnext": 2}.get(self.block, 1)
+        return {"bottleneck": 4, "resnext": 2, "wide": 2}.get(self.block, 1)
 
     @property
     def widths(self):
-        """`planes` of the four stages (resnext3D.py:134-137 doubles them)."""
-        return (128, 256, 512, 1024) if self.block == "resnext" else (64, 128, 256, 512)
+        """`planes` of the four stages (resnext3D.py:134-137 doubles them, wideresnet3D.py:125-128 scales by k)."""
+        if self.block == "resnext":
+            return (128, 256, 512, 1024)
+        return tuple(w * self.k for w in (64, 128, 256, 512)) if self.block == "wide" else (64, 128, 256, 512)
 
 
 ARCHS = {
@@ -72,6 +75,8 @@ ARCHS = {
     "resnext3d101": Arch("resnext", (3, 4, 23, 3), "B", head="fc"),
     "resnext3d152": Arch("resnext", (3, 8, 36, 3), "B", head="fc"),
     "resnext3d200": Arch("resnext", (3, 24, 36, 3), "B", head="fc"),
+    # WideResNet-50 3-D (wideresnet3D.py:202-210; module-level upstream, keeps `fc`)
+    "wideresnet3d50": Arch("wide", (3, 4, 6, 3), "B", head="fc", k=2),
     "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
     "resnet34": Arch("basic", (3, 4, 6, 3), "B", dims=2),
     "resnet50": Arch("bottleneck", (3, 4, 6, 3), "B", dims=2),
@@ -135,6 +140,13 @@ def _block(arch, cin, planes, stride, with_down, with_nl):
         blk.conv2 = nn.Conv3d(mid, mid, 3, stride, 1, groups=arch.cardinality, bias=False)
         blk.bn2 = nn.BatchNorm3d(mid)
         blk.conv3 = nn.Conv3d(mid, planes * 2, 1, bias=False)
+        blk.bn3 = nn.BatchNorm3d(planes * 2)
+    elif arch.block == "wide":           # wideresnet3D.py:71-84
+        blk.conv1 = nn.Conv3d(cin, planes, 1, bias=False)
+        blk.bn1 = nn.BatchNorm3d(planes)
+        blk.conv2 = nn.Conv3d(planes, planes, 3, stride, 1, bias=False)
+        blk.bn2 = nn.BatchNorm3d(planes)
+        blk.conv3 = nn.Conv3d(planes, planes * 2, 1, bias=False)
         blk.bn3 = nn.BatchNorm3d(planes * 2)
     elif arch.block == "bottleneck":
         blk.conv1 = _conv(arch, cin, planes, 1)

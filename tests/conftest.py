@@ -53,6 +53,7 @@ GOLDEN_CASES = {
     "resnext3d50_small": ("resnext3d50", dict(num_classes=400)),
     "resnext3d10_odd": ("resnext3d10", dict(num_classes=17)),
     "resnext3d50_full": ("resnext3d50", dict(num_classes=400)),
+    "wideresnet3d50_small": ("wideresnet3d50", dict(num_classes=400, pretrained=None)),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),

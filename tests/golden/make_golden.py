@@ -49,6 +49,7 @@ CASES = {
     "resnext3d50_small": ("resnext3d50", (2, 3, 8, 64, 64), dict(num_classes=400)),
     "resnext3d10_odd": ("resnext3d10", (3, 3, 5, 50, 70), dict(num_classes=17)),
     "resnext3d50_full": ("resnext3d50", (2, 3, 16, 224, 224), dict(num_classes=400)),
+    "wideresnet3d50_small": ("wideresnet3d50", (2, 3, 8, 64, 64), dict(num_classes=400, pretrained=None)),
     # BASELINE.json config 3 at full size (8 x 3 x 32 x 112 x 112): the composite and its two parents
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=400)),
@@ -171,6 +172,8 @@ def main():
             model = composite(**kw)
         elif arch.startswith("r2plus1d"):
             model = getattr(r2, arch)(**kw)
+        elif arch.startswith("wideresnet"):
+            model = getattr(ref_shim.import_wideresnet3d(), arch)(**kw)
         else:
             model = ref.__dict__[arch](**kw)
         model.eval()
@@ -186,7 +189,7 @@ def main():
             g = torch.Generator().manual_seed(X_SEED)
             x = torch.randn(*shape, generator=g)
         with torch.no_grad():
-            if hasattr(model, "features") and not arch.startswith("r2plus1d") and not arch.startswith("resnext"):
+            if hasattr(model, "features") and not arch.startswith(("r2plus1d", "resnext", "wideresnet")):
                 feat = model.features(x)
                 logits = model.logits(feat)
             else:   # R2Plus1D keeps ResNet3D.forward / fc (r2plus1d.py:99-110)

@@ -419,3 +419,16 @@ def test_biggan_generator_parity(ptx, res, ch, batch):
     print("biggan-deep-%d max|d image| = %.3e (pre-tanh range ~%.1f)" % (res, err, BG.pre_tanh(sd, z, sd["shared.weight"][lab]).abs().max().item()))
     with pytest.raises(Exception):
         G(z, G.shared(lab.to(DEV)).cpu())                            # CPU tensors: no fallback
+
+
+def test_plan_cache_is_bounded(ptx):
+    """One plan (and its activation buffers) per input shape, least-recently-used eviction."""
+    model, _ = _build(ptx, "resnet3d10", dict(), 1)
+    eng = model.engine()
+    eng.max_plans = 3
+    outs = {}
+    for t in (4, 5, 6, 7, 4):
+        x = synth_clips(1, t, 32, 3)
+        outs.setdefault(t, []).append(model(x.to(DEV)).cpu())
+        assert len(eng._plans) <= 3
+    assert torch.equal(outs[4][0], outs[4][1])            # a re-compiled plan gives the same answer

@@ -131,6 +131,25 @@ def test_oracle_slowfast_bit_equal_to_reference(fac, block, layers):
 
 
 @needs_ref
+def test_oracle_resnext_and_wide_bit_equal_to_reference(ptx):
+    ref = ref_shim.import_reference()
+    wide = ref_shim.import_wideresnet3d()
+    x = torch.randn(1, 3, 8, 48, 48, generator=torch.Generator().manual_seed(1))
+    for name, build in (("resnext3d10", lambda: ref.resnext3d10(num_classes=9)),
+                        ("resnext3d50", lambda: ref.resnext3d50(num_classes=9, shortcut_type="B")),
+                        ("wideresnet3d50", lambda: wide.wideresnet3d50(num_classes=9, pretrained=None))):
+        m = build()
+        m.eval()
+        sd = synth_state_dict(m.state_dict(), 3)
+        m.load_state_dict(sd)
+        mine = ptx.__dict__[name](num_classes=9, **({"pretrained": None} if name.startswith("wide") else {}))
+        assert [(k, tuple(v.shape)) for k, v in mine.state_dict().items()] == [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        with torch.no_grad():
+            want = m(x)
+        assert torch.equal(OF.forward(OF.ARCHS[name], sd, x), want), name
+
+
+@needs_ref
 def test_oracle_trn_bit_equal_to_reference():
     import types
     ref = ref_shim.import_reference(tv_standin.FACTORIES)
