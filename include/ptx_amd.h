@@ -223,7 +223,8 @@ int ptx_cbn_fold(const float* gain, const float* bias, const float* mean, const 
                  int32_t ld_out, int32_t plus_one, ptx_stream_t stream);
 /* y[n][h][w][c] = act(x[n][h/up][w/up][c] * scale[n][c] + shift[n][c]): the generator's
  * cBN -> ReLU -> nearest-upsample stage in one HBM pass (x NHWC row stride ldx, y row stride ldy;
- * scale/shift rows have stride ld_scale, so every cBN of the network can share one folded table).
+ * scale/shift rows have stride ld_scale, so every cBN of the network can share one folded table; ld_scale = 0:
+ * one row for all samples, i.e. a plain eval-mode BN -> ReLU ahead of a conv, pre_act_resnet3D.py:41-47).
  * act: 0 none, 1 ReLU, 2 tanh (output layer).  scale/shift may be NULL (identity affine). */
 int ptx_affine_act_upsample(const float* x, float* y, const float* scale, const float* shift, int32_t ld_scale,
                             int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, int32_t up,

@@ -45,7 +45,7 @@ class ArchCfg:
     expansion: int = field(init=False)
 
     def __post_init__(self):
-        self.expansion = {"bottleneck": 4, "resnext": 2, "wide": 2}.get(self.block, 1)
+        self.expansion = {"bottleneck": 4, "resnext": 2, "wide": 2, "preact_bottleneck": 4}.get(self.block, 1)
 
     @property
     def widths(self):
@@ -76,6 +76,9 @@ ARCHS = {
     "resnext3d50": ArchCfg("resnext", [3, 4, 6, 3], "B", head="fc"),
     "resnext3d101": ArchCfg("resnext", [3, 4, 23, 3], "B", head="fc"),
     "wideresnet3d50": ArchCfg("wide", [3, 4, 6, 3], "B", head="fc", k=2),
+    "preact_resnet3d10": ArchCfg("preact_basic", [1, 1, 1, 1], "B", head="fc"),
+    "preact_resnet3d18": ArchCfg("preact_basic", [2, 2, 2, 2], "B", head="fc"),
+    "preact_resnet3d50": ArchCfg("preact_bottleneck", [3, 4, 6, 3], "B", head="fc"),
     "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
     "resnet34": ArchCfg("basic", [3, 4, 6, 3], "B", dims=2),
     "resnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", dims=2),
@@ -178,7 +181,28 @@ def nonlocal_block(sd, x, p, mode="embedded_gaussian", sub_sample=False, bn_laye
 # --------------------------------------------------------------------------------------------
 # residual stages
 # --------------------------------------------------------------------------------------------
+def _preact_block(cfg, sd, x, p, planes, stride, has_down):
+    """PreActivationBottleneck.forward (pre_act_resnet3D.py:76-96) / PreActivationBasicBlock.forward (:41-57)."""
+    residual = x
+    out = F.relu(_bn(sd, x, p + ".bn1"))
+    if cfg.block == "preact_bottleneck":
+        out = _conv(sd, out, p + ".conv1", 1, 0)
+        out = _conv(sd, F.relu(_bn(sd, out, p + ".bn2")), p + ".conv2", stride, 1)
+        out = _conv(sd, F.relu(_bn(sd, out, p + ".bn3")), p + ".conv3", 1, 0)
+    else:
+        out = _conv(sd, out, p + ".conv1", stride, 1)
+        out = _conv(sd, F.relu(_bn(sd, out, p + ".bn2")), p + ".conv2", 1, 1)
+    if has_down:
+        if cfg.shortcut == "A":
+            residual = shortcut_a(x, planes * cfg.expansion, stride)
+        else:
+            residual = _bn(sd, _conv(sd, x, p + ".downsample.0", stride, 0), p + ".downsample.1")
+    return out + residual
+
+
 def _block(cfg, sd, x, p, planes, stride, has_down, nl):
+    if cfg.block.startswith("preact"):
+        return _preact_block(cfg, sd, x, p, planes, stride, has_down)
     residual = x
     if cfg.block == "resnext":       # ResNeXtBottleneck.forward, resnext3D.py:101-121
         out = F.relu(_bn(sd, _conv(sd, x, p + ".conv1", 1, 0), p + ".bn1"))

@@ -63,6 +63,14 @@ def import_r2plus1d():
     return importlib.import_module("pretorched.models.r2plus1d")
 
 
+def import_preact():
+    """pre_act_resnet3D.py:8 uses an absolute `import resnet3D`."""
+    ref = import_reference()
+    import importlib
+    sys.modules.setdefault("resnet3D", ref.models.resnet3D)
+    return importlib.import_module("pretorched.models.pre_act_resnet3D")
+
+
 def import_wideresnet3d():
     """wideresnet3D.py:9 does `from torchvision_models import ...` (absolute)."""
     ref = import_reference()

@@ -231,6 +231,24 @@ resnext3d152 = _resnext3d_factory("resnext3d152")
 resnext3d200 = _resnext3d_factory("resnext3d200")
 
 
+def _preact_factory(name):
+    def factory(num_classes=339, shortcut_type="B"):
+        return _build(name, num_classes, shortcut_type)
+    factory.__name__ = name
+    factory.__doc__ = ("Constructs a %s model (reference pretorched/models/pre_act_resnet3D.py:103-142: "
+                       "PreActivationResNet3D(block, layers, **kwargs) over ResNet3D's constructor)." % name)
+    return factory
+
+
+preact_resnet3d10 = _preact_factory("preact_resnet3d10")
+preact_resnet3d18 = _preact_factory("preact_resnet3d18")
+preact_resnet3d34 = _preact_factory("preact_resnet3d34")
+preact_resnet3d50 = _preact_factory("preact_resnet3d50")
+preact_resnet3d101 = _preact_factory("preact_resnet3d101")
+preact_resnet3d152 = _preact_factory("preact_resnet3d152")
+preact_resnet3d200 = _preact_factory("preact_resnet3d200")
+
+
 def wideresnet3d50(num_classes=400, pretrained="kinetics-400", shortcut_type="B", k=2):
     """reference wideresnet3D.py:202-210 (module-level upstream; no checkpoint URL is published for it)."""
     key = "wideresnet3d50" if k == 2 else "wideresnet3d50/k%d" % k
@@ -291,4 +309,5 @@ model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d
                "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
                "resnet101", "resnet152", "trn", "i3d", "resnext3d10", "resnext3d18", "resnext3d34", "resnext3d50",
-               "resnext3d101", "resnext3d152", "resnext3d200", "wideresnet3d50"]
+               "resnext3d101", "resnext3d152", "resnext3d200", "wideresnet3d50", "preact_resnet3d10", "preact_resnet3d18", "preact_resnet3d34",
+               "preact_resnet3d50", "preact_resnet3d101", "preact_resnet3d152", "preact_resnet3d200"]

@@ -529,7 +529,7 @@ extern "C" int ptx_affine_act_upsample(const float* x, float* y, const float* sc
     if (relu < 0 || relu > 2) return fail(PTX_ERR_INVALID, "affine_act_upsample: act must be 0, 1 or 2");
     const int c4 = (C + 3) / 4 * 4;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || up < 1 || up > 8 || ldx < c4 || ldy < c4 || ldx % 4 || ldy % 4 ||
-        (scale && ld_scale < C))
+        (scale && ld_scale != 0 && ld_scale < C))
         return fail(PTX_ERR_INVALID, "affine_act_upsample: bad extents");
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "affine_act_upsample: misaligned pointer");
     const size_t total4 = (size_t)N * H * up * W * up * (c4 / 4);

@@ -508,6 +508,8 @@ class Plan:
         """One residual block.  `out`: optional pre-allocated target (a channel slice of the next
         stage's concatenated input, slowfast.py:145-151) for the block's final conv."""
         s = blk.stride
+        if arch.block.startswith("preact"):
+            return self._block_preact(arch, blk, x, name)
         fuse = (self.fuse_shortcut and blk.has_shortcut and arch.shortcut == "B" and arch.block in ("bottleneck", "resnext", "wide")
                 and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.downsample[0], (nn.Conv3d, nn.Conv2d)))
         if fuse:
@@ -541,6 +543,48 @@ class Plan:
         if blk.has_nl:
             o = self.nonlocal_block(o, blk.nonlocalblock, name + ".nonlocalblock")
         return o
+
+    def bn_relu(self, x, bn, label):
+        """Eval-mode BN -> ReLU as one HBM pass ahead of a conv (pre-activation blocks): the BN is folded to
+        a per-channel affine by ptx_cbn_fold whenever the weights change."""
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        sc, sh = torch.empty(x.C, **f32), torch.empty(x.C, **f32)
+        self.keepalive += [sc, sh]
+        lib, eps, C_ = self.lib, float(bn.eps), x.C
+
+        def refresh():
+            ts = [t.contiguous() for t in (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)]
+            check(lib.ptx_cbn_fold(_ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), C.c_float(eps), _ptr(sc), _ptr(sh),
+                                   1, C_, 0, 0, C_, 0, _stream()), "bn fold " + label)
+        if torch.device(self.dev).type != "meta":
+            self.refreshers.append(refresh)
+        y = self.act(x.N, x.T, x.H, x.W, x.C)
+        xp, yp, scp, shp = _ptr(x.t), _ptr(y.t), _ptr(sc), _ptr(sh)
+        rows, ldx, ldy = x.N * x.T * x.H, x.ld, y.ld
+
+        def step(st):
+            # [N*T*H, W] rows: the kernel's (n, h, w) decomposition only matters for upsampling
+            check(lib.ptx_affine_act_upsample(xp, yp, scp, shp, 0, 1, rows, x.W, C_, ldx, ldy, 1, 1, st), label)
+        self.steps.append(step)
+        return y
+
+    def _block_preact(self, arch, blk, x, name):
+        """pre_act_resnet3D.py:41-57 / :76-96: BN -> ReLU precede every conv, the residual joins un-activated.
+        bn1 reads the block input (which the residual also needs): one affine pass; bn2 / bn3 follow a conv
+        whose output nothing else reads: folded into that conv's filter, ReLU in its epilogue."""
+        s = blk.stride
+        if blk.has_shortcut and arch.shortcut == "B":
+            res, kind = self.conv_bn(x, blk.downsample[0], blk.downsample[1], label=name + ".downsample"), None
+        elif blk.has_shortcut:
+            res, kind = x, "padA"
+        else:
+            res, kind = x, None
+        a = self.bn_relu(x, blk.bn1, name + ".bn1")
+        o = self.conv_bn(a, blk.conv1, blk.bn2, relu=True, label=name + ".conv1")
+        if arch.block == "preact_bottleneck":
+            o = self.conv_bn(o, blk.conv2, blk.bn3, relu=True, label=name + ".conv2")
+            return self.conv_bn(o, blk.conv3, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv3")
+        return self.conv_bn(o, blk.conv2, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv2")
 
     # ---------------------------------------------------------------- SlowFast (slowfast.py:102-398)
     def _build_slowfast(self, model):

@@ -40,7 +40,7 @@ class Arch:
 
     @property
     def expansion(self):
-        return {"bottleneck": 4, "resnext": 2, "wide": 2}.get(self.block, 1)
+        return {"bottleneck": 4, "resnext": 2, "wide": 2, "preact_bottleneck": 4}.get(self.block, 1)
 
     @property
     def widths(self):
@@ -77,6 +77,14 @@ ARCHS = {
     "resnext3d200": Arch("resnext", (3, 24, 36, 3), "B", head="fc"),
     # WideResNet-50 3-D (wideresnet3D.py:202-210; module-level upstream, keeps `fc`)
     "wideresnet3d50": Arch("wide", (3, 4, 6, 3), "B", head="fc", k=2),
+    # pre-activation ResNet3D (pre_act_resnet3D.py:103-142; module-level upstream, keeps `fc`)
+    "preact_resnet3d10": Arch("preact_basic", (1, 1, 1, 1), "B", head="fc"),
+    "preact_resnet3d18": Arch("preact_basic", (2, 2, 2, 2), "B", head="fc"),
+    "preact_resnet3d34": Arch("preact_basic", (3, 4, 6, 3), "B", head="fc"),
+    "preact_resnet3d50": Arch("preact_bottleneck", (3, 4, 6, 3), "B", head="fc"),
+    "preact_resnet3d101": Arch("preact_bottleneck", (3, 4, 23, 3), "B", head="fc"),
+    "preact_resnet3d152": Arch("preact_bottleneck", (3, 8, 36, 3), "B", head="fc"),
+    "preact_resnet3d200": Arch("preact_bottleneck", (3, 24, 36, 3), "B", head="fc"),
     "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
     "resnet34": Arch("basic", (3, 4, 6, 3), "B", dims=2),
     "resnet50": Arch("bottleneck", (3, 4, 6, 3), "B", dims=2),
@@ -141,6 +149,18 @@ def _block(arch, cin, planes, stride, with_down, with_nl):
         blk.bn2 = nn.BatchNorm3d(mid)
         blk.conv3 = nn.Conv3d(mid, planes * 2, 1, bias=False)
         blk.bn3 = nn.BatchNorm3d(planes * 2)
+    elif arch.block == "preact_bottleneck":      # pre_act_resnet3D.py:60-74 (BN precedes each conv)
+        blk.bn1 = nn.BatchNorm3d(cin)
+        blk.conv1 = nn.Conv3d(cin, planes, 1, bias=False)
+        blk.bn2 = nn.BatchNorm3d(planes)
+        blk.conv2 = nn.Conv3d(planes, planes, 3, stride, 1, bias=False)
+        blk.bn3 = nn.BatchNorm3d(planes)
+        blk.conv3 = nn.Conv3d(planes, planes * 4, 1, bias=False)
+    elif arch.block == "preact_basic":           # pre_act_resnet3D.py:27-39
+        blk.bn1 = nn.BatchNorm3d(cin)
+        blk.conv1 = nn.Conv3d(cin, planes, 3, stride, 1, bias=False)
+        blk.bn2 = nn.BatchNorm3d(planes)
+        blk.conv2 = nn.Conv3d(planes, planes, 3, 1, 1, bias=False)
     elif arch.block == "wide":           # wideresnet3D.py:71-84
         blk.conv1 = nn.Conv3d(cin, planes, 1, bias=False)
         blk.bn1 = nn.BatchNorm3d(planes)

@@ -54,6 +54,8 @@ GOLDEN_CASES = {
     "resnext3d10_odd": ("resnext3d10", dict(num_classes=17)),
     "resnext3d50_full": ("resnext3d50", dict(num_classes=400)),
     "wideresnet3d50_small": ("wideresnet3d50", dict(num_classes=400, pretrained=None)),
+    "preact_resnet3d50_small": ("preact_resnet3d50", dict(num_classes=339)),
+    "preact_resnet3d18_odd": ("preact_resnet3d18", dict(num_classes=17, shortcut_type="A")),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),
@@ -63,6 +65,14 @@ TRN_CASES = ("trn_htrn_small", "trn_mstrn_small", "trn_trn_b1")
 SLOWFAST_CASES = ("slowfast50_sf_small", "slowfast50_s_small", "slowfast50_f_small", "slowfast18_sf_small",
                   "slowfast50_sf_full")
 FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3")
+
+
+def oracle_cfg(arch, kw):
+    """The oracle's ArchCfg for a golden case (factory kwargs may override the shortcut type)."""
+    import dataclasses
+    from oracle import functional as OF
+    cfg = OF.ARCHS[arch]
+    return dataclasses.replace(cfg, shortcut=kw["shortcut_type"]) if "shortcut_type" in kw else cfg
 
 
 def golden_recipe(blob):

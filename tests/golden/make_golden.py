@@ -50,6 +50,8 @@ CASES = {
     "resnext3d10_odd": ("resnext3d10", (3, 3, 5, 50, 70), dict(num_classes=17)),
     "resnext3d50_full": ("resnext3d50", (2, 3, 16, 224, 224), dict(num_classes=400)),
     "wideresnet3d50_small": ("wideresnet3d50", (2, 3, 8, 64, 64), dict(num_classes=400, pretrained=None)),
+    "preact_resnet3d50_small": ("preact_resnet3d50", (2, 3, 8, 64, 64), dict(num_classes=339)),
+    "preact_resnet3d18_odd": ("preact_resnet3d18", (3, 3, 5, 50, 70), dict(num_classes=17, shortcut_type="A")),
     # BASELINE.json config 3 at full size (8 x 3 x 32 x 112 x 112): the composite and its two parents
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=400)),
@@ -163,7 +165,7 @@ def main():
 
     # (2+1)D reference models must be *built and run* before any resnet3d* factory patches
     # ResNet3D.forward at class level -- so handle them first.
-    order = sorted(CASES, key=lambda n: 0 if "r2plus1d" in n else 1)
+    order = sorted(CASES, key=lambda n: 0 if ("r2plus1d" in n or "preact" in n) else 1)
     for case in order:
         if only and case not in only:
             continue
@@ -172,6 +174,8 @@ def main():
             model = composite(**kw)
         elif arch.startswith("r2plus1d"):
             model = getattr(r2, arch)(**kw)
+        elif arch.startswith("preact"):
+            model = getattr(ref_shim.import_preact(), arch)(**kw)
         elif arch.startswith("wideresnet"):
             model = getattr(ref_shim.import_wideresnet3d(), arch)(**kw)
         else:
@@ -189,7 +193,7 @@ def main():
             g = torch.Generator().manual_seed(X_SEED)
             x = torch.randn(*shape, generator=g)
         with torch.no_grad():
-            if hasattr(model, "features") and not arch.startswith(("r2plus1d", "resnext", "wideresnet")):
+            if hasattr(model, "features") and not arch.startswith(("r2plus1d", "resnext", "wideresnet", "preact")):
                 feat = model.features(x)
                 logits = model.logits(feat)
             else:   # R2Plus1D keeps ResNet3D.forward / fc (r2plus1d.py:99-110)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import (GOLDEN_CASES, SLOWFAST_CASES, TRN_CASES, golden_input, golden_recipe, golden_slowfast,
-                      golden_trn, load_golden)
+                      golden_trn, load_golden, oracle_cfg)
 from oracle import functional as OF
 from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
@@ -61,7 +61,7 @@ def test_model_parity_small(ptx, case):
     if "features" in blob.files:
         _check(feats, torch.from_numpy(blob["features"]), case + " features vs golden")
     # (b) oracle restatement, same run
-    cfg = OF.ARCHS[arch]
+    cfg = oracle_cfg(arch, kw)
     with torch.no_grad():
         of = OF.features(cfg, sd, x)
         ol = OF.logits(cfg, sd, of)

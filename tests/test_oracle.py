@@ -8,7 +8,7 @@ import json
 import os
 
 from conftest import (GOLDEN, GOLDEN_CASES, SLOWFAST_CASES, TRN_CASES, golden_input, golden_recipe, golden_slowfast,
-                      golden_trn, load_golden)
+                      golden_trn, load_golden, oracle_cfg)
 from oracle import functional as OF
 from oracle import ref_shim, tv_standin
 from pretorched_x_amd.testing import synth_state_dict
@@ -32,7 +32,7 @@ from conftest import FULL_SIZE
 def test_oracle_matches_golden(ptx, case):
     arch, kw = GOLDEN_CASES[case]
     blob = load_golden(case)
-    cfg = OF.ARCHS[arch]
+    cfg = oracle_cfg(arch, kw)
     _, sd = _arch_sd(ptx, arch, kw, golden_recipe(blob))
     x = golden_input(blob)
     with torch.no_grad():
