@@ -13,6 +13,7 @@ Design (MI355X-first, not a translation of the reference's nn.Module graphs):
 torch is used for device memory (torch.empty), streams and parameter storage only.
 """
 import collections
+import contextlib
 import ctypes as C
 import json
 import os
@@ -243,6 +244,8 @@ class Plan:
         self.norm = norm                 # NormDesc when the input is uint8 frames (Engine.forward_frames)
         self.head = None                 # custom classifier tail (two-pathway / per-frame heads)
         self.refreshers = []             # extra weight-derived tables rebuilt with the packed filters
+        self._run_lock = threading.Lock()
+        self._last_done, self._last_stream = None, None
         self.in_ptr2 = C.c_void_p(0)     # second input (BigGAN: class embedding)
         self.lib = _lib.lib()
         self.steps = []          # callables(stream)
@@ -889,6 +892,26 @@ class Plan:
             fn()
         return keep
 
+    @contextlib.contextmanager
+    def exclusive(self):
+        """A plan owns ONE set of activation buffers: concurrent callers (host threads on their own HIP
+        streams, e.g. DataParallel-style workers sharing a device) are serialised -- on the host by a lock,
+        on the device by making this run wait for the event that closed the previous one."""
+        if torch.cuda.is_current_stream_capturing():
+            yield
+            return
+        with self._run_lock:
+            st = torch.cuda.current_stream()
+            if self._last_done is not None and self._last_stream != st.cuda_stream:
+                st.wait_event(self._last_done)
+            try:
+                yield
+            finally:
+                if self._last_done is None:
+                    self._last_done = torch.cuda.Event()
+                self._last_done.record(st)
+                self._last_stream = st.cuda_stream
+
     def run_features(self, x):
         self.in_ptr = _ptr(x)
         st = _stream()
@@ -1008,13 +1031,14 @@ class Engine:
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
-            f = plan.run_features(x)
-            if model.arch.dims == 2:
-                out = torch.empty((f.N, f.C, f.H, f.W), device=x.device, dtype=torch.float32)
-            else:
-                out = torch.empty((f.N, f.C, f.T, f.H, f.W), device=x.device, dtype=torch.float32)
-            check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), f.N, f.C, f.S, f.ld, _stream()),
-                  "ptx_ndhwc_to_ncdhw")
+            with plan.exclusive():
+                f = plan.run_features(x)
+                if model.arch.dims == 2:
+                    out = torch.empty((f.N, f.C, f.H, f.W), device=x.device, dtype=torch.float32)
+                else:
+                    out = torch.empty((f.N, f.C, f.T, f.H, f.W), device=x.device, dtype=torch.float32)
+                check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), f.N, f.C, f.S, f.ld, _stream()),
+                      "ptx_ndhwc_to_ncdhw")
         return out
 
     def _head(self, model, pooled_ptr, N, Cf, dev):
@@ -1093,8 +1117,9 @@ class Engine:
         return g["out"].clone()
 
     def _forward_eager(self, model, plan, x):
-        plan.run_features(x)
-        return plan.run_head(self, model)
+        with plan.exclusive():
+            plan.run_features(x)
+            return plan.run_head(self, model)
 
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""
@@ -1137,9 +1162,12 @@ class Engine:
             plan = self.plan_for(model, z)
             plan.in_ptr2 = _ptr(y)
             self._maybe_tune(model, plan, z)
-            f = plan.run_features(z)
-            out = torch.empty((N, 3, f.H, f.W), device=z.device, dtype=torch.float32)
-            check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), N, 3, f.H * f.W, f.ld, _stream()), "ptx_ndhwc_to_ncdhw")
+            with plan.exclusive():
+                plan.in_ptr2 = _ptr(y)
+                f = plan.run_features(z)
+                out = torch.empty((N, 3, f.H, f.W), device=z.device, dtype=torch.float32)
+                check(_lib.lib().ptx_ndhwc_to_ncdhw(_ptr(f.t), _ptr(out), N, 3, f.H * f.W, f.ld, _stream()),
+                      "ptx_ndhwc_to_ncdhw")
         return out
 
     def forward_frames(self, model, frames, opts=None):

@@ -432,3 +432,33 @@ def test_plan_cache_is_bounded(ptx):
         outs.setdefault(t, []).append(model(x.to(DEV)).cpu())
         assert len(eng._plans) <= 3
     assert torch.equal(outs[4][0], outs[4][1])            # a re-compiled plan gives the same answer
+
+
+def test_concurrent_callers_share_a_plan_safely(ptx):
+    """Host threads on their own HIP streams calling one model with one input shape (a DataParallel-style
+    worker pool on one device): the plan's single buffer set is serialised, every caller gets its own answer."""
+    import threading
+    model, sd = _build(ptx, "resnet3d18", dict(num_classes=50, pretrained=None), 4)
+    xs = [synth_clips(2, 8, 64, 100 + i) for i in range(6)]
+    want = [OF.forward(oracle_cfg("resnet3d18", {}), sd, x) for x in xs]
+    model(xs[0].to(DEV))                                   # compile + tune once
+    torch.cuda.synchronize()
+    got, errs = [None] * len(xs), []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                xd = xs[i].to(DEV, non_blocking=False)
+                for _ in range(5):
+                    out = model(xd)
+                st.synchronize()
+                got[i] = out.cpu()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(xs))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for g, w in zip(got, want):
+        _check(g, w, "concurrent caller")
