@@ -481,12 +481,9 @@ class Plan:
     # ---------------------------------------------------------------- network
     def _build(self, model):
         kind = getattr(model, "plan_kind", "resnet")
-        if kind == "biggan":
-            return self._build_biggan(model)
-        if kind == "slowfast":
-            return self._build_slowfast(model)
-        if kind == "i3d":
-            return self._build_i3d(model)
+        if kind != "resnet":                     # SlowFast / I3D / BigGAN-deep: plans.py
+            from . import plans
+            return getattr(plans, "build_" + kind)(self, model)
         arch = model.arch
         shp = self.shape
         if arch.dims == 2:
@@ -588,286 +585,6 @@ class Plan:
             o = self.conv_bn(o, blk.conv2, blk.bn3, relu=True, label=name + ".conv2")
             return self.conv_bn(o, blk.conv3, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv3")
         return self.conv_bn(o, blk.conv2, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv2")
-
-    # ---------------------------------------------------------------- SlowFast (slowfast.py:102-398)
-    def _build_slowfast(self, model):
-        N, Cin, T, H, W = self.shape
-        arch, mode = model.arch, model.mode
-        pool = ((1, 3, 3), (1, 2, 2), (0, 1, 1))
-        stages = ("res2", "res3", "res4", "res5")
-
-        def out_hw(blk, x):
-            # (1,3,3) pad (0,1,1) conv carrying the block's spatial stride (slowfast.py:16-20,72-74)
-            return (x.H - 1) // blk.stride + 1, (x.W - 1) // blk.stride + 1
-
-        fast_feat = slow_feat = None
-        taps = []                                            # fast activations feeding the lateral convs
-        if mode in ("sf", "f"):
-            fast = model.fast if mode == "sf" else model
-            step = model.fast_stride
-            raw = RawInput(N, Cin, len(range(0, T, step)), H, W, t_step=step, T_full=T, norm=self.norm)
-            f = self.conv_bn(raw, fast.conv1, fast.bn1, relu=True, label="fast.conv1")
-            f = self.maxpool(f, *pool)
-            taps.append(f)
-            for name in stages:
-                for bi, blk in enumerate(getattr(fast, name)):
-                    f = self._block(arch, blk, f, "fast.%s.%d" % (name, bi))
-                taps.append(f)
-            fast_feat = f
-        if mode in ("sf", "s"):
-            slow = model.slow if mode == "sf" else model
-            step = model.slow_stride
-            raw = RawInput(N, Cin, len(range(0, T, step)), H, W, t_step=step, T_full=T, norm=self.norm)
-            s = self.conv_bn(raw, slow.conv1, slow.bn1, relu=True, label="slow.conv1")
-            laterals = ([model.fast.lateral_p1, model.fast.lateral_res2, model.fast.lateral_res3,
-                         model.fast.lateral_res4] if mode == "sf" else None)
-
-            def fuse_lateral(i, main_C, dims):
-                """Allocate cat([main, lateral_i(fast tap i)], dim=1) and emit the lateral conv into its slice."""
-                lat = laterals[i]
-                k, st_, pd = _geom(lat)
-                src = taps[i]
-                lt = ((src.T + 2 * pd[0] - k[0]) // st_[0] + 1, src.H, src.W)
-                if lt != dims:
-                    raise PtxError("SlowFast: lateral %d yields %s but the slow pathway is %s at that stage -- "
-                                   "torch.cat would fail in the reference too (slowfast.py:145-151); the lateral convs "
-                                   "stride time by 8, so slow_stride must be 8 * fast_stride" % (i, lt, dims))
-                cat = self.act(N, dims[0], dims[1], dims[2], main_C + lat.out_channels)
-                self.conv(src, self.pack(lat, None), st_, pd, y=cat.slice(main_C, lat.out_channels),
-                          label="fast.lateral%d" % i)
-                return cat
-
-            if laterals:
-                Ho, Wo = (s.H - 1) // 2 + 1, (s.W - 1) // 2 + 1
-                x = fuse_lateral(0, s.C, (s.T, Ho, Wo))
-                self.maxpool(s, *pool, y=x.slice(0, s.C))
-            else:
-                x = self.maxpool(s, *pool)
-            for si, name in enumerate(stages):
-                blocks = list(getattr(slow, name))
-                for bi, blk in enumerate(blocks):
-                    label = "slow.%s.%d" % (name, bi)
-                    if laterals and bi == len(blocks) - 1 and si < 3:
-                        Ho, Wo = out_hw(blk, x)
-                        cout = blk.out_channels
-                        nxt = fuse_lateral(si + 1, cout, (x.T, Ho, Wo))
-                        self._block(arch, blk, x, label, out=nxt.slice(0, cout))
-                        x = nxt
-                    else:
-                        x = self._block(arch, blk, x, label)
-            slow_feat = x
-        if mode != "sf":
-            self.feat = slow_feat if mode == "s" else fast_feat
-            self.pooled = torch.empty((N, self.feat.C), device=self.dev, dtype=torch.float32)
-            return
-        # two-pathway head: cat([avgpool(slow), avgpool(fast)]) -> dropout (identity) -> last_linear
-        self.feat = slow_feat
-        cs, cf = slow_feat.C, fast_feat.C
-        ps = torch.empty((N, cs), device=self.dev, dtype=torch.float32)
-        pf = torch.empty((N, cf), device=self.dev, dtype=torch.float32)
-        self.pooled = torch.empty((N, cs + cf), device=self.dev, dtype=torch.float32)
-        lib, pooled = self.lib, self.pooled
-
-        def head(engine, model):
-            st = _stream()
-            for f_, p_ in ((slow_feat, ps), (fast_feat, pf)):
-                check(lib.ptx_global_avgpool(_ptr(f_.t), _ptr(p_), f_.N, f_.C, f_.S, f_.ld, 0, st), "ptx_global_avgpool")
-            check(lib.ptx_copy2d(_ptr(ps), _ptr(pooled), N, cs, cs, cs + cf, st), "ptx_copy2d")
-            check(lib.ptx_copy2d(_ptr(pf), _ptr(pooled, cs), N, cf, cf, cs + cf, st), "ptx_copy2d")
-            out = engine._head(model, _ptr(pooled), N, cs + cf, self.dev)
-            return out if out is not None else model.head_module(pooled.clone())
-        self.head = head
-
-    # ---------------------------------------------------------------- I3D (Inception-v1 3-D)
-    def _build_i3d(self, model):
-        N, Cin, T, H, W = self.shape
-        one = (1, 1, 1)
-
-        def unit(x, u, label, y=None):
-            conv = u.conv3d
-            k, s, _ = _geom(conv)
-            bn = u.bn if u.has_bn else None
-            if isinstance(x, RawInput):
-                return self.conv_bn(x, conv, bn, relu=True, label=label)
-            return self.conv(x, self.pack(conv, bn), s, (0, 0, 0), relu=u.has_bn, label=label, y=y, same=True)
-
-        raw = RawInput(N, Cin, T, H, W, norm=self.norm)
-        x = unit(raw, model.Conv3d_1a_7x7, "Conv3d_1a_7x7")
-        x = self.maxpool(x, (1, 3, 3), (1, 2, 2), None, same=True)
-        x = unit(x, model.Conv3d_2b_1x1, "Conv3d_2b_1x1")
-        x = unit(x, model.Conv3d_2c_3x3, "Conv3d_2c_3x3")
-        x = self.maxpool(x, (1, 3, 3), (1, 2, 2), None, same=True)
-        for entry in model.layout:
-            name = entry[0]
-            if name.startswith("pool"):
-                x = self.maxpool(x, entry[1], entry[2], None, same=True)
-                continue
-            m = getattr(model, name)
-            out = self.act(x.N, x.T, x.H, x.W, m.out_channels)
-            c1, c2, c3 = m.splits[0], m.splits[0] + m.splits[1], m.splits[0] + m.splits[1] + m.splits[2]
-            # the four branches write their channel slices of the module output: no torch.cat
-            unit(x, m.b0, name + ".b0", y=out.slice(0, m.splits[0]))
-            unit(unit(x, m.b1a, name + ".b1a"), m.b1b, name + ".b1b", y=out.slice(c1, m.splits[1]))
-            unit(unit(x, m.b2a, name + ".b2a"), m.b2b, name + ".b2b", y=out.slice(c2, m.splits[2]))
-            pooled = self.maxpool(x, (3, 3, 3), one, None, same=True)
-            unit(pooled, m.b3b, name + ".b3b", y=out.slice(c3, m.splits[3]))
-            x = out
-        self.feat = x
-        # head: avg_pool3d([2,7,7], stride 1) -> dropout (identity) -> 1x1x1 conv with bias -> squeeze ->
-        # mean over the remaining time steps
-        if (x.H, x.W) != (7, 7) or x.T < 2:
-            self.head = None
-            self.pooled = None
-            self.head_error = ("I3D head: AvgPool3d([2,7,7]) needs a [T>=2,7,7] Mixed_5c map (224x224 input, >=16 "
-                               "frames); got [%d,%d,%d]" % (x.T, x.H, x.W))
-            return
-        Tf, Cf = x.T, x.C
-        frame_mean = torch.empty((N * Tf, Cf), device=self.dev, dtype=torch.float32)
-        win = torch.empty((N * (Tf - 1), Cf), device=self.dev, dtype=torch.float32)
-        self.pooled = win
-        lib = self.lib
-
-        def head(engine, model):
-            st = _stream()
-            conv = model.head_module
-            if not isinstance(conv, nn.Conv3d):
-                raise PtxError("I3D: model.logits.conv3d must be a 1x1x1 Conv3d")
-            ncls = conv.out_channels
-            check(lib.ptx_global_avgpool(_ptr(x.t), _ptr(frame_mean), N * Tf, Cf, x.H * x.W, x.ld, 0, st),
-                  "ptx_global_avgpool")
-            check(lib.ptx_window_mean(_ptr(frame_mean), _ptr(win), N, Tf, Cf, 2, 1, st), "ptx_window_mean")
-            w = conv.weight.detach().reshape(ncls, Cf).contiguous()
-            b = conv.bias.detach().contiguous() if conv.bias is not None else None
-            per_frame = torch.empty((N * (Tf - 1), ncls), device=self.dev, dtype=torch.float32)
-            check(lib.ptx_linear_fwd(_ptr(win), _ptr(w), _ptr(b) if b is not None else C.c_void_p(0), _ptr(per_frame),
-                                     N * (Tf - 1), Cf, ncls, Cf, ncls, 0, st), "ptx_linear_fwd")
-            out = torch.empty((N, ncls), device=self.dev, dtype=torch.float32)
-            check(lib.ptx_window_mean(_ptr(per_frame), _ptr(out), N, Tf - 1, ncls, Tf - 1, 1, st), "ptx_window_mean")
-            return out
-        self.head = head
-
-    # ---------------------------------------------------------------- BigGAN-deep generator
-    def _build_biggan(self, model):
-        N = self.shape[0]
-        lib, dev = self.lib, self.dev
-        cond_dim, sdim, eps = model.cond_dim, model.shared_dim, float(model.bn_eps)
-        f32 = dict(device=dev, dtype=torch.float32)
-        cond = torch.empty((N, cond_dim), **f32)
-        # every conditional BN of the network, in execution order -> one [sum C] table
-        ccbns = []
-        for stage in model.blocks:
-            for blk in stage:
-                if blk.kind == "gblock":
-                    ccbns += [blk.bn1, blk.bn2, blk.bn3, blk.bn4]
-        offs, tot = {}, 0
-        for bn in ccbns:
-            offs[id(bn)] = tot
-            tot += bn.channels
-        wg, wb = torch.empty((tot, cond_dim), **f32), torch.empty((tot, cond_dim), **f32)
-        mean_all, var_all = torch.empty(tot, **f32), torch.empty(tot, **f32)
-        gain_all, bias_all = torch.empty((N, tot), **f32), torch.empty((N, tot), **f32)
-        scale_all, shift_all = torch.empty((N, tot), **f32), torch.empty((N, tot), **f32)
-        obn = model.output_layer[0]
-        oscale, oshift = torch.empty((N, obn.channels), **f32), torch.empty((N, obn.channels), **f32)
-        bw = model.bottom_width
-        c0 = model.linear.out_features // (bw * bw)
-        w0, b0 = torch.empty((bw * bw * c0, cond_dim), **f32), torch.empty(bw * bw * c0, **f32)
-        self.keepalive += [cond, wg, wb, mean_all, var_all, gain_all, bias_all, scale_all, shift_all, oscale, oshift, w0, b0]
-
-        def refresh_tables():
-            # weight relayout only (concatenation / row permutation), rebuilt when a parameter changes
-            for bn in ccbns:
-                o, c = offs[id(bn)], bn.channels
-                wg[o:o + c].copy_(bn.gain.weight.detach())
-                wb[o:o + c].copy_(bn.bias.weight.detach())
-                mean_all[o:o + c].copy_(bn.stored_mean)
-                var_all[o:o + c].copy_(bn.stored_var)
-            # first Linear emits NCHW-ordered features (c, h, w); permute its rows so it writes NHWC directly
-            w0.copy_(model.linear.weight.detach().view(c0, bw, bw, cond_dim).permute(1, 2, 0, 3).reshape(-1, cond_dim))
-            b0.copy_(model.linear.bias.detach().view(c0, bw, bw).permute(1, 2, 0).reshape(-1))
-        if torch.device(dev).type != "meta":
-            self.refreshers.append(refresh_tables)
-
-        def prologue(st, self=self):
-            # y = cat([shared(labels), z], 1); all cBN gains/biases in two GEMVs; fold with the stored statistics
-            check(lib.ptx_copy2d(self.in_ptr2, _ptr(cond), N, sdim, sdim, cond_dim, st), "cond.y")
-            check(lib.ptx_copy2d(self.in_ptr, _ptr(cond, sdim), N, cond_dim - sdim, cond_dim - sdim, cond_dim, st), "cond.z")
-            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(wg), None, _ptr(gain_all), N, cond_dim, tot, cond_dim, tot, 0, st), "cbn.gain")
-            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(wb), None, _ptr(bias_all), N, cond_dim, tot, cond_dim, tot, 0, st), "cbn.bias")
-            check(lib.ptx_cbn_fold(_ptr(gain_all), _ptr(bias_all), _ptr(mean_all), _ptr(var_all), C.c_float(eps),
-                                   _ptr(scale_all), _ptr(shift_all), N, tot, tot, tot, tot, 1, st), "cbn.fold")
-            check(lib.ptx_cbn_fold(_ptr(obn.gain.detach()), _ptr(obn.bias.detach()), _ptr(obn.stored_mean),
-                                   _ptr(obn.stored_var), C.c_float(eps), _ptr(oscale), _ptr(oshift), N, obn.channels, 0, 0,
-                                   obn.channels, 0, st), "bn.fold")
-        self.steps.append(prologue)
-
-        h = self.act(N, 1, bw, bw, c0)
-
-        def first_linear(st, hp=_ptr(h.t)):
-            check(lib.ptx_linear_fwd(_ptr(cond), _ptr(w0), _ptr(b0), hp, N, cond_dim, bw * bw * c0, cond_dim, bw * bw * c0,
-                                     0, st), "linear")
-        self.steps.append(first_linear)
-
-        def affine(x, sc, sh, ld_s, up, act=1):
-            y = self.act(N, 1, x.H * up, x.W * up, x.C)
-            xp, yp, H_, W_, C_, ldx, ldy = _ptr(x.t), _ptr(y.t), x.H, x.W, x.C, x.ld, y.ld
-
-            def step(st):
-                check(lib.ptx_affine_act_upsample(xp, yp, sc, sh, ld_s, N, H_, W_, C_, ldx, ldy, up, act, st),
-                      "ptx_affine_act_upsample")
-            self.steps.append(step)
-            return y
-
-        def cbn(x, bn, up=1):
-            o = offs[id(bn)]
-            return affine(x, _ptr(scale_all, o), _ptr(shift_all, o), tot, up)
-
-        one, zero = (1, 1, 1), (0, 0, 0)
-        for si, stage in enumerate(model.blocks):
-            for bi, blk in enumerate(stage):
-                name = "blocks.%d.%d" % (si, bi)
-                if blk.kind == "gblock":
-                    up = 2 if blk.upsample else 1
-                    t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None), one, zero, label=name + ".conv1")
-                    t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None), one, (0, 1, 1), label=name + ".conv2")
-                    t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None), one, (0, 1, 1), label=name + ".conv3")
-                    if up == 1 and blk.in_channels == blk.out_channels:
-                        h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, label=name + ".conv4")
-                    else:   # skip = upsample(x[:, :Cout]) gathered in the epilogue
-                        h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, res_kind="up",
-                                      res_stride=(0, up // 2, up // 2), label=name + ".conv4")
-                else:
-                    h = self._biggan_attention(h, blk, name)
-        a = affine(h, _ptr(oscale), _ptr(oshift), obn.channels, 1)
-        img = self.conv(a, self.pack(model.output_layer[2], None), one, (0, 1, 1), label="output_layer.2")
-        self.feat = affine(img, None, None, 0, 1, act=2)            # tanh
-        self.pooled = None
-
-    def _biggan_attention(self, x, att, name):
-        """layers.Attention: theta^T phi over 2x2-max-pooled keys, softmax, values g, output conv * gamma + x."""
-        lib = self.lib
-        N, HW = x.N, x.H * x.W
-        c8, c2 = att.ch // 8, att.ch // 2
-        one, zero = (1, 1, 1), (0, 0, 0)
-        tpg = self.conv(x, self.pack([att.theta, att.phi, att.g], None), one, zero, label=name + ".theta_phi_g")
-        phi = self.maxpool(tpg.slice(c8, c8), (1, 2, 2), (1, 2, 2), (0, 0, 0))
-        g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
-        S4 = HW // 4
-        ldf = _r4(S4)
-        f = torch.empty((N, HW, ldf), device=self.dev, dtype=torch.float32)
-        gT = torch.empty((N, c2, ldf), device=self.dev, dtype=torch.float32)
-        yatt = self.act(N, 1, x.H, x.W, c2)
-        self.keepalive += [f, gT]
-        th, ph, gp, fp, gtp, yp = _ptr(tpg.t), _ptr(phi.t), _ptr(g.t), _ptr(f), _ptr(gT), _ptr(yatt.t)
-        ld3, ldp, ldg, yld = tpg.ld, phi.ld, g.ld, yatt.ld
-
-        def step(st):
-            check(lib.ptx_bgemm_nt(th, ph, fp, N, HW, S4, c8, ld3, ldp, ldf, HW * ld3, S4 * ldp, HW * ldf, st), "attn f")
-            check(lib.ptx_softmax_rows(fp, N * HW, S4, ldf, 0, st), "attn softmax")
-            check(lib.ptx_transpose_last2(gp, gtp, N, S4, c2, ldg, ldf, st), "attn g^T")
-            check(lib.ptx_bgemm_nt(fp, gtp, yp, N, HW, c2, S4, ldf, ldf, yld, HW * ldf, c2 * ldf, HW * yld, st), "attn y")
-        self.steps.append(step)
-        return self.conv(yatt, self.pack(att.o, None, scale=att.gamma), one, zero, res=x, label=name + ".o")
 
     # ---------------------------------------------------------------- running
     def run_head(self, engine, model):
