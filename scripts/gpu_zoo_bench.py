@@ -9,7 +9,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import pretorched_x_amd as ptx  # noqa: E402
 from pretorched_x_amd.testing import BIGGAN_RECIPE, I3D_RECIPE, synth_state_dict  # noqa: E402
 
@@ -110,4 +111,4 @@ for name, build, recipe, shape in CASES:
     torch.cuda.empty_cache()
 json.dump(dict(peak_tflops=157.3, note="clips (videos / images for TRN / 2-D) per second on one MI355X, fp32 MFMA; "
                "FLOPs = 2 x MACs of the plan's conv launches; cpu_units_per_s = oracle/ (CPU restatement of the "
-               "reference path) on a 2-unit sample of the same workload", rows=rows), open("gpurun_out/zoo_bench.json", "w"), indent=1)
+               "reference path) on a 2-unit sample of the same workload", rows=rows), open(os.path.join(ROOT, "gpurun_out", "zoo_bench.json"), "w"), indent=1)
