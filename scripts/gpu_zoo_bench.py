@@ -26,6 +26,8 @@ CASES = [
     ("i3d batch 8", lambda: ptx.i3d(400), I3D_RECIPE, (8, 3, 64, 224, 224)),
     ("resnet3d101", lambda: ptx.resnet3d101(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
     ("resnext3d101", lambda: ptx.resnext3d101(num_classes=400), dict(last_bn_damp=2.0), (8, 3, 16, 224, 224)),
+    ("wideresnet3d50", lambda: ptx.wideresnet3d50(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
+    ("preact_resnet3d50", lambda: ptx.preact_resnet3d50(num_classes=339), {}, (8, 3, 16, 224, 224)),
     ("resnet3d18", lambda: ptx.resnet3d18(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
     ("resnet50 2-D", lambda: ptx.resnet50(num_classes=1000, pretrained=None), dict(last_bn_damp=0.7), (64, 3, 224, 224)),
     ("biggan-deep-256 G (cfg5, fp32)", lambda: ptx.biggan_deep(256), BIGGAN_RECIPE, (64, 128)),
@@ -39,7 +41,8 @@ from oracle import biggan_standin as BG, i3d_standin as I3  # noqa: E402
 def _cpu_fn(name, sd):
     if "cfg3" in name:
         return lambda x: OF.forward(OF.ARCHS["nonlocal_r2plus1d50"], sd, x)
-    for arch in ("r2plus1d50", "nonlocalresnet3d50", "resnet3d101", "resnet3d18", "resnext3d101"):
+    for arch in ("r2plus1d50", "nonlocalresnet3d50", "resnet3d101", "resnet3d18", "resnext3d101", "wideresnet3d50",
+                 "preact_resnet3d50"):
         if name.startswith(arch):
             return lambda x, a=arch: OF.forward(OF.ARCHS[a], sd, x)
     if name.startswith("slowfast"):
