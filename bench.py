@@ -9,6 +9,11 @@ clips per GPU, clips/sec + max|dlogits| vs the CPU path.
 One process per GPU; a step = one forward of this rank's 8 clips (inputs resident in HBM) plus,
 for N > 1, the single all-gather of logits (RCCL).  Weak scaling: 8 clips per GPU.
 Rank 0 prints ONE JSON line.
+
+`--workload` selects another BASELINE.json configuration through the same harness (same JSON schema;
+the default, and what the driver runs, is config 2):
+    cfg1  resnet18 2-D, 1x3x224x224 (plumbing case)      cfg3  (2+1)D-50 + NL blocks, 8x3x32x112x112
+    cfg4  I3D, 2x3x64x224x224 per GPU (16 clips / 8 GPUs)  cfg5  BigGAN-deep-256 generator, batch 64 (fp32 path)
 """
 import argparse
 import json
@@ -26,6 +31,40 @@ GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
+def other_workload(name, rank):
+    """(model, state_dict, cpu input, forward(model, device input), cpu oracle fn, units per GPU, unit, label)
+    for the non-headline BASELINE.json configurations."""
+    import pretorched_x_amd as ptx
+    from oracle import functional as OF
+    from pretorched_x_amd.testing import BIGGAN_RECIPE, I3D_RECIPE, synth_state_dict
+    g = torch.Generator().manual_seed(99 + rank)
+    if name == "cfg1":
+        m, recipe, x = ptx.resnet18(num_classes=1000, pretrained=None), {}, torch.randn(1, 3, 224, 224, generator=g)
+        return m, recipe, x, None, lambda sd, x: OF.forward(OF.ARCHS["resnet18"], sd, x), "images", \
+            "resnet18 2-D forward, 1x3x224x224 (config 1; arithmetic reference = torchvision stand-in, parity unpinned)"
+    if name == "cfg3":
+        m, recipe = ptx.nonlocal_r2plus1d50(339), dict(inner_bn_damp=0.9, nl_bn_damp=0.05)
+        x = torch.randn(8, 3, 32, 112, 112, generator=g)
+        return m, recipe, x, None, lambda sd, x: OF.forward(OF.ARCHS["nonlocal_r2plus1d50"], sd, x), "clips", \
+            "resnet2p1d50 + NL blocks forward, 8x3x32x112x112 synthetic clips per GPU (config 3)"
+    if name == "cfg4":
+        from oracle import i3d_standin as I3
+        m, recipe, x = ptx.i3d(400), I3D_RECIPE, torch.randn(2, 3, 64, 224, 224, generator=g)
+        return m, recipe, x, None, lambda sd, x: I3.forward(sd, x), "clips", \
+            "I3D (InceptionV1-3D) forward, 2x3x64x224x224 synthetic clips per GPU = 16 over 8 GPUs (config 4; parity unpinned)"
+    if name == "cfg5":
+        from oracle import biggan_standin as BG
+        m, recipe = ptx.biggan_deep(256), BIGGAN_RECIPE
+        z = torch.randn(64, 128, generator=g)
+        lab = torch.randint(0, 1000, (64,), generator=g)
+
+        def fwd(model, zd, lab=lab):
+            return model(zd, model.shared(lab.to(zd.device)))
+        return m, recipe, z, fwd, lambda sd, z: BG.forward(sd, z, sd["shared.weight"][lab[:z.shape[0]]]), "images", \
+            "BigGAN-deep-256 generator, batch 64 z ~ N(0,1) + class labels per GPU, fp32 MFMA path (config 5; parity unpinned)"
+    raise SystemExit("unknown workload %r" % name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,6 +73,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -53,25 +93,40 @@ def main():
     from pretorched_x_amd.parallel import gather_logits
     from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
-    model = ptx.__dict__["resnet3d50"](num_classes=CLASSES, pretrained=None)
-    sd = synth_state_dict(model.state_dict(), 1234)
+    headline = args.workload == "cfg2"
+    fwd, unit, units_per_gpu = None, "clips", CLIPS_PER_GPU
+    if headline:
+        model = ptx.__dict__["resnet3d50"](num_classes=CLASSES, pretrained=None)
+        sd = synth_state_dict(model.state_dict(), 1234)
+        x_cpu = synth_clips(CLIPS_PER_GPU, FRAMES, SIZE, 99 + rank)       # per-rank clips
+        from oracle import functional as OF_
+        cpu_fn = lambda sd_, x_: OF_.forward(OF_.ARCHS["resnet3d50"], sd_, x_)   # noqa: E731
+        label = ("resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
+                 "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE))
+    else:
+        model, recipe, x_cpu, fwd, cpu_fn, unit, label = other_workload(args.workload, rank)
+        sd = synth_state_dict(model.state_dict(), 1234, **recipe)
+        units_per_gpu = x_cpu.shape[0]
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.engine().check_weights = True
-    x_cpu = synth_clips(CLIPS_PER_GPU, FRAMES, SIZE, 99 + rank)       # per-rank clips
     x = x_cpu.to(dev)
+    run = (lambda: model(x)) if fwd is None else (lambda: fwd(model, x))
 
     eng = model.engine()
     if not args.no_autotune:
-        eng.autotune(model, x, iters=2, verbose=args.verbose and rank == 0)
-        if rank == 0 and os.environ.get("PTX_TUNED_OUT"):
+        if headline:
+            eng.autotune(model, x, iters=2, verbose=args.verbose and rank == 0)
+        else:
+            run()                                  # first call compiles the plan and times untuned tiles
+        if headline and rank == 0 and os.environ.get("PTX_TUNED_OUT"):
             from pretorched_x_amd.engine import save_tuned_table
             save_tuned_table(os.environ["PTX_TUNED_OUT"])
 
     def step():
-        out = model(x)
-        if world > 1:
-            out = gather_logits(out, total=CLIPS_PER_GPU * world)
+        out = run()
+        if world > 1 and out.dim() == 2:           # class logits: the path's one collective (images stay sharded)
+            out = gather_logits(out, total=units_per_gpu * world)
         return out
 
     for _ in range(args.warmup):
@@ -94,12 +149,13 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
-    clips_per_s = CLIPS_PER_GPU * world * args.steps / elapsed
+    clips_per_s = units_per_gpu * world * args.steps / elapsed
 
     result = None
     if rank == 0:
         # ---- per-kernel roofline: every conv launch timed with HIP events on the launch stream ----
-        rows = eng.profile_convs(model, x, iters=5)
+        plan = list(eng._plans.values())[-1]
+        rows = eng.profile_convs(model, x, iters=5, plan=plan)
         by_kernel = {}
         for label, macs, ms, cfg, split in rows:
             k = by_kernel.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
@@ -140,7 +196,8 @@ def main():
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
         }
-        net_tf = GFLOP_PER_CLIP * 1e9 * clips_per_s / world / 1e12
+        gflop_per_unit = GFLOP_PER_CLIP if headline else sum(2e-9 * r[1] for r in rows) / plan.shape[0]
+        net_tf = gflop_per_unit * 1e9 * clips_per_s / world / 1e12
         roofline_net = {"bound": "mfma", "achieved": round(net_tf, 2), "peak": PEAK_F32_MFMA_TF,
                         "unit": "TFLOP/s", "frac": round(net_tf / PEAK_F32_MFMA_TF, 4),
                         "conv_ms_sum": round(conv_ms, 3),
@@ -151,9 +208,9 @@ def main():
         cpu = None
         parity = None
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
-            from oracle import functional as OF
-            cfg = OF.ARCHS["resnet3d50"]
             ncpu = os.cpu_count() or 1
+            # bounded sample: the full batch for config 2, at most 2 units for the heavier configurations
+            xs = x_cpu if headline else x_cpu[:min(2, units_per_gpu)]
             # pick the thread count that runs the reference path fastest on this host (SMT
             # oversubscription makes oneDNN conv3d collapse), then time it: bounded to ~30 s
             cands = sorted({c for c in (16, 32, 64, 128, ncpu // 2) if 1 <= c <= ncpu})
@@ -162,7 +219,7 @@ def main():
             for n in cands:
                 torch.set_num_threads(n)
                 t1 = time.perf_counter()
-                want = OF.forward(cfg, sd, x_cpu)
+                want = cpu_fn(sd, xs)
                 dt = time.perf_counter() - t1
                 if best_t is None or dt < best_t:
                     best_t, best_n = dt, n
@@ -172,25 +229,27 @@ def main():
             times = [best_t]
             while len(times) < 4 and time.perf_counter() < deadline:
                 t1 = time.perf_counter()
-                OF.forward(cfg, sd, x_cpu)
+                cpu_fn(sd, xs)
                 times.append(time.perf_counter() - t1)
             med = sorted(times)[len(times) // 2]
-            cpu = {"value": round(CLIPS_PER_GPU / med, 3), "unit": "clips/s", "cores": best_n,
-                   "kind": "port", "sample": "%d timed forwards of the full 8x3x16x224x224 batch (median), "
-                   "oracle/functional.py (torch CPU fp32, oneDNN) on %d of %d host threads" % (len(times), best_n, ncpu)}
-            got = model(x).cpu()
+            cpu = {"value": round(xs.shape[0] / med, 3), "unit": "%s/s" % unit, "cores": best_n,
+                   "kind": "port", "sample": "%d timed forwards of %s (median), oracle/ (torch CPU fp32, oneDNN) on %d of "
+                   "%d host threads" % (len(times), "the full 8x3x16x224x224 batch" if headline else
+                                        "%d of the %d %s of a step" % (xs.shape[0], units_per_gpu, unit), best_n, ncpu)}
+            got = run().cpu()[:xs.shape[0]]
             parity = {"max_abs_dlogits": float((got - want).abs().max().item()),
                       "max_abs_logit": float(want.abs().max().item()),
-                      "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))), "tolerance": 1e-3}
+                      "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
+                      "tolerance": 1e-3}
 
         result = {
-            "metric": "clips/sec, resnet3d50 forward 8x3x16x224x224 per GPU (+ max|dlogits| vs CPU)",
-            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "metric": ("clips/sec, resnet3d50 forward 8x3x16x224x224 per GPU (+ max|dlogits| vs CPU)" if headline else
+                       "%s/sec, %s (+ max|d output| vs CPU)" % (unit, args.workload)),
+            "value": round(clips_per_s, 2), "unit": "%s/s" % unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
-                                   "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE),
-                       "clips_per_gpu": CLIPS_PER_GPU, "global_batch": CLIPS_PER_GPU * world,
+            "config": {"workload": label,
+                       "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
             "roofline": roofline, "roofline_net": roofline_net, "cpu_baseline": cpu, "parity": parity,
         }

@@ -1017,13 +1017,15 @@ class Engine:
             save_tuned_table()
         return plan
 
-    def profile_convs(self, model, x, iters=5):
-        """Per-conv-launch timing with HIP events on the current stream (for bench.py's roofline)."""
-        self._validate(model, x, model.arch.dims)
+    def profile_convs(self, model, x, iters=5, plan=None):
+        """Per-conv-launch timing with HIP events on the current stream (for bench.py's roofline).  `plan`:
+        an already compiled (and run) plan, for models whose input is not one NCDHW tensor."""
         rows = []
         with torch.cuda.device(x.device):
-            plan = self.plan_for(model, x.contiguous())
-            plan.run_features(x.contiguous())
+            if plan is None:
+                self._validate(model, x, model.arch.dims)
+                plan = self.plan_for(model, x.contiguous())
+                plan.run_features(x.contiguous())
             for stp in plan.conv_steps:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 stp(_stream())
