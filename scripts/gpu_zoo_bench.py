@@ -112,6 +112,9 @@ for name, build, recipe, shape in CASES:
         rows[-1]["conv_launches"], "-" if cpu_units is None else "%.2f" % cpu_units, CPU_THREADS), flush=True)
     del m, x, y
     torch.cuda.empty_cache()
+if os.environ.get("PTX_TUNED_OUT"):               # every tile choice made in this process (all models) -> one table
+    from pretorched_x_amd.engine import save_tuned_table
+    save_tuned_table(os.environ["PTX_TUNED_OUT"])
 json.dump(dict(peak_tflops=157.3, note="clips (videos / images for TRN / 2-D) per second on one MI355X, fp32 MFMA; "
                "FLOPs = 2 x MACs of the plan's conv launches; cpu_units_per_s = oracle/ (CPU restatement of the "
                "reference path) on a 2-unit sample of the same workload", rows=rows), open(os.path.join(ROOT, "gpurun_out", "zoo_bench.json"), "w"), indent=1)
