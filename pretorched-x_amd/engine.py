@@ -450,37 +450,61 @@ class Plan:
         return y
 
     def nonlocal_block(self, x, nl, label):
-        """Embedded-gaussian non-local block (nonlocalnet.py:143-166): fused g/theta/phi projection,
-        f = theta^T phi, row softmax, y = f g, W projection + BN + residual."""
-        if getattr(nl, "mode", "embedded_gaussian") != "embedded_gaussian":
-            raise PtxError("only the embedded_gaussian non-local mode is implemented on the HIP path")
+        """Non-local block (nonlocalnet.py:139-243): pointwise projections in one launch, f = theta^T phi on
+        MFMA, row softmax (or 1/N scaling), y = f g on MFMA, W projection (+BN) + residual in one launch.
+        Modes: embedded_gaussian (:143-166), dot_product (:192-211, f / N), gaussian (:168-190, theta = phi = x);
+        `sub_sample` max-pools phi and g 2x2x2 (:126-131).  concatenation (:213-243) is not on the HIP path."""
+        mode = getattr(nl, "mode", "embedded_gaussian")
+        sub = bool(getattr(nl, "sub_sample", False))
+        if mode not in ("embedded_gaussian", "dot_product", "gaussian"):
+            raise PtxError("non-local mode %r is not implemented on the HIP path (embedded_gaussian, dot_product, "
+                           "gaussian are)" % mode)
         lib = self.lib
-        ci = nl.g.out_channels
-        S = x.S
-        one = (1, 1, 1)
-        zero = (0, 0, 0)
-        tpg = self.conv(x, self.pack([nl.theta, nl.phi, nl.g], None), one, zero, label=label + ".theta_phi_g")
-        ldf = _r4(S)
-        f = torch.empty((x.N, S, ldf), device=self.dev, dtype=torch.float32)
-        gT = torch.empty((x.N, ci, ldf), device=self.dev, dtype=torch.float32)
+        first = (lambda m: m[0]) if sub else (lambda m: m)        # Sequential(conv, max_pool) when sub-sampling
+        g_conv = first(nl.g)
+        ci = g_conv.out_channels
+        one, zero = (1, 1, 1), (0, 0, 0)
+        if mode == "gaussian":
+            g_act = self.conv(x, self.pack(g_conv, None), one, zero, label=label + ".g")
+            th_act = ph_act = x                                   # theta = phi = the input itself
+        else:
+            tpg = self.conv(x, self.pack([nl.theta, first(nl.phi), g_conv], None), one, zero, label=label + ".theta_phi_g")
+            th_act, ph_act, g_act = tpg.slice(0, ci), tpg.slice(ci, ci), tpg.slice(2 * ci, ci)
+        if sub:
+            pool = ((2, 2, 2), (2, 2, 2), (0, 0, 0))          # nn.MaxPool3d(kernel_size=2): stride 2, floor
+            if min(x.T, x.H, x.W) < 2:
+                raise PtxError("%s: sub_sample needs at least 2 positions along T, H and W" % label)
+            ph_act = self.maxpool(ph_act, *pool)
+            g_act = self.maxpool(g_act, *pool)
+        N, Sq, Sk, K = x.N, x.S, ph_act.S, th_act.C
+        ldf = _r4(Sk)
+        f = torch.empty((N, Sq, ldf), device=self.dev, dtype=torch.float32)
+        gT = torch.empty((N, ci, ldf), device=self.dev, dtype=torch.float32)
         yatt = self.act(x.N, x.T, x.H, x.W, ci)
         self.keepalive += [f, gT]
-        N, ld3 = x.N, tpg.ld
-        th, ph, gp = _ptr(tpg.t, 0), _ptr(tpg.t, ci), _ptr(tpg.t, 2 * ci)
-        fp, gtp, yp = _ptr(f), _ptr(gT), _ptr(yatt.t)
-        yld = yatt.ld
+        th, ph, gp = _ptr(th_act.t), _ptr(ph_act.t), _ptr(g_act.t)
+        lda, ldb, ldg = th_act.ld, ph_act.ld, g_act.ld
+        fp, gtp, yp, yld = _ptr(f), _ptr(gT), _ptr(yatt.t), yatt.ld
+        scale_only = int(mode == "dot_product")
 
         def step(st):
-            check(lib.ptx_bgemm_nt(th, ph, fp, N, S, S, ci, ld3, ld3, ldf, S * ld3, S * ld3, S * ldf, st), "bgemm f")
-            check(lib.ptx_softmax_rows(fp, N * S, S, ldf, 0, st), "softmax")
-            check(lib.ptx_transpose_last2(gp, gtp, N, S, ci, ld3, ldf, st), "transpose g")
-            check(lib.ptx_bgemm_nt(fp, gtp, yp, N, S, ci, S, ldf, ldf, yld, S * ldf, ci * ldf, S * yld, st), "bgemm y")
+            check(lib.ptx_bgemm_nt(th, ph, fp, N, Sq, Sk, K, lda, ldb, ldf, Sq * lda, Sk * ldb, Sq * ldf, st), "bgemm f")
+            check(lib.ptx_softmax_rows(fp, N * Sq, Sk, ldf, scale_only, st), "softmax")
+            check(lib.ptx_transpose_last2(gp, gtp, N, Sk, ci, ldg, ldf, st), "transpose g")
+            check(lib.ptx_bgemm_nt(fp, gtp, yp, N, Sq, ci, Sk, ldf, ldf, yld, Sq * ldf, ci * ldf, Sq * yld, st), "bgemm y")
         self.steps.append(step)
-        return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
+        if getattr(nl, "bn_layer", True):
+            return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
+        return self.conv(yatt, self.pack(nl.W, None), one, zero, res=x, label=label + ".W")
 
     # ---------------------------------------------------------------- network
     def _build(self, model):
         kind = getattr(model, "plan_kind", "resnet")
+        if kind == "nlblock":                    # a standalone NonLocalBlock3D: [B,C,T,H,W] -> [B,C,T,H,W]
+            N, Cc, T, H, W = self.shape
+            self.feat = self.nonlocal_block(self.to_channels_last(RawInput(N, Cc, T, H, W)), model, "nl")
+            self.pooled = None
+            return
         if kind != "resnet":                     # SlowFast / I3D / BigGAN-deep: plans.py
             from . import plans
             return getattr(plans, "build_" + kind)(self, model)

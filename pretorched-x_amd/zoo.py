@@ -139,6 +139,54 @@ def _nonlocal(channels):
     return nl
 
 
+class NonLocalBlock3D(nn.Module):
+    """Standalone non-local block with the reference's constructor and parameter names
+    (nonlocalnet.py:51-131, :264-270): z = W(y) + x over [B,C,T,H,W].  HIP path: modes embedded_gaussian,
+    dot_product and gaussian, with or without `sub_sample` / `bn_layer`; 'concatenation' raises."""
+    plan_kind = "nlblock"
+
+    def __init__(self, in_channels, inter_channels=None, mode="embedded_gaussian", sub_sample=False, bn_layer=True):
+        super().__init__()
+        assert mode in ["embedded_gaussian", "gaussian", "dot_product", "concatenation"]
+        self.mode, self.dimension, self.sub_sample, self.bn_layer = mode, 3, sub_sample, bn_layer
+        self.in_channels = in_channels
+        self.inter_channels = inter_channels if inter_channels is not None else max(in_channels // 2, 1)
+        ci = self.inter_channels
+        self.arch = Arch("nlblock", (), "B")
+        self.g = nn.Conv3d(in_channels, ci, 1)
+        if bn_layer:
+            self.W = nn.Sequential(nn.Conv3d(ci, in_channels, 1), nn.BatchNorm3d(in_channels))
+            nn.init.constant_(self.W[1].weight, 0)
+            nn.init.constant_(self.W[1].bias, 0)
+        else:
+            self.W = nn.Conv3d(ci, in_channels, 1)
+            nn.init.constant_(self.W.weight, 0)
+            nn.init.constant_(self.W.bias, 0)
+        self.theta = self.phi = self.concat_project = None
+        if mode in ("embedded_gaussian", "dot_product", "concatenation"):
+            self.theta = nn.Conv3d(in_channels, ci, 1)
+            self.phi = nn.Conv3d(in_channels, ci, 1)
+            if mode == "concatenation":
+                self.concat_project = nn.Sequential(nn.Conv2d(ci * 2, 1, 1, 1, 0, bias=False), nn.ReLU())
+        if sub_sample:
+            self.g = nn.Sequential(self.g, nn.MaxPool3d(kernel_size=2))
+            self.phi = nn.MaxPool3d(kernel_size=2) if self.phi is None else nn.Sequential(self.phi, nn.MaxPool3d(kernel_size=2))
+        self.eval()
+        self._engine = Engine()
+
+    def forward(self, x):
+        return self._engine.features(self, x)
+
+    def engine(self):
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if "_engine" in self.__dict__:
+            self._engine.invalidate()
+        return r
+
+
 def _block(arch, cin, planes, stride, with_down, with_nl):
     blk = Bag()
     if arch.block == "resnext":          # resnext3D.py:76-99

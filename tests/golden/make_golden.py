@@ -222,9 +222,32 @@ def main():
 
     if not only or "trn" in only:
         make_trn(ref, trn, keys_out)
+    if not only or "nlblock" in only:
+        make_nlblock(ref, keys_out)
     if not only or any(c.startswith("slowfast") for c in only):
         make_slowfast(ref, keys_out, only)
     json.dump(keys_out, open(keys_path, "w"))
+
+
+NL_CASES = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
+            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]
+
+
+def make_nlblock(ref, keys_out):
+    """Standalone NonLocalBlock3D (nonlocalnet.py:264-270) in every mode the HIP path runs."""
+    nl = ref.models.nonlocalnet
+    x = torch.randn(2, 16, 4, 8, 6, generator=torch.Generator().manual_seed(X_SEED))
+    blob = dict(shape=np.array(x.shape), w_seed=W_SEED, x_seed=X_SEED)
+    for mode, sub, bn in NL_CASES:
+        blk = nl.NonLocalBlock3D(16, mode=mode, sub_sample=sub, bn_layer=bn).eval()
+        sd = synth_state_dict(blk.state_dict(), W_SEED)
+        blk.load_state_dict(sd)
+        tag = "%s_%d_%d" % (mode, sub, bn)
+        keys_out["nlblock_" + tag] = [[k, list(v.shape)] for k, v in blk.state_dict().items()]
+        with torch.no_grad():
+            blob[tag] = blk(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "nlblock.npz"), **blob)
+    print("nlblock modes", [k for k in blob if k not in ("shape", "w_seed", "x_seed")])
 
 
 def make_trn(ref, trn, keys_out):

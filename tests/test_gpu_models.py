@@ -462,3 +462,25 @@ def test_concurrent_callers_share_a_plan_safely(ptx):
     assert not errs, errs
     for g, w in zip(got, want):
         _check(g, w, "concurrent caller")
+
+
+def test_nonlocal_block_modes(ptx):
+    """Standalone NonLocalBlock3D on the GPU: embedded_gaussian / dot_product / gaussian, with and without
+    sub_sample and bn_layer, against the real reference's outputs (golden) and the oracle."""
+    blob = load_golden("nlblock")
+    x = golden_input(blob)
+    for mode, sub, bn in [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
+                          ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]:
+        tag = "%s_%d_%d" % (mode, sub, bn)
+        blk = ptx.NonLocalBlock3D(16, mode=mode, sub_sample=sub, bn_layer=bn)
+        sd = synth_state_dict(blk.state_dict(), int(blob["w_seed"]))
+        blk.load_state_dict(sd)
+        blk = blk.to(DEV).eval()
+        y = blk(x.to(DEV))
+        torch.cuda.synchronize()
+        _check(y, torch.from_numpy(blob[tag]), "nlblock %s vs golden" % tag, 1e-4)
+        with torch.no_grad():
+            want = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
+        _check(y, want, "nlblock %s vs oracle" % tag, 1e-4)
+    with pytest.raises(Exception):
+        ptx.NonLocalBlock3D(16, mode="concatenation").to(DEV)(x.to(DEV))

@@ -313,3 +313,26 @@ def test_biggan_standin_and_plan(ptx):
     assert lab_["blocks.0.0.conv4"].flags & ptx._lib.PTX_EPI_RES_ADD
     with pytest.raises(ValueError):
         ptx.biggan_deep(pretrained="imagenet")
+
+
+NL_CASES = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
+            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]
+
+
+def test_oracle_nlblock_golden(ptx):
+    """Standalone NonLocalBlock3D: parameter names equal to the reference's in every mode, oracle equal
+    to the reference outputs (sub_sample and bn_layer=False included)."""
+    blob = load_golden("nlblock")
+    x = golden_input(blob)
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    for mode, sub, bn in NL_CASES:
+        tag = "%s_%d_%d" % (mode, sub, bn)
+        blk = ptx.NonLocalBlock3D(16, mode=mode, sub_sample=sub, bn_layer=bn)
+        assert [[k, list(v.shape)] for k, v in blk.state_dict().items()] == keys["nlblock_" + tag], tag
+        sd = synth_state_dict(blk.state_dict(), int(blob["w_seed"]))
+        with torch.no_grad():
+            y = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
+        assert np.abs(y.numpy() - blob[tag]).max() <= GOLDEN_TOL, tag
+    with pytest.raises(Exception):
+        m = ptx.NonLocalBlock3D(16, mode="concatenation")
+        m.engine().dry_plan(m, (1, 16, 2, 4, 4))
