@@ -229,6 +229,11 @@ int ptx_cbn_fold(const float* gain, const float* bias, const float* mean, const 
 int ptx_affine_act_upsample(const float* x, float* y, const float* scale, const float* shift, int32_t ld_scale,
                             int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, int32_t up,
                             int32_t act, ptx_stream_t stream);
+/* Non-local 'concatenation' affinity (nonlocalnet.py:213-243): the 1x1 conv over cat([theta_i, phi_j]) is
+ * a[i] + b[j] with a = theta . w[:ci], b = phi . w[ci:], so
+ *   f[n][i][j] = relu(a[n][i] + b[n][j]) / cols        (f row stride ldf; columns [cols, ldf) zeroed) */
+int ptx_outer_sum_relu(const float* a, const float* b, float* f, int32_t batch, int32_t rows, int32_t cols,
+                       int32_t ldf, ptx_stream_t stream);
 /* y[r][0..cols) = x[r][0..cols) for r < rows (row strides ldx / ldy, all multiples of 4): places a
  * tensor into a channel slice of another -- torch.cat(dim=1) plumbing (slowfast.py:145, 395) */
 int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,

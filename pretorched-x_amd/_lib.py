@@ -101,6 +101,7 @@ SIGNATURES = {
     "ptx_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "ptx_cbn_fold": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ptx_affine_act_upsample": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ptx_outer_sum_relu": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ptx_copy2d": (C.c_int, [_P, _P, _L, _I, _L, _L, _P]),
     "ptx_window_mean": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ptx_global_avgpool": (C.c_int, [_P, _P, _I, _I, _L, _I, _I, _P]),

@@ -446,6 +446,17 @@ __global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* _
     }
 }
 
+__global__ void __launch_bounds__(256) outer_sum_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ f, size_t total, int rows, int cols, int ldf) {
+    const float inv = 1.0f / (float)cols;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int j = (int)(e % ldf);
+        const size_t r = e / ldf;                    // n * rows + i
+        const size_t n = r / rows;
+        f[e] = j < cols ? fmaxf(a[r] + b[n * cols + j], 0.f) * inv : 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) window_mean_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total,
                                                           int T, int To, int inner, int k, int stride) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -548,6 +559,16 @@ extern "C" int ptx_copy2d(const float* x, float* y, int64_t rows, int32_t cols, 
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, cols / 4,
                        (long long)ldx, (long long)ldy);
     return hip_check(hipGetLastError(), "copy2d launch");
+}
+
+extern "C" int ptx_outer_sum_relu(const float* a, const float* b, float* f, int32_t batch, int32_t rows, int32_t cols,
+                                  int32_t ldf, ptx_stream_t stream) {
+    if (!a || !b || !f) return fail(PTX_ERR_INVALID, "outer_sum_relu: null pointer");
+    if (batch <= 0 || rows <= 0 || cols <= 0 || ldf < cols) return fail(PTX_ERR_INVALID, "outer_sum_relu: bad extents");
+    const size_t total = (size_t)batch * rows * ldf;
+    hipLaunchKernelGGL(outer_sum_relu_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, f, total, rows,
+                       cols, ldf);
+    return hip_check(hipGetLastError(), "outer_sum_relu launch");
 }
 
 extern "C" int ptx_window_mean(const float* x, float* y, int32_t outer, int32_t T, int32_t inner, int32_t k,

@@ -452,13 +452,13 @@ class Plan:
     def nonlocal_block(self, x, nl, label):
         """Non-local block (nonlocalnet.py:139-243): pointwise projections in one launch, f = theta^T phi on
         MFMA, row softmax (or 1/N scaling), y = f g on MFMA, W projection (+BN) + residual in one launch.
-        Modes: embedded_gaussian (:143-166), dot_product (:192-211, f / N), gaussian (:168-190, theta = phi = x);
-        `sub_sample` max-pools phi and g 2x2x2 (:126-131).  concatenation (:213-243) is not on the HIP path."""
+        Modes: embedded_gaussian (:143-166), dot_product (:192-211, f / N), gaussian (:168-190, theta = phi = x),
+        concatenation (:213-243: relu(w . cat(theta_i, phi_j)) / N = relu(a_i + b_j) / N with two GEMVs);
+        `sub_sample` max-pools phi and g 2x2x2 (:126-131)."""
         mode = getattr(nl, "mode", "embedded_gaussian")
         sub = bool(getattr(nl, "sub_sample", False))
-        if mode not in ("embedded_gaussian", "dot_product", "gaussian"):
-            raise PtxError("non-local mode %r is not implemented on the HIP path (embedded_gaussian, dot_product, "
-                           "gaussian are)" % mode)
+        if mode not in ("embedded_gaussian", "dot_product", "gaussian", "concatenation"):
+            raise PtxError("unknown non-local mode %r" % mode)
         lib = self.lib
         first = (lambda m: m[0]) if sub else (lambda m: m)        # Sequential(conv, max_pool) when sub-sampling
         g_conv = first(nl.g)
@@ -486,10 +486,21 @@ class Plan:
         lda, ldb, ldg = th_act.ld, ph_act.ld, g_act.ld
         fp, gtp, yp, yld = _ptr(f), _ptr(gT), _ptr(yatt.t), yatt.ld
         scale_only = int(mode == "dot_product")
+        if mode == "concatenation":
+            av = torch.empty(N * Sq, device=self.dev, dtype=torch.float32)
+            bv = torch.empty(N * Sk, device=self.dev, dtype=torch.float32)
+            self.keepalive += [av, bv]
+            avp, bvp, proj = _ptr(av), _ptr(bv), nl.concat_project[0]
 
         def step(st):
-            check(lib.ptx_bgemm_nt(th, ph, fp, N, Sq, Sk, K, lda, ldb, ldf, Sq * lda, Sk * ldb, Sq * ldf, st), "bgemm f")
-            check(lib.ptx_softmax_rows(fp, N * Sq, Sk, ldf, scale_only, st), "softmax")
+            if mode == "concatenation":
+                w = proj.weight.detach().reshape(-1).contiguous()          # [2*ci]: theta half | phi half
+                check(lib.ptx_linear_fwd(th, _ptr(w), None, avp, N * Sq, ci, 1, lda, 1, 0, st), "concat a")
+                check(lib.ptx_linear_fwd(ph, _ptr(w, ci), None, bvp, N * Sk, ci, 1, ldb, 1, 0, st), "concat b")
+                check(lib.ptx_outer_sum_relu(avp, bvp, fp, N, Sq, Sk, ldf, st), "concat f")
+            else:
+                check(lib.ptx_bgemm_nt(th, ph, fp, N, Sq, Sk, K, lda, ldb, ldf, Sq * lda, Sk * ldb, Sq * ldf, st), "bgemm f")
+                check(lib.ptx_softmax_rows(fp, N * Sq, Sk, ldf, scale_only, st), "softmax")
             check(lib.ptx_transpose_last2(gp, gtp, N, Sk, ci, ldg, ldf, st), "transpose g")
             check(lib.ptx_bgemm_nt(fp, gtp, yp, N, Sq, ci, Sk, ldf, ldf, yld, Sq * ldf, ci * ldf, Sq * yld, st), "bgemm y")
         self.steps.append(step)

@@ -142,7 +142,7 @@ def _nonlocal(channels):
 class NonLocalBlock3D(nn.Module):
     """Standalone non-local block with the reference's constructor and parameter names
     (nonlocalnet.py:51-131, :264-270): z = W(y) + x over [B,C,T,H,W].  HIP path: modes embedded_gaussian,
-    dot_product and gaussian, with or without `sub_sample` / `bn_layer`; 'concatenation' raises."""
+    dot_product, gaussian and concatenation, with or without `sub_sample` / `bn_layer`."""
     plan_kind = "nlblock"
 
     def __init__(self, in_channels, inter_channels=None, mode="embedded_gaussian", sub_sample=False, bn_layer=True):

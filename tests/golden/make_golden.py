@@ -230,7 +230,8 @@ def main():
 
 
 NL_CASES = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
-            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]
+            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
+            ("concatenation", False, True), ("concatenation", True, False)]
 
 
 def make_nlblock(ref, keys_out):

@@ -791,3 +791,15 @@ def test_grouped_conv(ptx):
             torch.cuda.synchronize()
             close(from_cl(yd, Cc), want)
         assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, 28, 1, _st()) == 2   # 64-wide tile
+
+
+def test_outer_sum_relu(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    a, b = rnd(3, 10, seed=150), rnd(3, 7, seed=151)
+    ad, bd = a.to(DEV), b.to(DEV)
+    f = torch.full((3, 10, 8), float("nan"), device=DEV)
+    L.check(lib.ptx_outer_sum_relu(_p(ad), _p(bd), _p(f), 3, 10, 7, 8, _st()), "outer_sum_relu")
+    torch.cuda.synchronize()
+    want = F.relu(a[:, :, None] + b[:, None, :]) / 7
+    close(f.cpu()[..., :7], want, tol=1e-6)
+    assert bool((f[..., 7:] == 0).all())

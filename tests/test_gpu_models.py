@@ -470,7 +470,8 @@ def test_nonlocal_block_modes(ptx):
     blob = load_golden("nlblock")
     x = golden_input(blob)
     for mode, sub, bn in [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
-                          ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]:
+                          ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
+                          ("concatenation", False, True), ("concatenation", True, False)]:
         tag = "%s_%d_%d" % (mode, sub, bn)
         blk = ptx.NonLocalBlock3D(16, mode=mode, sub_sample=sub, bn_layer=bn)
         sd = synth_state_dict(blk.state_dict(), int(blob["w_seed"]))
@@ -483,4 +484,4 @@ def test_nonlocal_block_modes(ptx):
             want = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
         _check(y, want, "nlblock %s vs oracle" % tag, 1e-4)
     with pytest.raises(Exception):
-        ptx.NonLocalBlock3D(16, mode="concatenation").to(DEV)(x.to(DEV))
+        ptx.NonLocalBlock3D(16, mode="gaussian", sub_sample=True).to(DEV)(torch.zeros(1, 16, 1, 4, 4, device=DEV))

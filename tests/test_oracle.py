@@ -316,7 +316,8 @@ def test_biggan_standin_and_plan(ptx):
 
 
 NL_CASES = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
-            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False)]
+            ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
+            ("concatenation", False, True), ("concatenation", True, False)]
 
 
 def test_oracle_nlblock_golden(ptx):
@@ -333,6 +334,6 @@ def test_oracle_nlblock_golden(ptx):
         with torch.no_grad():
             y = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
         assert np.abs(y.numpy() - blob[tag]).max() <= GOLDEN_TOL, tag
-    with pytest.raises(Exception):
-        m = ptx.NonLocalBlock3D(16, mode="concatenation")
-        m.engine().dry_plan(m, (1, 16, 2, 4, 4))
+    with pytest.raises(Exception):               # sub_sample needs >= 2 positions along every axis
+        m = ptx.NonLocalBlock3D(16, mode="gaussian", sub_sample=True)
+        m.engine().dry_plan(m, (1, 16, 1, 4, 4))
