@@ -101,10 +101,10 @@ def main():
         x_cpu = synth_clips(CLIPS_PER_GPU, FRAMES, SIZE, 99 + rank)       # per-rank clips
         from oracle import functional as OF_
         cpu_fn = lambda sd_, x_: OF_.forward(OF_.ARCHS["resnet3d50"], sd_, x_)   # noqa: E731
-        label = ("resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
-                 "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE))
+        workload_label = ("resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
+                          "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE))
     else:
-        model, recipe, x_cpu, fwd, cpu_fn, unit, label = other_workload(args.workload, rank)
+        model, recipe, x_cpu, fwd, cpu_fn, unit, workload_label = other_workload(args.workload, rank)
         sd = synth_state_dict(model.state_dict(), 1234, **recipe)
         units_per_gpu = x_cpu.shape[0]
     model.load_state_dict(sd)
@@ -248,7 +248,7 @@ def main():
             "value": round(clips_per_s, 2), "unit": "%s/s" % unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label,
+            "config": {"workload": workload_label,
                        "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
             "roofline": roofline, "roofline_net": roofline_net, "cpu_baseline": cpu, "parity": parity,
