@@ -12,7 +12,7 @@ from pretorched_x_amd.testing import synth_state_dict  # noqa: E402
 import importlib.util  # noqa: E402
 spec = importlib.util.spec_from_file_location("zoo", "scripts/gpu_zoo_bench.py")
 src = open("scripts/gpu_zoo_bench.py").read().split("only = sys.argv[1:]")[0]
-ns = {}
+ns = {"__file__": os.path.abspath("scripts/gpu_zoo_bench.py")}
 exec(compile(src, "zoo_cases", "exec"), ns)
 name, build, recipe, shape = [c for c in ns["CASES"] if args[0] in c[0]][0]
 m = build()
