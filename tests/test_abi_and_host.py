@@ -246,3 +246,25 @@ def test_slowfast_plan_wiring_without_gpu(ptx):
     m8 = ptx.slowfast.resnet50(num_classes=5, slow_stride=8)
     with pytest.raises(ptx.PtxError):
         m8.engine().dry_plan(m8, (1, 3, 32, 64, 64))
+
+
+def test_bench_workload_table(ptx):
+    """bench.py --workload: every BASELINE configuration builds, its plan compiles at the stated input and the
+    CPU-oracle leg is callable (checked on a reduced input where the full one would take minutes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(GOLDEN), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.CLIPS_PER_GPU == 8 and abs(bench.GFLOP_PER_CLIP - 79.692) < 1e-9 and bench.PEAK_F32_MFMA_TF == 157.3
+    from pretorched_x_amd.testing import synth_state_dict
+    for w, units in (("cfg1", 1), ("cfg3", 8), ("cfg4", 2), ("cfg5", 64)):
+        model, recipe, x, fwd, cpu_fn, unit, label = bench.other_workload(w, 0)
+        assert x.shape[0] == units and unit in ("clips", "images") and w[-1] in label.split("config ")[1][:2]
+        shape = tuple(x.shape) if w != "cfg5" else (4, 128)
+        plan = model.engine().dry_plan(model, shape)
+        assert len(plan.conv_steps) > 10
+        if w == "cfg1":
+            sd = synth_state_dict(model.state_dict(), 1234, **recipe)
+            assert tuple(cpu_fn(sd, x).shape) == (1, 1000)
+    with pytest.raises(SystemExit):
+        bench.other_workload("cfg9", 0)
