@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* _
                                                                   int up, int relu) {
     const int c4 = (C + 3) / 4;
     const int Ho = H * up, Wo = W * up;
+    const bool vec4 = scale && (C % 4 == 0) && (lds_ % 4 == 0) && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % c4);
         size_t pos = i / c4;
@@ -430,11 +431,25 @@ __global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* _
         const int n = (int)(r / Ho);
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ho / up) * W + wo / up) * ldx + q * 4);
         float o[4] = {v.x, v.y, v.z, v.w};
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (scale) {
+            const float* sp = scale + (size_t)n * lds_ + q * 4;
+            const float* hp = shift + (size_t)n * lds_ + q * 4;
+            if (vec4) {                                   // one 16-byte load each instead of four scalar ones
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp), h4 = *reinterpret_cast<const f32x4*>(hp);
+                sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+                sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q * 4 + e < C) { sc[e] = sp[e]; sh[e] = hp[e]; }
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = q * 4 + e;
             if (c < C) {
-                if (scale) o[e] = fmaf(o[e], scale[(size_t)n * lds_ + c], shift[(size_t)n * lds_ + c]);
+                if (scale) o[e] = fmaf(o[e], sc[e], sh[e]);
                 if (relu == 1) o[e] = fmaxf(o[e], 0.f);
                 else if (relu == 2) o[e] = tanhf(o[e]);
             } else {
