@@ -46,6 +46,12 @@ typedef void* ptx_stream_t; /* hipStream_t */
 #define PTX_EPI_RES_UP 64u   /* with RES_PADA: the residual is nearest-UPsampled (index = out >> res_s*, res_s* =
                                 log2 factor) and channel-truncated (res_C >= Co): the BigGAN-deep GBlock
                                 skip `up(x[:, :out_channels])`                                            */
+#define PTX_F16_OPERANDS 128u /* ptx_conv3d_fwd: x and w_packed hold IEEE halfs (fp16 MFMA, fp32 accumulate, fp32 bias /
+                                residual / output).  The descriptor's Ci, ldx and Kc then count 32-bit WORDS, i.e.
+                                channel PAIRS (channels % 8 == 0); pack with ptx_pack_desc.f16.  Runs on the
+                                ".../f16" tile configurations (BigGAN generator, BASELINE config 5)            */
+#define PTX_ACT_OUT_F16 0x100 /* ptx_affine_act_upsample: OR into `act` -- y is written as halfs (ldy in halfs,
+                                multiple of 8): the cBN -> ReLU -> upsample pass feeds an fp16-operand conv      */
 #define PTX_PRO_RELU 8u      /* ptx_linear_fwd only: ReLU on the input while loading (trn.py:39-45) */
 #define PTX_EPI_ACCUM 16u    /* ptx_linear_fwd only: y += result (trn.py:110 stack(...).sum(0))   */
 
@@ -142,6 +148,9 @@ typedef struct ptx_pack_desc {
      * coalesced LDS-staged operands instead of per-lane 16-byte gathers.  co_per_super = output channels
      * of one super-group (rows [s*co_per_super, (s+1)*co_per_super) share the input columns of super-group s). */
     int32_t sub_groups, co_per_super;
+    /* != 0: w_packed is written as IEEE halfs (Kc counts halfs, multiple of 8; ptx_packed_weight_elems counts
+     * halfs) for PTX_F16_OPERANDS convs.  bias_out stays fp32. */
+    int32_t f16;
 } ptx_pack_desc;
 
 size_t ptx_packed_weight_elems(const ptx_pack_desc* desc);

@@ -18,6 +18,8 @@ PTX_EPI_RES_PADA = 4
 PTX_PRO_RELU = 8
 PTX_EPI_ACCUM = 16
 PTX_EPI_RES_UP = 64
+PTX_F16_OPERANDS = 128
+PTX_ACT_OUT_F16 = 0x100
 
 
 class PtxError(RuntimeError):
@@ -39,7 +41,7 @@ class ConvDesc(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("Co", "Ci", "kT", "kH", "kW", "Kc", "Co_pad", "fold_kw",
-                                         "ld_k", "k_off", "bias_accumulate", "sub_groups", "co_per_super")]
+                                         "ld_k", "k_off", "bias_accumulate", "sub_groups", "co_per_super", "f16")]
 
 
 class PoolDesc(C.Structure):

@@ -71,8 +71,13 @@ class BigGANDeepGenerator(nn.Module):
     plan_kind = "biggan"
 
     def __init__(self, resolution=256, ch=128, dim_z=128, shared_dim=128, n_classes=1000, depth=2, bottom_width=4,
-                 bn_eps=1e-5):
+                 bn_eps=1e-5, precision="fp32"):
         super().__init__()
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        # 'fp16': the cBN -> ReLU (-> upsample) passes emit halfs and every GBlock / output conv runs on fp16 MFMA
+        # with fp32 accumulation, bias, skip connection and output (BASELINE.json config 5 names fp16 MFMA)
+        self.precision = precision
         if resolution not in _ARCH:
             raise ValueError("resolution must be one of %s" % sorted(_ARCH))
         self.resolution, self.ch, self.dim_z, self.shared_dim = resolution, ch, dim_z, shared_dim

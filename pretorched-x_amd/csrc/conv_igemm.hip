@@ -59,7 +59,8 @@ struct ConvArgs {
     const float* x2;
     int dual, ldx2, kA2, kc1, wcol2, T2, H2, W2, s2T, s2H, s2W;
     unsigned x2_bytes;
-    int groups, cig, cog;  // grouped conv (direct kernels only): input / output channels per group
+    int groups, cig, cog;  // grouped conv: input / output channels per group
+    int f16;               // A / B operands are halfs; K extents count 32-bit words
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
 };
 
@@ -76,12 +77,17 @@ __device__ __forceinline__ void post_barrier_offsets(int& a, int& b) {
     asm volatile("; ds_reads of the next LDS buffer depend on these" : "+v"(a), "+v"(b)::"memory");
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 template <int MT> struct Mfma;
 template <> struct Mfma<32> {
     using acc_t = f32x16;
     static constexpr int NACC = 16;
     static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // fp16 operands: the same 16-byte fragment holds 8 halfs = K 16 per lane group pair, one instruction
+    static __device__ __forceinline__ acc_t mma16(f32x4 a, f32x4 b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int r, int lane) {
         return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -92,6 +98,9 @@ template <> struct Mfma<16> {
     static constexpr int NACC = 4;
     static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ acc_t mma16(f32x4 a, f32x4 b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
 };
@@ -120,8 +129,13 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE>
+// F16: the A / B operands are IEEE halfs.  Everything that MOVES data (buffer loads, LDS-DMA, swizzle, tap
+// pruning, K tails) works on 32-bit words and does not care; the descriptor then counts channel PAIRS.  Only
+// the fragment -> MFMA step differs: the 16-byte fragment a lane reads is 8 halfs, consumed by ONE
+// v_mfma_f32_32x32x16_f16 / 16x16x32_f16 instead of four fp32 MFMAs.  Accumulators, epilogue and output stay fp32.
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
+    static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
     constexpr int NT = 64 * WM * WN;         // threads per workgroup (4 or 8 waves)
@@ -453,6 +467,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
     };
     auto mma_frags = [&](int slot, int nr) {
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(fa[slot][i], fb[slot][j], acc[i][j]);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r < nr) {
@@ -656,10 +677,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -673,8 +694,13 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE, bool F16 = false>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr (F16) {
+        if ((a.kA % BK) || (a.kB % BK))
+            return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE, true>(a, grid, st);
+        return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA, NSTAGE, true>(a, grid, st);
+    }
     if constexpr (BK == 24 && MT == 32 && !DMA) {
         // kW-folded stem: one 24-wide chunk per tap of which at most 22 columns are live
         if (a.k_live <= 22 && a.kA == 24 && a.kB == 24)
@@ -831,19 +857,23 @@ struct ConvConfig {
     const char* name;
     launch_fn launch;
     bool direct;      // VALU kernel: no split-K, own grid
+    bool f16;         // fp16 operands (PTX_F16_OPERANDS)
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false, false }
 #define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false, false }
 #define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false, false }
 #define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false }
 
 #define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
-    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true }
+    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false }
+#define PTX_CFG_F16(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/f16", \
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, true>, false, true }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -929,6 +959,16 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 32, 32, 4, 1, 16),       // 71
     PTX_CFG_DIRECT(1024, 4, 4, 4, 4),     // 72 group width 4 (ResNeXt3D layer1, cardinality 32)
     PTX_CFG_DIRECT(512, 4, 4, 4, 2),      // 73
+    // fp16 operands (BigGAN generator, config 5): LDS-DMA tiles; BK counts 32-bit words = channel pairs
+    PTX_CFG_F16(128, 128, 32, 4, 2, 32),  // 74
+    PTX_CFG_F16(128, 64, 32, 4, 2, 32),   // 75
+    PTX_CFG_F16(64, 64, 32, 2, 2, 32),    // 76
+    PTX_CFG_F16(64, 128, 32, 2, 2, 32),   // 77
+    PTX_CFG_F16(128, 128, 16, 4, 2, 32),  // 78
+    PTX_CFG_F16(64, 64, 16, 2, 2, 32),    // 79
+    PTX_CFG_F16(32, 64, 32, 2, 2, 16),    // 80
+    PTX_CFG_F16(64, 32, 32, 2, 2, 16),    // 81 narrow outputs (the 3-channel image conv)
+    PTX_CFG_F16(256, 128, 32, 4, 2, 32),  // 82
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -995,6 +1035,10 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     const int taps = d->kT * d->kH * d->kW;
     const int ncol = (d->Co + 3) / 4 * 4;
     int cfg;
+    if (d->flags & PTX_F16_OPERANDS) {
+        const int64_t Mrows = (int64_t)d->N * d->To * d->Ho * d->Wo;
+        return ncol <= 32 ? 81 : (Mrows < 8192 ? 80 : (ncol >= 128 ? 74 : 75));
+    }
     if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
         const int cog = d->Co / d->groups;
         if (cog % 32 == 0) return 37;              // 64x32x32 MFMA tile inside one group
@@ -1033,6 +1077,8 @@ namespace ptx {
 int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
                 hipStream_t st) {
     const ConvConfig& c = kConfigs[config];
+    if ((a.f16 != 0) != c.f16)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16-operand problems run on the /f16 tile configurations only (and vice versa)");
     if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
     a.m_tiles = cdiv(a.M, c.BM);
@@ -1146,6 +1192,8 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)wb;
     }
+    a.f16 = (d->flags & PTX_F16_OPERANDS) ? 1 : 0;
+    if (a.f16 && (x2 || d->groups > 1)) return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16 operands: single-source dense convs only");
     a.groups = d->groups > 1 ? d->groups : 1;
     a.cig = d->Ci / a.groups; a.cog = d->Co / a.groups;
     if (a.groups > 1) {

@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const
             v = w[src] * bn_scale(gamma, var, eps, co);
         }
         const size_t ld = d.ld_k > 0 ? (size_t)d.ld_k : (size_t)d.Kc;
-        out[((size_t)tap * d.Co_pad + co) * ld + d.k_off + k] = v;
+        const size_t dst = ((size_t)tap * d.Co_pad + co) * ld + d.k_off + k;
+        if (d.f16) reinterpret_cast<_Float16*>(out)[dst] = (_Float16)v;     // round-to-nearest-even
+        else out[dst] = v;
     }
 }
 
@@ -292,6 +294,8 @@ extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, cons
                               d->co_per_super % d->sub_groups || d->Co % d->co_per_super))
         return fail(PTX_ERR_INVALID, "pack: super-group packing needs sub_groups | Ci, sub_groups | co_per_super | Co, no kW fold");
     const int keff = d->fold_kw ? d->kW * d->Ci : d->Ci;
+    if (d->f16 && (d->Kc % 8 || d->ld_k || d->k_off))
+        return fail(PTX_ERR_INVALID, "pack: fp16 filters need Kc %% 8 == 0 and no K-concatenation window");
     if (d->Kc < keff || d->Kc % 4 || d->Co_pad < d->Co || d->Co_pad % 128)
         return fail(PTX_ERR_INVALID, "pack: Kc=%d must cover K=%d (multiple of 4); Co_pad=%d must cover Co=%d (multiple of 128)",
                     d->Kc, keff, d->Co_pad, d->Co);

@@ -418,7 +418,9 @@ __global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* _
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int lds_,
                                                                   size_t total4, int H, int W, int C, int ldx, int ldy,
-                                                                  int up, int relu) {
+                                                                  int up, int relu_in) {
+    const bool out_f16 = (relu_in & PTX_ACT_OUT_F16) != 0;
+    const int relu = relu_in & 0xff;
     const int c4 = (C + 3) / 4;
     const int Ho = H * up, Wo = W * up;
     const bool vec4 = scale && (C % 4 == 0) && (lds_ % 4 == 0) && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0);
@@ -456,8 +458,14 @@ __global__ void __launch_bounds__(256) affine_act_upsample_kernel(const float* _
                 o[e] = 0.f;
             }
         }
-        f32x4 w4 = {o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4*>(y + pos * ldy + q * 4) = w4;
+        if (out_f16) {
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            const half4 h4 = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(y) + pos * ldy + q * 4) = h4;
+        } else {
+            f32x4 w4 = {o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(y + pos * ldy + q * 4) = w4;
+        }
     }
 }
 
@@ -552,7 +560,10 @@ extern "C" int ptx_affine_act_upsample(const float* x, float* y, const float* sc
                                        int32_t ldy, int32_t up, int32_t relu, ptx_stream_t stream) {
     if (!x || !y || ((scale == nullptr) != (shift == nullptr)))
         return fail(PTX_ERR_INVALID, "affine_act_upsample: null pointer (scale and shift go together)");
-    if (relu < 0 || relu > 2) return fail(PTX_ERR_INVALID, "affine_act_upsample: act must be 0, 1 or 2");
+    if ((relu & ~PTX_ACT_OUT_F16) < 0 || (relu & ~PTX_ACT_OUT_F16) > 2)
+        return fail(PTX_ERR_INVALID, "affine_act_upsample: act must be 0, 1 or 2 (| PTX_ACT_OUT_F16)");
+    if ((relu & PTX_ACT_OUT_F16) && (ldy % 8 || ((uintptr_t)y & 7)))
+        return fail(PTX_ERR_INVALID, "affine_act_upsample: fp16 output needs ldy %% 8 == 0");
     const int c4 = (C + 3) / 4 * 4;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || up < 1 || up > 8 || ldx < c4 || ldy < c4 || ldx % 4 || ldy % 4 ||
         (scale && ld_scale != 0 && ld_scale < C))

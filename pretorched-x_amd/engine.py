@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
-                   PTX_EPI_RES_UP, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
+                   PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None
@@ -89,12 +89,13 @@ def _geom(conv):
 
 class Act:
     """A channels-last activation: tensor [N,T,H,W,ld], C valid channels."""
-    __slots__ = ("t", "N", "T", "H", "W", "C", "ld")
+    __slots__ = ("t", "N", "T", "H", "W", "C", "ld", "f16")
 
-    def __init__(self, dev, N, T, H, W, C_, ld=None):
+    def __init__(self, dev, N, T, H, W, C_, ld=None, f16=False):
         self.N, self.T, self.H, self.W, self.C = N, T, H, W, C_
-        self.ld = _r4(C_) if ld is None else ld
-        self.t = torch.empty((N, T, H, W, self.ld), device=dev, dtype=torch.float32)
+        self.f16 = bool(f16)       # halfs: the operand of an fp16-MFMA conv (row stride a multiple of 8 halfs)
+        self.ld = ((C_ + 7) // 8 * 8 if f16 else _r4(C_)) if ld is None else ld
+        self.t = torch.empty((N, T, H, W, self.ld), device=dev, dtype=torch.float16 if f16 else torch.float32)
         if self.ld != C_ and self.t.device.type != "meta":
             self.t.zero_()
 
@@ -106,7 +107,9 @@ class Act:
         """Channels [c0, c0 + C_) of this activation as an output target: same row stride, so a conv /
         pool writing it fills its part of a channel concatenation (torch.cat(dim=1)) in place."""
         assert c0 % 4 == 0 and c0 + C_ <= self.ld
+        assert not self.f16, "channel slices are fp32 only"
         v = Act.__new__(Act)
+        v.f16 = False
         v.N, v.T, v.H, v.W, v.C, v.ld = self.N, self.T, self.H, self.W, C_, self.ld
         v.t = self.t[..., c0:c0 + C_]
         return v
@@ -126,7 +129,8 @@ def _same_geometry(dims, k, s):
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
-    def __init__(self, dev, convs, bn, fold_kw=False, scale=None):
+    def __init__(self, dev, convs, bn, fold_kw=False, scale=None, f16=False):
+        self.f16 = bool(f16)         # filter stored as halfs for an fp16-operand conv
         self.convs = list(convs)     # >1: concatenated along Co (non-local g/theta/phi)
         self.bn = bn
         self.scale = scale           # scalar Parameter multiplying the filter (self-attention gamma)
@@ -149,15 +153,17 @@ class Packed:
             self.Ci = SUPER
         self.fold_kw = bool(fold_kw)
         keff = kW * self.Ci if fold_kw else self.Ci
-        self.Kc = _r4(keff)
+        self.Kc = (keff + 7) // 8 * 8 if self.f16 else _r4(keff)
+        if self.f16 and (fold_kw or self.groups > 1 or self.Ci % 2):
+            raise PtxError("fp16 filters: dense, unfolded convs with an even channel count only")
         if fold_kw:
             self.Kc = max(self.Kc, 24) if keff <= 24 else self.Kc
         self.Co_pad = _r128(self.Co)
         self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
         self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw), 0, 0, 0,
-                          self.sub_groups, self.Ci if self.sub_groups else 0)
+                          self.sub_groups, self.Ci if self.sub_groups else 0, int(self.f16))
         n = _lib.lib().ptx_packed_weight_elems(C.byref(self.d))
-        self.w = torch.empty(n, device=dev, dtype=torch.float32)
+        self.w = torch.empty(n, device=dev, dtype=torch.float16 if self.f16 else torch.float32)
         self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
 
     def refresh(self):
@@ -268,12 +274,12 @@ class Plan:
                 self.ws_ptr = _ptr(self.ws)
 
     # ---------------------------------------------------------------- building blocks
-    def pack(self, convs, bn, fold_kw=False, scale=None):
+    def pack(self, convs, bn, fold_kw=False, scale=None, f16=False):
         if not isinstance(convs, (list, tuple)):
             convs = [convs]
-        key = (tuple(id(c) for c in convs), id(bn), fold_kw, id(scale))
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw, id(scale), bool(f16))
         if key not in self._pack_cache:
-            p = Packed(self.dev, convs, bn, fold_kw, scale)
+            p = Packed(self.dev, convs, bn, fold_kw, scale, f16)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]
@@ -286,8 +292,8 @@ class Plan:
             self.packs.append(p)
         return self._pack_cache[key]
 
-    def act(self, N, T, H, W, C_, ld=None):
-        a = Act(self.dev, N, T, H, W, C_, ld)
+    def act(self, N, T, H, W, C_, ld=None, f16=False):
+        a = Act(self.dev, N, T, H, W, C_, ld, f16)
         self.acts.append(a)      # steps hold raw pointers: the plan owns every buffer
         return a
 
@@ -312,9 +318,17 @@ class Plan:
         flags = PTX_EPI_RELU if relu else 0
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
+        half = bool(getattr(x, "f16", False))
+        if half != bool(getattr(pk, "f16", False)):
+            raise PtxError("%s: activation and filter precisions differ" % label)
+        if half:        # fp16 operands: the descriptor counts 32-bit words (channel pairs)
+            if x.C % 2 or x.ld % 8 or x2 is not None:
+                raise PtxError("%s: fp16 operands need an even channel count and 16-byte rows" % label)
+            flags |= PTX_F16_OPERANDS
+            d.Ci, d.ldx = x.C // 2, x.ld // 2
         d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, y.ld
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
-        d.Kc, d.Co_pad = pk.Kc, pk.Co_pad
+        d.Kc, d.Co_pad = (pk.Kc // 2 if half else pk.Kc), pk.Co_pad
         d.groups = getattr(pk, "groups", 1)
         if d.groups > 1 and (x.C != pk.Ci * d.groups or pk.Ci % 4):
             raise PtxError("%s: grouped conv needs Ci/groups %% 4 == 0 and a %d-channel input" % (label, pk.Ci * d.groups))
@@ -991,6 +1005,8 @@ class Engine:
                 ncol = _r4(stp.d.Co)                          # columns written (ldy is only the row stride)
                 for cfg in range(ncfg):
                     name = lib.ptx_conv3d_config_name(cfg).decode()
+                    if name.endswith("/f16") != bool(stp.d.flags & PTX_F16_OPERANDS):
+                        continue                         # fp16-operand problems <-> fp16 tiles
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
                     narrow = bn_ <= 32 and bk == 32 and bm >= 128 and not name.endswith("/dma")   # Mx16 / Mx32 tiles
                     if (bk == 24) != (stp.d.Kc == 24) and not (stp.d.Kc == 24 and narrow):

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from ._lib import PtxError, check
+from ._lib import PTX_ACT_OUT_F16, PtxError, check
 from .engine import RawInput, _geom, _ptr, _r4, _stream
 
 
@@ -235,9 +235,14 @@ def build_biggan(self, model):
                                  0, st), "linear")
     self.steps.append(first_linear)
 
-    def affine(x, sc, sh, ld_s, up, act=1):
-        y = self.act(N, 1, x.H * up, x.W * up, x.C)
-        xp, yp, H_, W_, C_, ldx, ldy = _ptr(x.t), _ptr(y.t), x.H, x.W, x.C, x.ld, y.ld
+    half = getattr(model, "precision", "fp32") == "fp16"      # fp16 operands for every conv behind a cBN pass
+
+    def affine(x, sc, sh, ld_s, up, act=1, f16_out=None):
+        f16_out = (half and act == 1) if f16_out is None else f16_out
+        y = self.act(N, 1, x.H * up, x.W * up, x.C, f16=f16_out)
+        xp, yp, H_, W_, C_, ldx, ldy = _ptr(x.t), C.c_void_p(y.t.data_ptr()), x.H, x.W, x.C, x.ld, y.ld
+        if f16_out:
+            act |= PTX_ACT_OUT_F16
 
         def step(st):
             check(lib.ptx_affine_act_upsample(xp, yp, sc, sh, ld_s, N, H_, W_, C_, ldx, ldy, up, act, st),
@@ -255,18 +260,18 @@ def build_biggan(self, model):
             name = "blocks.%d.%d" % (si, bi)
             if blk.kind == "gblock":
                 up = 2 if blk.upsample else 1
-                t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None), one, zero, label=name + ".conv1")
-                t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None), one, (0, 1, 1), label=name + ".conv2")
-                t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None), one, (0, 1, 1), label=name + ".conv3")
+                t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None, f16=half), one, zero, label=name + ".conv1")
+                t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None, f16=half), one, (0, 1, 1), label=name + ".conv2")
+                t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None, f16=half), one, (0, 1, 1), label=name + ".conv3")
                 if up == 1 and blk.in_channels == blk.out_channels:
-                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, label=name + ".conv4")
+                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None, f16=half), one, zero, res=h, label=name + ".conv4")
                 else:   # skip = upsample(x[:, :Cout]) gathered in the epilogue
-                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, res_kind="up",
+                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None, f16=half), one, zero, res=h, res_kind="up",
                                   res_stride=(0, up // 2, up // 2), label=name + ".conv4")
             else:
                 h = biggan_attention(self, h, blk, name)
     a = affine(h, _ptr(oscale), _ptr(oshift), obn.channels, 1)
-    img = self.conv(a, self.pack(model.output_layer[2], None), one, (0, 1, 1), label="output_layer.2")
+    img = self.conv(a, self.pack(model.output_layer[2], None, f16=half), one, (0, 1, 1), label="output_layer.2")
     self.feat = affine(img, None, None, 0, 1, act=2)            # tanh
     self.pooled = None
 

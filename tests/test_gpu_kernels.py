@@ -803,3 +803,50 @@ def test_outer_sum_relu(ptx):
     want = F.relu(a[:, :, None] + b[:, None, :]) / 7
     close(f.cpu()[..., :7], want, tol=1e-6)
     assert bool((f[..., 7:] == 0).all())
+
+
+def test_conv_f16_operands(ptx):
+    """fp16-operand implicit GEMM (v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fp32 accumulate / bias / residual /
+    output): against an fp32 ATen conv of the SAME half-rounded inputs, so only the summation order differs."""
+    L, lib = ptx._lib, _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    f16cfgs = [i for i, n in enumerate(names) if n.endswith("/f16")]
+    assert len(f16cfgs) >= 6
+    for (N, H, W, Ci, Co, k, pad, relu, with_res) in [(2, 12, 10, 64, 96, 3, 1, True, True), (3, 9, 9, 40, 24, 1, 0, False, False),
+                                                      (1, 20, 20, 128, 3, 3, 1, False, False), (2, 6, 6, 256, 160, 1, 0, True, True)]:
+        x = rnd(N, Ci, 1, H, W, seed=160).half().float()
+        w = rnd(Co, Ci, 1, k, k, seed=161, scale=(Ci * k * k) ** -0.5).half().float()
+        bias = rnd(Co, seed=162)
+        res = rnd(N, Co, 1, H, W, seed=163) if with_res else None
+        want = F.conv3d(x, w, bias, 1, (0, pad, pad))
+        if res is not None:
+            want = want + res
+        want = F.relu(want) if relu else want
+        ldh = (Ci + 7) // 8 * 8
+        xh = torch.zeros(N, 1, H, W, ldh, dtype=torch.float16)
+        xh[..., :Ci] = x.permute(0, 2, 3, 4, 1).half()
+        xd = xh.to(DEV)
+        pd = L.PackDesc(Co, Ci, 1, k, k, ldh, (Co + 127) // 128 * 128, 0, 0, 0, 0, 0, 0, 1)
+        wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV, dtype=torch.float16)
+        bp = torch.empty(pd.Co_pad, device=DEV)
+        wd, bd = w.to(DEV), bias.to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0),
+                                         C.c_void_p(wp.data_ptr()), _p(bp), _st()), "pack f16")
+        rd = to_cl(res) if res is not None else None
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, H, W, Ci // 2, ldh // 2          # words = channel pairs
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, H, W, Co, _r4(Co)
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 1, k, k, 1, 1, 1, 0, pad, pad
+        d.Kc, d.Co_pad, d.groups = ldh // 2, pd.Co_pad, 1
+        d.flags = L.PTX_F16_OPERANDS | (L.PTX_EPI_RELU if relu else 0) | (L.PTX_EPI_RES_ADD if res is not None else 0)
+        d.ldr = rd.shape[-1] if rd is not None else 0
+        ws = torch.empty(4 * N * H * W * _r4(Co), device=DEV)
+        for cfg, split in [(-1, 0)] + [(c, 1) for c in f16cfgs] + [(f16cfgs[2], 3)]:
+            yd = torch.full((N, 1, H, W, _r4(Co)), float("nan"), device=DEV)
+            L.check(lib.ptx_conv3d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
+                                       _p(rd) if rd is not None else None, _p(yd), _p(ws), ws.numel() * 4, cfg, split, _st()),
+                    "conv f16 cfg %d" % cfg)
+            torch.cuda.synchronize()
+            close(from_cl(yd, Co), want, tol=1e-4)
+        assert lib.ptx_conv3d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
+                                  _p(rd) if rd is not None else None, _p(yd), None, 0, 28, 1, _st()) == 2      # fp32 tile

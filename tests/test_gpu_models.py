@@ -499,3 +499,24 @@ def test_i3d_forward_frames(ptx):
     opts = dict(mean=[0.5, 0.5, 0.5], std=[0.5, 0.5, 0.5], input_space="RGB", input_range=[0, 1])   # I3D's [-1, 1] scaling
     clip = OF.transform_frames(frames, **opts)
     _check(model.forward_frames(frames.to(DEV), opts), I3.forward(sd, clip), "i3d uint8 frames vs oracle")
+
+
+def test_biggan_generator_fp16(ptx):
+    """BigGAN-deep-256 with fp16 MFMA operands (config 5's precision): fp32 accumulate / skip / output.  Against the
+    fp32 stand-in oracle -- the tolerance is the builder's choice (parity unpinned): half-rounded activations
+    through 49 convs."""
+    from oracle import biggan_standin as BG
+    from pretorched_x_amd.testing import BIGGAN_RECIPE
+    G = ptx.biggan_deep(256, precision="fp16")
+    sd = synth_state_dict(G.state_dict(), 1234, **BIGGAN_RECIPE)
+    G.load_state_dict(sd)
+    G = G.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    z, lab = torch.randn(3, 128, generator=g), torch.randint(0, 1000, (3,), generator=g)
+    img = G(z.to(DEV), G.shared(lab.to(DEV)))
+    torch.cuda.synchronize()
+    want = BG.forward(sd, z, sd["shared.weight"][lab])
+    err = (img.cpu() - want).abs()
+    print("biggan-deep-256 fp16: max|d image| = %.3e, mean %.3e" % (err.max().item(), err.mean().item()))
+    assert err.max().item() <= 5e-2 and err.mean().item() <= 3e-3
+    assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))
