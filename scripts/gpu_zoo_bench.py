@@ -31,6 +31,7 @@ CASES = [
     ("resnet3d18", lambda: ptx.resnet3d18(num_classes=400, pretrained=None), {}, (8, 3, 16, 224, 224)),
     ("resnet50 2-D", lambda: ptx.resnet50(num_classes=1000, pretrained=None), dict(last_bn_damp=0.7), (64, 3, 224, 224)),
     ("biggan-deep-256 G (cfg5, fp32)", lambda: ptx.biggan_deep(256), BIGGAN_RECIPE, (64, 128)),
+    ("biggan-deep-256 G fp16 operands", lambda: ptx.biggan_deep(256, precision="fp16"), BIGGAN_RECIPE, (64, 128)),
     ("TRN resnet50 x8 frames", lambda: ptx.TRN(339, num_segments=8, consensus="MSTRN", pretrained=None), dict(last_bn_damp=0.7), (8, 8, 3, 224, 224)),
 ]
 # CPU leg (the reference path's restatement, oracle/): bounded sample of the same workload, like bench.py

@@ -257,10 +257,11 @@ def test_bench_workload_table(ptx):
     spec.loader.exec_module(bench)
     assert bench.CLIPS_PER_GPU == 8 and abs(bench.GFLOP_PER_CLIP - 79.692) < 1e-9 and bench.PEAK_F32_MFMA_TF == 157.3
     from pretorched_x_amd.testing import synth_state_dict
-    for w, units in (("cfg1", 1), ("cfg3", 8), ("cfg4", 2), ("cfg5", 64)):
+    for w, units in (("cfg1", 1), ("cfg3", 8), ("cfg4", 2), ("cfg5", 64), ("cfg5-fp32", 64)):
         model, recipe, x, fwd, cpu_fn, unit, label = bench.other_workload(w, 0)
-        assert x.shape[0] == units and unit in ("clips", "images") and w[-1] in label.split("config ")[1][:2]
-        shape = tuple(x.shape) if w != "cfg5" else (4, 128)
+        assert x.shape[0] == units and unit in ("clips", "images") and w[3] in label.split("config ")[1][:2]
+        shape = tuple(x.shape) if not w.startswith("cfg5") else (4, 128)
+        assert (getattr(model, "precision", "fp32") == "fp16") == (w == "cfg5")
         plan = model.engine().dry_plan(model, shape)
         assert len(plan.conv_steps) > 10
         if w == "cfg1":
