@@ -151,6 +151,11 @@ def test_conv_geometries_auto_config(ptx, g):
     close(hip_conv(ptx, x, w, s, p, bn=bn, relu=True), ref_conv(x, w, s, p, bn=bn, relu=True))
 
 
+def fp32_configs(lib):
+    """Tile configurations that take fp32 operands (the '/f16' ones have their own test)."""
+    return [i for i in range(lib.ptx_conv3d_num_configs()) if not lib.ptx_conv3d_config_name(i).decode().endswith("/f16")]
+
+
 def test_conv_every_config_and_split(ptx):
     lib = _lib(ptx)
     N, T, H, W, Ci, Co = 2, 3, 9, 10, 64, 160
@@ -159,7 +164,7 @@ def test_conv_every_config_and_split(ptx):
     res = rnd(N, Co, T, H, W, seed=7)
     want = ref_conv(x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res)
     errs = {}
-    for cfg in range(lib.ptx_conv3d_num_configs()):
+    for cfg in fp32_configs(lib):
         for split in (1, 2, 5):
             got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res, cfg=cfg, split=split)
             errs[(lib.ptx_conv3d_config_name(cfg).decode(), split)] = (got - want).abs().max().item()
@@ -201,7 +206,7 @@ def test_conv_ragged_channels_every_config(ptx):
     x, w = rnd(2, 51, 3, 7, 6, seed=8), rnd(85, 51, 1, 3, 3, seed=9, scale=0.05)
     bias = rnd(85, seed=10)
     want = ref_conv(x, w, (1, 1, 1), (0, 1, 1), bias=bias)
-    for cfg in range(lib.ptx_conv3d_num_configs()):
+    for cfg in fp32_configs(lib):
         close(hip_conv(ptx, x, w, (1, 1, 1), (0, 1, 1), bias=bias, cfg=cfg, split=1), want)
 
 
@@ -760,7 +765,7 @@ def test_grouped_conv(ptx):
     d.groups = 3
     assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, -1, 1, _st()) == 1
     # narrow groups packed as block-diagonal 32-wide super-groups -> MFMA tiles inside one super-group
-    mfma = [i for i, n in enumerate(names) if not n.endswith("/direct") and n.split("x")[1] in ("16", "32")]
+    mfma = [i for i, n in enumerate(names) if not n.endswith(("/direct", "/f16")) and n.split("x")[1] in ("16", "32")]
     assert len(mfma) >= 4
     for (N, T, H, W, Cc, G, s_) in [(2, 4, 9, 10, 128, 32, (1, 1, 1)), (1, 5, 11, 8, 256, 32, (2, 2, 2)), (2, 3, 6, 6, 64, 4, (1, 1, 1))]:
         gw = Cc // G
