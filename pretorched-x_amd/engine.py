@@ -841,7 +841,7 @@ class Engine:
     def max_batch(self, model, sample_shape):
         """Largest batch whose biggest plan tensor stays under the 2 GiB per-launch limit."""
         one = Plan(self, model, (1,) + tuple(sample_shape), torch.device("meta"))
-        per_clip = max(a.t.numel() * 4 for a in one.acts)
+        per_clip = max(a.t.numel() * a.t.element_size() for a in one.acts)
         return max(1, int(self.LIMIT_BYTES // per_clip))
 
     def _chunked(self, fn, model, x):
@@ -921,9 +921,10 @@ class Engine:
             mb = self._sig.get(key)
             if mb is None:
                 one = Plan(self, model, (1, model.dim_z), torch.device("meta"))
-                mb = self._sig[key] = max(1, int(self.LIMIT_BYTES // max(a.t.numel() * 4 for a in one.acts)))
-        if N > mb:
-            return torch.cat([self.generate(model, z[i:i + mb], y[i:i + mb]) for i in range(0, N, mb)], 0)
+                mb = self._sig[key] = max(1, int(self.LIMIT_BYTES // max(a.t.numel() * a.t.element_size() for a in one.acts)))
+        if N > mb:      # balanced chunks (64 -> 32 + 32, not 63 + 1): every chunk keeps the GEMMs' M large
+            size = -(-N // (-(-N // mb)))
+            return torch.cat([self.generate(model, z[i:i + size], y[i:i + size]) for i in range(0, N, size)], 0)
         with torch.cuda.device(z.device):
             plan = self.plan_for(model, z)
             plan.in_ptr2 = _ptr(y)
@@ -971,7 +972,8 @@ class Engine:
             if mb is None:
                 mb = self._sig[key] = self.max_batch(model, shape[1:])
         if N > mb:
-            return torch.cat([self.forward_frames(model, frames[i:i + mb], opts) for i in range(0, N, mb)], 0)
+            size = -(-N // (-(-N // mb)))
+            return torch.cat([self.forward_frames(model, frames[i:i + size], opts) for i in range(0, N, size)], 0)
         with torch.cuda.device(frames.device):
             plan = self.plan_for(model, frames, shape=shape, norm=norm)
             self._maybe_tune(model, plan, frames)
