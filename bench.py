@@ -69,6 +69,54 @@ def other_workload(name, rank):
     raise SystemExit("unknown workload %r" % name)
 
 
+def timed_steps(run, units_per_gpu, steps, warmup, dev, sync):
+    """The timed region of the bench contract -- W untimed warm-up steps, then exactly K steps bracketed by a
+    barrier + device synchronisation on both sides, MAX over ranks -- followed, for N > 1, by the self-check of
+    the clip-parallel step (parallel.verify_gather) OUTSIDE the timed region.  Backend-agnostic: the CPU test
+    drives this very function under gloo with a stand-in forward.
+    A step = one forward of this rank's units (+ the one all-gather of logits when N > 1).
+    Returns (elapsed seconds, last step output, verify dict or None)."""
+    import torch.distributed as dist
+    from pretorched_x_amd.parallel import gather_logits, verify_gather
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def step():
+        out = run()
+        if world > 1 and out.dim() == 2:           # class logits: the path's one collective (images stay sharded)
+            out = gather_logits(out, total=units_per_gpu * world)
+        return out
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    verify = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        local = run()
+        if local.dim() == 2:
+            verify = verify_gather(local, gather_logits(local, total=units_per_gpu * world))
+            # a second, independent forward must reproduce the timed steps' result bit for bit
+            verify["deterministic"] = bool(torch.equal(gather_logits(local, total=units_per_gpu * world), out))
+            flag = torch.tensor([int(verify["deterministic"])], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verify["deterministic"] = bool(flag.item())
+    return elapsed, out, verify
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +142,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import pretorched_x_amd as ptx
-    from pretorched_x_amd.parallel import gather_logits
+    from pretorched_x_amd.parallel import broadcast_tuned_table
     from pretorched_x_amd.testing import synth_clips, synth_state_dict
 
     headline = args.workload == "cfg2"
@@ -121,39 +169,33 @@ def main():
     run = (lambda: model(x)) if fwd is None else (lambda: fwd(model, x))
 
     eng = model.engine()
+    tuned_entries = None
     if not args.no_autotune:
-        if headline:
-            eng.autotune(model, x, iters=2, verbose=args.verbose and rank == 0)
-        else:
-            run()                                  # first call compiles the plan and times untuned tiles
+        # tile configurations are timed on rank 0 ONLY and broadcast: N tuners running at once on one node
+        # perturb each other's HIP-event timings, and every rank must launch the same kernels
+        if rank == 0:
+            if headline:
+                eng.autotune(model, x, iters=2, verbose=args.verbose)
+            else:
+                run()                              # first call compiles the plan and times untuned tiles
+            torch.cuda.synchronize()
+        if world > 1:
+            tuned_entries = broadcast_tuned_table(src=0)
+            eng.invalidate()                       # plans pick their tiles at compile time: recompile with the table
         if headline and rank == 0 and os.environ.get("PTX_TUNED_OUT"):
             from pretorched_x_amd.engine import save_tuned_table
             save_tuned_table(os.environ["PTX_TUNED_OUT"])
 
-    def step():
-        out = run()
-        if world > 1 and out.dim() == 2:           # class logits: the path's one collective (images stay sharded)
-            out = gather_logits(out, total=units_per_gpu * world)
-        return out
-
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
+    elapsed, out, verify = timed_steps(run, units_per_gpu, args.steps, args.warmup, dev, torch.cuda.synchronize)
+    ranks_seen = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
+                                      "name": torch.cuda.get_device_name(local), "pid": os.getpid(),
+                                      "plan_builds": eng.plan_builds})
+        ranks_seen = {"world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(),
+                      "distinct_devices": len({r["device"] for r in seen}), "ranks": seen,
+                      "tuned_entries_broadcast": tuned_entries}
 
     ms_per_step = 1e3 * elapsed / args.steps
     clips_per_s = units_per_gpu * world * args.steps / elapsed
@@ -214,6 +256,17 @@ def main():
         # ---- CPU baseline: the oracle restatement of the reference path on this box's host cores ----
         cpu = None
         parity = None
+        if not args.no_cpu_baseline and world > 1:
+            # N > 1: the CPU baseline is reported at N = 1 only (bench contract), but the line stays
+            # self-verifying -- rank 0 checks ITS OWN shard against the oracle (one bounded CPU forward)
+            xs = x_cpu if headline else x_cpu[:min(2, units_per_gpu)]
+            torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(1, world))))
+            want = cpu_fn(sd, xs)
+            got = run().cpu()[:xs.shape[0]]
+            parity = {"max_abs_dlogits": float((got - want).abs().max().item()),
+                      "max_abs_logit": float(want.abs().max().item()),
+                      "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
+                      "tolerance": tolerance, "scope": "rank 0's shard (%d %s) vs the CPU oracle" % (xs.shape[0], unit)}
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
             ncpu = os.cpu_count() or 1
             # bounded sample: the full batch for config 2, at most 2 units for the heavier configurations
@@ -259,6 +312,7 @@ def main():
                        "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
             "roofline": roofline, "roofline_net": roofline_net, "cpu_baseline": cpu, "parity": parity,
+            "distributed_check": verify, "ranks_seen": ranks_seen,
         }
     if world > 1:
         dist.barrier()

@@ -159,6 +159,12 @@ int ptx_pack_conv_weight(const ptx_pack_desc* desc, const float* w /* [Co][Ci][k
                          const float* bn_mean, const float* bn_var, float bn_eps,
                          float* w_packed, float* bias_out /* [Co_pad] */, ptx_stream_t stream);
 
+/* Weight-change detection for the host-side cache of packed filters (the reference re-reads its parameters
+ * on every forward, resnet3D.py:125-143, so edits such as `m.weight.data.fill_(1)`, resnet3D.py:199-201, take
+ * effect immediately): *out += a 64-bit position-sensitive sum over the bit patterns of n fp32 tensors,
+ * table[i] = (device pointer, element count) as int64 pairs in device memory; the caller zeroes *out first. */
+int ptx_checksum_f32(const int64_t* table, int32_t n, uint64_t* out, ptx_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * Layout transforms at the API edge (the reference's tensors are NCDHW, torchvision_models.py:448).
  * ------------------------------------------------------------------------------------------ */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "ptx_conv3d_dual_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
     "ptx_packed_weight_elems": (_Z, [C.POINTER(PackDesc)]),
     "ptx_pack_conv_weight": (C.c_int, [C.POINTER(PackDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "ptx_checksum_f32": (C.c_int, [_P, _I, _P, _P]),
     "ptx_ncdhw_to_ndhwc": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
     "ptx_ndhwc_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
     "ptx_fold_kw_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

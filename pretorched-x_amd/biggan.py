@@ -19,7 +19,7 @@ folded from ONE linear over all 50 cBN layers (`ptx_linear_fwd` + `ptx_cbn_fold`
 import torch
 import torch.nn as nn
 
-from .engine import Engine
+from .engine import EngineOwner
 from .zoo import Arch, Bag
 
 
@@ -66,7 +66,7 @@ _ARCH = {
 }
 
 
-class BigGANDeepGenerator(nn.Module):
+class BigGANDeepGenerator(EngineOwner, nn.Module):
     """forward(z [B,dim_z], y [B,shared_dim] = self.shared(labels)) -> images [B,3,R,R] in (-1, 1)."""
     plan_kind = "biggan"
 
@@ -105,27 +105,16 @@ class BigGANDeepGenerator(nn.Module):
         out_bn.channels = outs[-1] * ch
         self.output_layer = nn.ModuleList([out_bn, nn.ReLU(), nn.Conv2d(outs[-1] * ch, 3, 3, padding=1)])
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         # spectral-norm power-iteration buffers of the original release are not parameters here
         sd = {k: v for k, v in state_dict.items() if not (k.rsplit(".", 1)[-1].startswith(("u", "sv"))
                                                           and k.rsplit(".", 1)[-1][1:].lstrip("v").isdigit())}
-        r = super().load_state_dict(sd, strict=strict, **kw)
-        self._engine.invalidate()
-        return r
+        return super().load_state_dict(sd, strict=strict, **kw)
 
     def forward(self, z, y):
         return self._engine.generate(self, z, y)
-
-    def engine(self):
-        return self._engine
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        if "_engine" in self.__dict__:
-            self._engine.invalidate()
-        return r
 
 
 def biggan_deep(resolution=256, pretrained=None, **kwargs):

@@ -267,6 +267,29 @@ static unsigned grid_for(size_t work_items) {
     return (unsigned)b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// parameter checksum: a 64-bit, position-sensitive sum over the bit patterns of a SET of fp32 tensors
+// (table of (device pointer, element count) pairs).  The host compares it between forwards to notice
+// weight edits that bypass torch's version counters (`p.data.fill_(..)`); HBM-bound, one launch.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) checksum_f32_kernel(const long long* __restrict__ table, int n,
+                                                           unsigned long long* __restrict__ out) {
+    const int t = blockIdx.y;
+    const unsigned* __restrict__ p = reinterpret_cast<const unsigned*>(table[2 * t]);
+    const long long cnt = table[2 * t + 1];
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.x * 256)
+        acc += (unsigned long long)p[i] * (unsigned long long)(2654435761u * (unsigned)i | 1u);
+    acc *= (unsigned long long)(2 * t + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)acc, o, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(acc >> 32), o, 64);
+        acc += ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -422,4 +445,12 @@ extern "C" int ptx_fold_kw_frames_u8(const uint8_t* frames, float* y, int32_t N,
     hipLaunchKernelGGL(fold_kw_frames_u8_kernel, dim3((unsigned)(N * T * H)), dim3(256), (size_t)C * W * sizeof(float),
                        (hipStream_t)stream, frames, y, C, T, H, W, frame_step, T_full, kW, sW, pW, Wo, ld, *norm);
     return hip_check(hipGetLastError(), "fold_kw_frames_u8 launch");
+}
+
+extern "C" int ptx_checksum_f32(const int64_t* table, int32_t n, uint64_t* out, ptx_stream_t stream) {
+    if (!table || !out || n <= 0) return fail(PTX_ERR_INVALID, "checksum: null pointer / empty table");
+    if (n > 65535) return fail(PTX_ERR_UNSUPPORTED, "checksum: more than 65535 tensors");
+    hipLaunchKernelGGL(checksum_f32_kernel, dim3(32, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(table), n, reinterpret_cast<unsigned long long*>(out));
+    return hip_check(hipGetLastError(), "checksum launch");
 }

@@ -18,6 +18,7 @@ import ctypes as C
 import json
 import os
 import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -27,8 +28,19 @@ from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI
                    PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
-_tuned = None
+_tuned = None                    # conv problem key -> (tile configuration NAME, split-K)
 _tuned_lock = threading.Lock()
+_cfg_index = None                # configuration name -> index into this build's kConfigs table
+
+
+def _config_index(name):
+    """Index of a tile configuration by NAME in the loaded library (None when this build has no such tile).
+    The tuned table stores names, so inserting / reordering kConfigs entries cannot remap it silently."""
+    global _cfg_index
+    if _cfg_index is None:
+        lib = _lib.lib()
+        _cfg_index = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
+    return _cfg_index.get(name)
 
 
 def _tuned_table():
@@ -38,15 +50,48 @@ def _tuned_table():
             _tuned = {}
             if os.path.exists(_TUNED_PATH):
                 try:
-                    _tuned = {k: tuple(v) for k, v in json.load(open(_TUNED_PATH)).items()}
+                    _tuned = {k: (str(v[0]), int(v[1])) for k, v in json.load(open(_TUNED_PATH)).items()
+                              if isinstance(v[0], str)}
                 except Exception:
                     _tuned = {}
         return _tuned
 
 
-def save_tuned_table(path=_TUNED_PATH):
+def tuned_lookup(key, f16=False):
+    """(config index, split-K) of a tuned conv problem, or None: unknown keys, tiles this build does not
+    have and entries of the wrong operand precision all fall back to ptx_conv3d_pick_config."""
+    ent = _tuned_table().get(key)
+    if ent is None or ent[0].endswith("/f16") != bool(f16):
+        return None
+    idx = _config_index(ent[0])
+    return None if idx is None else (idx, ent[1])
+
+
+def tuned_store(key, cfg_index, split):
+    name = _lib.lib().ptx_conv3d_config_name(int(cfg_index)).decode()
+    table = _tuned_table()
     with _tuned_lock:
-        json.dump({k: list(v) for k, v in sorted((_tuned or {}).items())}, open(path, "w"), indent=0)
+        table[key] = (name, int(split))
+
+
+def tuned_snapshot():
+    table = _tuned_table()
+    with _tuned_lock:
+        return dict(table)
+
+
+def tuned_merge(entries):
+    """Adopt another process's tuned entries (rank 0 tunes, every rank runs the same tiles)."""
+    table = _tuned_table()
+    with _tuned_lock:
+        for k, v in entries.items():
+            table[k] = (str(v[0]), int(v[1]))
+
+
+def save_tuned_table(path=_TUNED_PATH):
+    snap = tuned_snapshot()
+    with open(path, "w") as f:
+        f.write("{\n" + ",\n".join('%s: ["%s", %d]' % (json.dumps(k), v[0], v[1]) for k, v in sorted(snap.items())) + "\n}\n")
 
 
 def _r4(v):
@@ -126,19 +171,35 @@ def _same_geometry(dims, k, s):
     return out, front
 
 
+class _Ref:
+    """A module of the model tree by qualified name.  Plans outlive the module OBJECTS they were compiled
+    from: torch.nn.DataParallel builds fresh replicas (new module objects, new broadcast copies of the
+    parameters) on every forward (reference examples/imagenet_eval.py:136), so everything a plan needs from
+    the model later -- weights to re-pack, the classifier head -- is re-resolved by name on the model that is
+    executing.  Modules outside the tree (never the case for zoo models) are held directly."""
+    __slots__ = ("name", "obj")
+
+    def __init__(self, name, obj=None):
+        self.name, self.obj = name, obj
+
+
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
-    def __init__(self, dev, convs, bn, fold_kw=False, scale=None, f16=False):
+    def __init__(self, plan, convs, bn, fold_kw=False, scale=None, f16=False):
+        dev = plan.dev
+        self.plan = plan
         self.f16 = bool(f16)         # filter stored as halfs for an fp16-operand conv
-        self.convs = list(convs)     # >1: concatenated along Co (non-local g/theta/phi)
-        self.bn = bn
-        self.scale = scale           # scalar Parameter multiplying the filter (self-attention gamma)
-        c0 = self.convs[0]
+        convs = list(convs)          # >1: concatenated along Co (non-local g/theta/phi)
+        self.convs = [plan.ref(c) for c in convs]
+        self.bn = plan.ref(bn) if bn is not None else None
+        # scalar Parameter multiplying the filter (self-attention gamma): (owning module, attribute name)
+        self.scale = (plan.ref(scale[0]), scale[1]) if scale is not None else None
+        c0 = convs[0]
         (kT, kH, kW), _, _ = _geom(c0)
-        self.Co = sum(c.out_channels for c in self.convs)
+        self.Co = sum(c.out_channels for c in convs)
         self.groups = int(getattr(c0, "groups", 1))
-        if self.groups > 1 and (len(self.convs) > 1 or fold_kw):
+        if self.groups > 1 and (len(convs) > 1 or fold_kw):
             raise PtxError("grouped convolutions are packed one at a time, unfolded")
         self.Ci = c0.in_channels // self.groups      # K extent of one filter row (per group)
         self.real_ci = self.Ci
@@ -167,7 +228,8 @@ class Packed:
         self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
 
     def refresh(self):
-        convs, bn = self.convs, self.bn
+        get = self.plan.get
+        convs, bn = [get(c) for c in self.convs], (get(self.bn) if self.bn is not None else None)
         if len(convs) == 1:
             w = convs[0].weight.detach()
             cb = convs[0].bias.detach() if convs[0].bias is not None else None
@@ -189,7 +251,8 @@ class Packed:
             eps = float(bn.eps)
         elif self.scale is not None:     # w * gamma through the BN-fold path: gamma / sqrt(1 + 0), beta = mean = 0
             one = torch.ones(self.Co, device=w.device, dtype=torch.float32)
-            ts = [one * self.scale.detach().reshape(()), torch.zeros_like(one), torch.zeros_like(one), one]
+            gamma = getattr(get(self.scale[0]), self.scale[1])
+            ts = [one * gamma.detach().reshape(()), torch.zeros_like(one), torch.zeros_like(one), one]
             keep += ts
             args = [_ptr(t) for t in ts]
         check(_lib.lib().ptx_pack_conv_weight(C.byref(self.d), _ptr(w), _ptr(cb) if cb is not None else null,
@@ -202,8 +265,10 @@ class PackedDual:
     """K-concatenated filter of a bottleneck's last 1x1x1 conv (+BN) and its shortcut-B conv (+BN):
     rows [Kc | Kc2], summed biases -- the operand of ptx_conv3d_dual_fwd."""
 
-    def __init__(self, dev, conv, bn, conv2, bn2):
-        self.parts = [(conv, bn), (conv2, bn2)]
+    def __init__(self, plan, conv, bn, conv2, bn2):
+        dev = plan.dev
+        self.plan = plan
+        self.parts = [(plan.ref(conv), plan.ref(bn)), (plan.ref(conv2), plan.ref(bn2))]
         self.Co, self.Ci, self.Ci2 = conv.out_channels, conv.in_channels, conv2.in_channels
         assert conv2.out_channels == self.Co
         self.Kc, self.Kc2 = _r4(self.Ci), _r4(self.Ci2)
@@ -219,6 +284,7 @@ class PackedDual:
     def refresh(self):
         null = C.c_void_p(0)
         for d, (conv, bn) in zip(self.descs, self.parts):
+            conv, bn = self.plan.get(conv), self.plan.get(bn)
             w = conv.weight.detach().contiguous()
             cb = conv.bias.detach().contiguous() if conv.bias is not None else None
             ts = [t.contiguous() for t in (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)]
@@ -267,19 +333,39 @@ class Plan:
         self.tuned = False
         self.graph = None
         self.fuse_shortcut = os.environ.get("PTX_FUSE_SHORTCUT", "1") != "0"
+        # qualified names of the model's modules: everything the plan keeps from the model is a _Ref
+        self._names = {id(m): n for n, m in model.named_modules()}
+        self._cur = model                # the model (or DataParallel replica) whose tensors are valid right now
         with _device_ctx(dev):
             self._build(model)
             if self.ws_bytes:
                 self.ws = torch.empty(self.ws_bytes // 4, device=dev, dtype=torch.float32)
                 self.ws_ptr = _ptr(self.ws)
+        self._cur = None
+
+    # ---------------------------------------------------------------- model references
+    def ref(self, module):
+        name = self._names.get(id(module))
+        return _Ref(name) if name is not None else _Ref(None, module)
+
+    def get(self, ref):
+        if ref.name is None:
+            return ref.obj
+        if self._cur is None:
+            raise PtxError("plan used outside a bound model (internal error)")
+        return self._cur.get_submodule(ref.name) if ref.name else self._cur
+
+    def bind(self, model):
+        self._cur = model
 
     # ---------------------------------------------------------------- building blocks
     def pack(self, convs, bn, fold_kw=False, scale=None, f16=False):
+        """scale: (module, attribute name) of a scalar Parameter multiplying the filter."""
         if not isinstance(convs, (list, tuple)):
             convs = [convs]
-        key = (tuple(id(c) for c in convs), id(bn), fold_kw, id(scale), bool(f16))
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw, None if scale is None else (id(scale[0]), scale[1]), bool(f16))
         if key not in self._pack_cache:
-            p = Packed(self.dev, convs, bn, fold_kw, scale, f16)
+            p = Packed(self, convs, bn, fold_kw, scale, f16)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]
@@ -287,7 +373,7 @@ class Plan:
     def pack_dual(self, conv, bn, conv2, bn2):
         key = ("dual", id(conv), id(bn), id(conv2), id(bn2))
         if key not in self._pack_cache:
-            p = PackedDual(self.dev, conv, bn, conv2, bn2)
+            p = PackedDual(self, conv, bn, conv2, bn2)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]
@@ -359,9 +445,9 @@ class Plan:
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
-        tuned = _tuned_table().get(key)
+        tuned = tuned_lookup(key, half)
         if tuned is not None:
-            st.cfg, st.split = int(tuned[0]), int(tuned[1])
+            st.cfg, st.split = tuned
         else:
             sk = C.c_int(1)
             st.cfg = self.lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))
@@ -504,11 +590,11 @@ class Plan:
             av = torch.empty(N * Sq, device=self.dev, dtype=torch.float32)
             bv = torch.empty(N * Sk, device=self.dev, dtype=torch.float32)
             self.keepalive += [av, bv]
-            avp, bvp, proj = _ptr(av), _ptr(bv), nl.concat_project[0]
+            avp, bvp, proj_ref = _ptr(av), _ptr(bv), self.ref(nl.concat_project[0])
 
         def step(st):
             if mode == "concatenation":
-                w = proj.weight.detach().reshape(-1).contiguous()          # [2*ci]: theta half | phi half
+                w = self.get(proj_ref).weight.detach().reshape(-1).contiguous()          # [2*ci]: theta half | phi half
                 check(lib.ptx_linear_fwd(th, _ptr(w), None, avp, N * Sq, ci, 1, lda, 1, 0, st), "concat a")
                 check(lib.ptx_linear_fwd(ph, _ptr(w, ci), None, bvp, N * Sk, ci, 1, ldb, 1, 0, st), "concat b")
                 check(lib.ptx_outer_sum_relu(avp, bvp, fp, N, Sq, Sk, ldf, st), "concat f")
@@ -599,9 +685,10 @@ class Plan:
         f32 = dict(device=self.dev, dtype=torch.float32)
         sc, sh = torch.empty(x.C, **f32), torch.empty(x.C, **f32)
         self.keepalive += [sc, sh]
-        lib, eps, C_ = self.lib, float(bn.eps), x.C
+        lib, eps, C_, bn_ref = self.lib, float(bn.eps), x.C, self.ref(bn)
 
         def refresh():
+            bn = self.get(bn_ref)
             ts = [t.contiguous() for t in (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)]
             check(lib.ptx_cbn_fold(_ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), C.c_float(eps), _ptr(sc), _ptr(sh),
                                    1, C_, 0, 0, C_, 0, _stream()), "bn fold " + label)
@@ -650,7 +737,9 @@ class Plan:
             out = model.head_module(self.pooled.clone())
         return out
 
-    def refresh_weights(self):
+    def refresh_weights(self, model):
+        """Re-pack every filter (and rebuild the weight-derived tables) from `model`'s current tensors."""
+        self.bind(model)
         keep = []
         for p in self.packs:
             keep.append(p.refresh())
@@ -702,9 +791,27 @@ def _foldable(conv, x):
     return isinstance(x, RawInput)
 
 
+def _is_replica(model):
+    return bool(getattr(model, "_is_replica", False))
+
+
+def _first_weight(model):
+    """A weight tensor of the model: works for DataParallel replicas too, whose `parameters()` is empty
+    (replicate() stores the broadcast copies as plain attributes)."""
+    for m in model.modules():
+        w = getattr(m, "weight", None)
+        if isinstance(w, torch.Tensor):
+            return w
+    raise PtxError("model has no weights")
+
+
 class Engine:
-    """Per-model executor.  Stateless w.r.t. the model object (DataParallel replicas share it),
-    caches keyed by device."""
+    """Per-model executor, shared by the model and its torch.nn.DataParallel replicas (a replica's __dict__
+    is a copy of the model's, so `_engine` is the same object).  Plans -- packed filters, activation buffers,
+    launch lists -- are keyed by (input shape, device); whether the packed filters are current is decided from
+    the OWNER model's parameters (replicas are rebuilt on every forward and carry fresh broadcast copies of
+    the same values), and a re-pack reads the tensors of whichever model / replica is executing on that
+    device."""
 
     def __init__(self, model=None):
         self._plans = collections.OrderedDict()
@@ -713,7 +820,23 @@ class Engine:
         self.max_plans = int(os.environ.get("PTX_MAX_PLANS", "16"))
         self._lock = threading.RLock()
         self._sig = {}
-        self.check_weights = True
+        self._owner = weakref.ref(model) if model is not None else None
+        self._epoch = 0                  # bumped by invalidate(): load_state_dict / .to() / refresh()
+        self._tensors = None             # (epoch, flat list of the owner's parameters and buffers)
+        self.plan_builds = 0             # diagnostics: plans compiled / filter re-packs so far
+        self.weight_refreshes = 0
+        # How a forward decides whether the packed (BN-folded) filters are still current:
+        #   True / "version"  (default) compare (data_ptr, _version) of every parameter and buffer of the owner
+        #                     model -- catches load_state_dict, optimizer-style in-place updates, copy_();
+        #                     ~50 us of host time per forward for ResNet3D-50 (the tensor list is cached)
+        #   "checksum"        additionally compare a device-side checksum of the parameter bytes
+        #                     (ptx_checksum_f32): also catches edits through `.data`, which bypass the version
+        #                     counters (`p.data.fill_(1)` leaves p._version unchanged); one extra launch + a
+        #                     device->host sync per forward
+        #   False             O(1): only invalidate() / model.refresh() / load_state_dict / .to() re-pack
+        self.check_weights = os.environ.get("PTX_CHECK_WEIGHTS", "version")
+        if self.check_weights in ("0", "false", "False"):
+            self.check_weights = False
         # tile configurations of conv problems that are not in the tuned table are timed (HIP events,
         # < 1 s per network) the first time a plan runs; PTX_AUTOTUNE=0 keeps the heuristic defaults
         self.auto_tune = os.environ.get("PTX_AUTOTUNE", "1") != "0"
@@ -735,6 +858,19 @@ class Engine:
         with self._lock:
             self._plans.clear()
             self._sig.clear()
+            self._epoch += 1
+            self._tensors = None
+
+    def owner(self, model):
+        """The model whose parameters define weight identity: the constructed model itself; for a
+        DataParallel replica the model it was replicated from."""
+        if not _is_replica(model):
+            if self._owner is None or self._owner() is not model:
+                self._owner = weakref.ref(model)      # deep copies / unpickled models bind on first use
+                self._tensors = None
+            return model
+        own = self._owner() if self._owner is not None else None
+        return own if own is not None else model
 
     def dry_plan(self, model, shape):
         """Compile a plan on the 'meta' device: every descriptor, tile choice and buffer shape is
@@ -754,24 +890,55 @@ class Engine:
         want = 4 if dims == 2 else 5
         if x.dim() != want:
             raise PtxError("expected a %d-D input, got shape %s" % (want, tuple(x.shape)))
-        p = next(model.parameters())
+        p = _first_weight(model)
         if p.device != x.device:
             raise PtxError("input on %s but parameters on %s" % (x.device, p.device))
 
-    @staticmethod
-    def _signature(model):
-        return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+    def _owner_tensors(self, root):
+        """Flat list of the owner's parameters and buffers, cached until the next invalidate(): walking the
+        module tree costs ~0.4 ms per call for ResNet3D-50, reading 480 version counters ~50 us."""
+        cached = self._tensors
+        if cached is None or cached[0] != self._epoch or cached[1] is not root:
+            ts = list(root.parameters()) + list(root.buffers())
+            if not ts and _is_replica(root):             # an orphan replica: its broadcast copies
+                ts = [t for m in root.modules() for t in getattr(m, "_former_parameters", {}).values()]
+                ts += list(root.buffers())
+            cached = self._tensors = (self._epoch, root, ts)
+        return cached[2]
+
+    def _signature(self, model):
+        root = self.owner(model)
+        ts = self._owner_tensors(root)
+        sig = tuple((t.data_ptr(), t._version) for t in ts)
+        if self.check_weights == "checksum":
+            sig = (sig, self._checksum(ts))
+        return sig
+
+    def _checksum(self, ts):
+        """Order-independent 64-bit sum of the fp32 bit patterns of every floating-point tensor, computed
+        on the device the tensors live on (ptx_checksum_f32); synchronises on the result."""
+        fl = [t for t in ts if t.is_cuda and t.dtype == torch.float32 and t.numel() > 0]
+        if not fl:
+            return 0
+        dev = fl[0].device
+        with torch.cuda.device(dev):
+            tab = torch.tensor([[t.data_ptr(), t.numel()] for t in fl], dtype=torch.int64).to(dev)
+            out = torch.zeros(1, dtype=torch.int64, device=dev)
+            check(_lib.lib().ptx_checksum_f32(C.c_void_p(tab.data_ptr()), len(fl), C.c_void_p(out.data_ptr()), _stream()),
+                  "ptx_checksum_f32")
+            return int(out.item())
 
     def plan_for(self, model, x, shape=None, norm=None):
         """shape / norm: the NCDHW view and NormDesc of a uint8-frames input (forward_frames)."""
         shape = tuple(x.shape) if shape is None else tuple(shape)
         nkey = None if norm is None else (tuple(norm.mean), tuple(norm.std), norm.swap_rb, norm.to_255)
-        key = (shape, x.device.index, id(model), nkey)
+        key = (shape, x.device.index, nkey)
         with self._lock:
             plan = self._plans.get(key)
             fresh = plan is None
             if fresh:
                 plan = Plan(self, model, shape, x.device, norm)
+                self.plan_builds += 1
                 self._plans[key] = plan
                 while len(self._plans) > max(1, self.max_plans):
                     old, _ = self._plans.popitem(last=False)         # LRU eviction frees the plan's buffers
@@ -781,8 +948,10 @@ class Engine:
             if fresh or self.check_weights:
                 sig = self._signature(model)
                 if fresh or self._sig.get(key) != sig:
-                    with torch.cuda.device(x.device):
-                        plan.refresh_weights()
+                    # the re-pack writes the filters other host threads' runs may still be reading
+                    with torch.cuda.device(x.device), plan.exclusive():
+                        plan.refresh_weights(model)
+                    self.weight_refreshes += 1
                     self._sig[key] = sig
             return plan
 
@@ -798,6 +967,7 @@ class Engine:
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
             with plan.exclusive():
+                plan.bind(model)
                 f = plan.run_features(x)
                 if model.arch.dims == 2:
                     out = torch.empty((f.N, f.C, f.H, f.W), device=x.device, dtype=torch.float32)
@@ -846,7 +1016,7 @@ class Engine:
 
     def _chunked(self, fn, model, x):
         """Run `fn(model, chunk)` over batch slices that respect the per-launch size limit."""
-        key = ("maxb", tuple(x.shape[1:]), id(model))
+        key = ("maxb", tuple(x.shape[1:]))
         with self._lock:
             mb = self._sig.get(key)
             if mb is None:
@@ -858,10 +1028,19 @@ class Engine:
         return torch.cat([fn(model, x[i:i + size]) for i in range(0, x.shape[0], size)], 0)
 
     def _maybe_tune(self, model, plan, x):
-        if self.auto_tune and not plan.tuned:
+        """First use of a plan: time the tile configurations of conv problems the tuned table does not know.
+        Runs under the plan's exclusive lock (the tuner relaunches convs into the plan's buffers and edits
+        the steps' tile choices), and `plan.tuned` is set only when it is done, so a second thread arriving
+        meanwhile waits instead of running a half-tuned plan."""
+        if not self.auto_tune or plan.tuned:
+            return
+        with plan.exclusive():
+            if plan.tuned:
+                return
+            if any(tuned_lookup(json.dumps(s.d.key()), bool(s.d.flags & PTX_F16_OPERANDS)) is None
+                   for s in plan.conv_steps):
+                self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
-            if any(json.dumps(s.d.key()) not in _tuned_table() for s in plan.conv_steps):
-                self.autotune(model, x, iters=2, only_untuned=True, plan=plan)
 
     def _forward_graph(self, model, plan, x):
         """Capture (once) and replay forward() as a hipGraph.  The input is staged into a static
@@ -884,6 +1063,7 @@ class Engine:
 
     def _forward_eager(self, model, plan, x):
         with plan.exclusive():
+            plan.bind(model)
             plan.run_features(x)
             return plan.run_head(self, model)
 
@@ -916,7 +1096,7 @@ class Engine:
             raise PtxError("generate: z and y must share batch size and device")
         z, y = z.contiguous(), y.contiguous()
         N = z.shape[0]
-        key = ("maxb", ("biggan",), id(model))
+        key = ("maxb", ("biggan",))
         with self._lock:
             mb = self._sig.get(key)
             if mb is None:
@@ -930,6 +1110,7 @@ class Engine:
             plan.in_ptr2 = _ptr(y)
             self._maybe_tune(model, plan, z)
             with plan.exclusive():
+                plan.bind(model)
                 plan.in_ptr2 = _ptr(y)
                 f = plan.run_features(z)
                 out = torch.empty((N, 3, f.H, f.W), device=z.device, dtype=torch.float32)
@@ -966,7 +1147,7 @@ class Engine:
         else:
             N, H, W, Cc = frames.shape
             shape = (N, Cc, H, W)
-        key = ("maxb", shape[1:], id(model))
+        key = ("maxb", shape[1:])
         with self._lock:
             mb = self._sig.get(key)
             if mb is None:
@@ -981,15 +1162,21 @@ class Engine:
 
     def autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False, plan=None):
         """Time every compiled tile configuration (x a few split-K factors) for each distinct conv
-        problem of the plan with HIP events and keep the fastest."""
+        problem of the plan with HIP events and keep the fastest.  Holds the plan's exclusive lock: the
+        tuner relaunches convs into the plan's buffers."""
         if plan is None:
             self._validate(model, x, model.arch.dims)
+            with torch.cuda.device(x.device):
+                plan = self.plan_for(model, x.contiguous())
+        with torch.cuda.device(x.device), plan.exclusive():
+            return self._autotune(model, x, iters, verbose, persist, only_untuned, plan)
+
+    def _autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False, plan=None):
         lib = _lib.lib()
-        table = _tuned_table()
         with torch.cuda.device(x.device):
             if plan is None:
                 plan = self.plan_for(model, x.contiguous())
-            plan.tuned = True
+            plan.bind(model)
             plan.run_features(x.contiguous())      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
             seen = {}
@@ -999,7 +1186,7 @@ class Engine:
                 if key in seen:
                     stp.cfg, stp.split = seen[key]
                     continue
-                if only_untuned and key in table:
+                if only_untuned and tuned_lookup(key, bool(stp.d.flags & PTX_F16_OPERANDS)) is not None:
                     continue
                 best = None
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
@@ -1057,13 +1244,14 @@ class Engine:
                     best = (float("nan"), lib.ptx_conv3d_pick_config(C.byref(stp.d), C.byref(sk)), sk.value)
                 stp.cfg, stp.split = best[1], best[2]
                 seen[key] = (best[1], best[2])
-                table[key] = (best[1], best[2])
+                tuned_store(key, best[1], best[2])
                 if verbose:
                     print("tune %-34s M=%-8d N=%-5d K=%-6d -> %-20s split=%d  %.3f ms  %.1f TF" % (
                         stp.label, M, stp.d.Co, stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW,
                         lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
                         2e-9 * stp.macs / best[0]))
             plan.run_features(x.contiguous())
+            plan.tuned = True
             if log is not None:
                 log.close()
         if persist:
@@ -1078,6 +1266,7 @@ class Engine:
             if plan is None:
                 self._validate(model, x, model.arch.dims)
                 plan = self.plan_for(model, x.contiguous())
+                plan.bind(model)
                 plan.run_features(x.contiguous())
             for stp in plan.conv_steps:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1092,16 +1281,49 @@ class Engine:
         return rows
 
 
+class EngineOwner:
+    """nn.Module plumbing shared by every HIP-executed model class: the per-model Engine and the hooks
+    that tell it the weights changed.  Mixed in ahead of nn.Module."""
+
+    def _init_engine(self):
+        self._engine = Engine(self)
+
+    def engine(self):
+        return self._engine
+
+    def refresh(self):
+        """Drop every compiled plan and packed (BN-folded) filter: the next forward re-reads the parameters.
+        load_state_dict(), .to()/.cuda() and in-place updates that bump a tensor's version counter are noticed
+        automatically; edits made through `.data` (e.g. `m.weight.data.fill_(1)`), replaced trunk modules and
+        `engine().check_weights = False` need this call (or `engine().check_weights = "checksum"`)."""
+        self._engine.invalidate()
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._engine.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if "_engine" in self.__dict__:
+            self._engine.invalidate()
+        return r
+
+
 # ---------------------------------------------------------------------------------------------
 # TRN relation MLP (trn.py:39-45): ReLU -> Linear -> ReLU -> Linear
 # ---------------------------------------------------------------------------------------------
 def linear(x, lin, flags=0):
     """y = x @ W^T + b through ptx_linear_fwd for any [..., K] float32 CUDA tensor (TRN classifier,
     trn.py:257-258)."""
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise PtxError("linear: input must be a float32 CUDA tensor (no CPU fallback)")
     if not isinstance(lin, torch.nn.Linear):
         return lin(x)                                   # user-replaced head: theirs to run
+    from . import eager
+    if eager.wanted(lin, x):                            # train() / autograd / CPU model (eager.py)
+        return lin(x)
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise PtxError("linear: input must be a float32 CUDA tensor (no CPU fallback)")
     K = lin.in_features
     flat = x.contiguous().view(-1, K)
     M = flat.shape[0]

@@ -14,7 +14,7 @@ four branches of an Inception module write their channel slices of the module ou
 """
 import torch.nn as nn
 
-from .engine import Engine
+from .engine import EngineOwner
 from .zoo import Arch, Bag
 
 
@@ -57,7 +57,7 @@ _LAYOUT = (
 )
 
 
-class InceptionI3d(nn.Module):
+class InceptionI3d(EngineOwner, nn.Module):
     """[B,3,T,224,224] -> [B,num_classes]: per-frame logits averaged over the remaining time steps (the
     original model's `reduce_mean(logits, axis=1)`).  `features` returns the Mixed_5c map."""
     plan_kind = "i3d"
@@ -76,7 +76,7 @@ class InceptionI3d(nn.Module):
         self.dropout = nn.Dropout(dropout_keep_prob)
         self.logits = _unit(1024, num_classes, bn=False, bias=True)
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
     @property
     def head_module(self):
@@ -98,15 +98,6 @@ class InceptionI3d(nn.Module):
 
     def forward_frames(self, frames, opts):
         return self._engine.forward_frames(self, frames, opts)
-
-    def engine(self):
-        return self._engine
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        if "_engine" in self.__dict__:
-            self._engine.invalidate()
-        return r
 
 
 def i3d(num_classes=400, pretrained=None):

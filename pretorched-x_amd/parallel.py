@@ -63,3 +63,42 @@ def clip_parallel_forward(forward_fn, local_clips, total=None, group=None):
     """Run `forward_fn` (e.g. a pretorched_x_amd model) on this rank's clips and return the logits
     of the WHOLE batch on every rank."""
     return gather_logits(forward_fn(local_clips), total=total, group=group)
+
+
+def verify_gather(local_logits, gathered, group=None):
+    """Self-check of the clip-parallel step, run on EVERY rank (bench.py does it after the timed region):
+      * order: this rank's rows of the gathered tensor are bit-identical to what it computed
+        (rank order == clip order, the reference's DataParallel gather semantics,
+        examples/imagenet_eval.py:136);
+      * replicas: every rank holds bit-identical gathered logits (element-wise MAX == MIN over ranks of the
+        int32 bit patterns);
+    both flags are all-reduced, so the returned dict is the same on every rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = local_logits.shape[0]
+    counts = torch.zeros(world, dtype=torch.int64, device=local_logits.device)
+    counts[rank] = n
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    start = int(counts[:rank].sum().item())
+    total = int(counts.sum().item())
+    order_ok = gathered.shape[0] == total and bool(torch.equal(gathered[start:start + n], local_logits))
+    bits = gathered.contiguous().view(torch.int32)
+    hi, lo = bits.clone(), bits.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    same = bool(torch.equal(hi, lo))
+    flags = torch.tensor([int(order_ok), int(same)], dtype=torch.int32, device=local_logits.device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+    return {"gather_order_ok": bool(flags[0].item()), "replicas_identical": bool(flags[1].item()),
+            "ranks": world, "rows": total}
+
+
+def broadcast_tuned_table(src=0, group=None):
+    """Tile choices measured on rank `src` (Engine.autotune) adopted by every rank: N concurrent tuners on one
+    node perturb each other's HIP-event timings, and every rank should run the same kernels anyway."""
+    from . import engine as _engine
+    box = [_engine.tuned_snapshot() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    if dist.get_rank(group) != src:
+        _engine.tuned_merge(box[0])
+    return len(box[0])

@@ -201,21 +201,26 @@ def build_biggan(self, model):
     w0, b0 = torch.empty((bw * bw * c0, cond_dim), **f32), torch.empty(bw * bw * c0, **f32)
     self.keepalive += [cond, wg, wb, mean_all, var_all, gain_all, bias_all, scale_all, shift_all, oscale, oshift, w0, b0]
 
+    bn_refs = [(self.ref(bn), offs[id(bn)], bn.channels) for bn in ccbns]
+    lin_ref, obn_ref = self.ref(model.linear), self.ref(obn)
+
     def refresh_tables():
         # weight relayout only (concatenation / row permutation), rebuilt when a parameter changes
-        for bn in ccbns:
-            o, c = offs[id(bn)], bn.channels
+        linear = self.get(lin_ref)
+        for r, o, c in bn_refs:
+            bn = self.get(r)
             wg[o:o + c].copy_(bn.gain.weight.detach())
             wb[o:o + c].copy_(bn.bias.weight.detach())
             mean_all[o:o + c].copy_(bn.stored_mean)
             var_all[o:o + c].copy_(bn.stored_var)
         # first Linear emits NCHW-ordered features (c, h, w); permute its rows so it writes NHWC directly
-        w0.copy_(model.linear.weight.detach().view(c0, bw, bw, cond_dim).permute(1, 2, 0, 3).reshape(-1, cond_dim))
-        b0.copy_(model.linear.bias.detach().view(c0, bw, bw).permute(1, 2, 0).reshape(-1))
+        w0.copy_(linear.weight.detach().view(c0, bw, bw, cond_dim).permute(1, 2, 0, 3).reshape(-1, cond_dim))
+        b0.copy_(linear.bias.detach().view(c0, bw, bw).permute(1, 2, 0).reshape(-1))
     if torch.device(dev).type != "meta":
         self.refreshers.append(refresh_tables)
 
     def prologue(st, self=self):
+        obn = self.get(obn_ref)
         # y = cat([shared(labels), z], 1); all cBN gains/biases in two GEMVs; fold with the stored statistics
         check(lib.ptx_copy2d(self.in_ptr2, _ptr(cond), N, sdim, sdim, cond_dim, st), "cond.y")
         check(lib.ptx_copy2d(self.in_ptr, _ptr(cond, sdim), N, cond_dim - sdim, cond_dim - sdim, cond_dim, st), "cond.z")
@@ -299,4 +304,4 @@ def biggan_attention(self, x, att, name):
         check(lib.ptx_transpose_last2(gp, gtp, N, S4, c2, ldg, ldf, st), "attn g^T")
         check(lib.ptx_bgemm_nt(fp, gtp, yp, N, HW, c2, S4, ldf, ldf, yld, HW * ldf, c2 * ldf, HW * yld, st), "attn y")
     self.steps.append(step)
-    return self.conv(yatt, self.pack(att.o, None, scale=att.gamma), one, zero, res=x, label=name + ".o")
+    return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma")), one, zero, res=x, label=name + ".o")

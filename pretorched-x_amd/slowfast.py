@@ -15,7 +15,7 @@ What the engine does differently from the reference graph (slowfast.py:140-156, 
 """
 import torch.nn as nn
 
-from .engine import Engine
+from .engine import EngineOwner
 from .zoo import Arch, Bag
 
 # the reference passes block *classes*; here the two kinds are named by these constants
@@ -141,7 +141,7 @@ class Fast(_Pathway):
         raise RuntimeError("Fast holds parameters; run it through SlowFast or FastOnly")
 
 
-class _Runnable:
+class _Runnable(EngineOwner):
     plan_kind = "slowfast"
 
     @property
@@ -155,15 +155,6 @@ class _Runnable:
     def forward_frames(self, frames, opts):
         """Decoded uint8 frames [B,T,H,W,3] -> logits, normalisation fused into the stems."""
         return self._engine.forward_frames(self, frames, opts)
-
-    def engine(self):
-        return self._engine
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        if "_engine" in self.__dict__:
-            self._engine.invalidate()
-        return r
 
 
 class SlowFast(_Runnable, nn.Module):
@@ -181,7 +172,7 @@ class SlowFast(_Runnable, nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.last_linear = nn.Linear(self.fast.inplanes + 512 * self.expansion, num_classes, bias=False)
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
 
 class SlowOnly(_Runnable, _Pathway):
@@ -197,7 +188,7 @@ class SlowOnly(_Runnable, _Pathway):
         self.dropout = nn.Dropout(dropout)
         self.last_linear = nn.Linear(self.inplanes, num_classes)
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
 
 class FastOnly(_Runnable, _Pathway):
@@ -212,7 +203,7 @@ class FastOnly(_Runnable, _Pathway):
         self.dropout = nn.Dropout(dropout)
         self.last_linear = nn.Linear(self.inplanes, num_classes)
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
 
 _MODES = {"sf": SlowFast, "f": FastOnly, "s": SlowOnly}

@@ -23,7 +23,8 @@ from typing import Optional, Sequence
 import torch
 import torch.nn as nn
 
-from .engine import Engine
+from . import eager
+from .engine import Engine, EngineOwner  # noqa: F401
 
 
 @dataclass(frozen=True)
@@ -139,7 +140,7 @@ def _nonlocal(channels):
     return nl
 
 
-class NonLocalBlock3D(nn.Module):
+class NonLocalBlock3D(EngineOwner, nn.Module):
     """Standalone non-local block with the reference's constructor and parameter names
     (nonlocalnet.py:51-131, :264-270): z = W(y) + x over [B,C,T,H,W].  HIP path: modes embedded_gaussian,
     dot_product, gaussian and concatenation, with or without `sub_sample` / `bn_layer`."""
@@ -172,19 +173,13 @@ class NonLocalBlock3D(nn.Module):
             self.g = nn.Sequential(self.g, nn.MaxPool3d(kernel_size=2))
             self.phi = nn.MaxPool3d(kernel_size=2) if self.phi is None else nn.Sequential(self.phi, nn.MaxPool3d(kernel_size=2))
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
     def forward(self, x):
+        if eager.wanted(self, x):          # train() / autograd / CPU tensors: the torch.nn path (eager.py)
+            eager._count()
+            return eager.nonlocal_block(self, x)
         return self._engine.features(self, x)
-
-    def engine(self):
-        return self._engine
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        if "_engine" in self.__dict__:
-            self._engine.invalidate()
-        return r
 
 
 def _block(arch, cin, planes, stride, with_down, with_nl):
@@ -245,7 +240,7 @@ def nl_placement(blocks, nonlocal_blocks):
     return [(i % freq == 0 and freq > 0) for i in range(blocks)]
 
 
-class VideoResNet(nn.Module):
+class VideoResNet(EngineOwner, nn.Module):
     """ResNet3D / R2Plus1D / NonLocalResNet3D / 2-D ResNet, one class, table driven."""
 
     def __init__(self, arch_name, num_classes):
@@ -281,7 +276,7 @@ class VideoResNet(nn.Module):
             self.last_linear = nn.Linear(arch.widths[3] * arch.expansion, num_classes)
         self._init_like_reference()
         self.eval()
-        self._engine = Engine()
+        self._init_engine()
 
     # -- initialisation with the reference's distributions (resnet3D.py:195-201, r2plus1d.py:103) --
     def _init_like_reference(self):
@@ -297,13 +292,21 @@ class VideoResNet(nn.Module):
         return self.fc if self.arch.head == "fc" else self.last_linear
 
     # -- the reference Model API (README "Model API"; torchvision_models.py:448-469) --
+    # eval mode + ROCm tensors: the HIP engine, always (it raises rather than degrade).  train() mode, inputs
+    # that require grad and CPU models are outside its contract and run the torch.nn path (eager.py)
     def features(self, input):
+        if eager.wanted(self, input):
+            return eager.resnet_features(self, input)
         return self._engine.features(self, input)
 
     def logits(self, features):
+        if eager.wanted(self, features):
+            return eager.resnet_logits(self, features)
         return self._engine.logits(self, features)
 
     def forward(self, input):
+        if eager.wanted(self, input):
+            return eager.resnet_forward(self, input)
         return self._engine.forward(self, input)
 
     def forward_frames(self, frames, opts=None):
@@ -311,21 +314,6 @@ class VideoResNet(nn.Module):
         reference's TransformImage (transforms/utils.py:72-75) is fused into the stem's fold kernel.
         opts: mean/std/input_space/input_range holder; default: this model's pretrained settings."""
         return self._engine.forward_frames(self, frames, opts)
-
-    def engine(self):
-        return self._engine
-
-    # nn.Module plumbing that must invalidate packed weights
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
-        self._engine.invalidate()
-        return r
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        if "_engine" in self.__dict__:
-            self._engine.invalidate()
-        return r
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,6 +332,8 @@ class Relation(nn.Module):
 
     def forward(self, input):
         from .engine import relation_mlp
+        if eager.wanted(self, input):
+            return eager.relation(self, input)
         flat = input.contiguous().view(-1, self.num_inputs * self.in_features)
         out = relation_mlp(flat, self.relate[1], self.relate[3])
         return out.view(input.size(0), -1, self.out_features)
@@ -371,6 +361,13 @@ class MultiScaleRelation(nn.Module):
         from ._lib import PTX_REL_MAX_FRAMES, PTX_REL_MAX_SETS
         from .engine import relation_mlp, relation_scale
         x = input.contiguous().view(-1, self.num_input, self.in_features)        # [B, T, F]
+        if eager.wanted(self, input):          # trn.py:95-113 on the torch.nn path: same RNG consumption
+            outs = []
+            for si in range(len(self.scales)):
+                picks = np.random.choice(len(self.relations_scales[si]), self.subsample_scales[si], replace=False)
+                for idx in picks:
+                    outs.append(self.relations[si](input[..., self.relations_scales[si][idx], :]))
+            return torch.stack(outs).sum(0).view(input.size(0), -1, self.out_features)
         grouped = (self.in_features % 4 == 0 and self.num_input <= PTX_REL_MAX_FRAMES
                    and max(self.subsample_scales) <= PTX_REL_MAX_SETS)
         total = None

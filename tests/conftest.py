@@ -27,6 +27,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _gpu_tests_never_take_the_torch_nn_path(request):
+    """`-m gpu` tests are parity tests of the HIP path: the torch.nn (train / CPU) path of eager.py must not
+    serve a single forward in them."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from pretorched_x_amd import eager
+    before = eager.calls
+    yield
+    assert eager.calls == before, "a GPU parity test ran the torch.nn path instead of the HIP engine"
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

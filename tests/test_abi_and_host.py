@@ -105,17 +105,133 @@ def test_registry_and_weight_abi(ptx):
     assert ptx.factored_mid_channels(64, 64, 3) == 144 and ptx.factored_mid_channels(3, 64, 7) == 110
 
 
-def test_no_cpu_fallback(ptx):
+def test_hip_engine_never_degrades(ptx, monkeypatch):
+    """Eval mode on ROCm tensors is ALWAYS the HIP engine; the engine itself has no CPU / training path."""
     m = ptx.resnet3d10()
+    eng = m.engine()
+    with pytest.raises(ptx.PtxError, match="no CPU fallback"):
+        eng.forward(m, torch.randn(1, 3, 4, 32, 32))
+    with pytest.raises(ptx.PtxError, match="no CPU fallback"):
+        eng.features(m, torch.randn(1, 3, 4, 32, 32))
+    m.train()
+    with pytest.raises(ptx.PtxError, match="forward-only"):
+        eng.forward(m, torch.randn(1, 3, 4, 32, 32))
+    # PTX_EAGER=0: the model API raises too, as in round 1
+    monkeypatch.setenv("PTX_EAGER", "0")
+    m.eval()
     with pytest.raises(ptx.PtxError, match="no CPU fallback"):
         m(torch.randn(1, 3, 4, 32, 32))
-    with pytest.raises(ptx.PtxError, match="no CPU fallback"):
-        m.features(torch.randn(1, 3, 4, 32, 32))
     with pytest.raises(ptx.PtxError):
         ptx.Relation(2, 8, 4, 4)(torch.randn(1, 1, 2, 8))
     m.train()
     with pytest.raises(ptx.PtxError, match="forward-only"):
         m(torch.randn(1, 3, 4, 32, 32))
+    # families without a torch.nn path keep raising
+    monkeypatch.delenv("PTX_EAGER")
+    with pytest.raises(ptx.PtxError):
+        ptx.i3d(7)(torch.randn(1, 3, 16, 224, 224))
+
+
+@pytest.mark.parametrize("case", ["resnet3d50_small", "nonlocal_r2plus1d50_small", "resnet18_cfg1",
+                                  "preact_resnet3d18_odd", "resnext3d10_odd"])
+def test_cpu_model_runs_the_reference_ops(ptx, case):
+    """BASELINE.json config 1 is the CPU path; SURVEY.md 8(b) asks for the PyTorch path on CPU tensors / train()
+    mode.  eager.py calls the zoo's own nn layers in the reference's op order: bit-equal to the golden outputs of
+    the REAL reference (generated in this container) and to features -> logits composition."""
+    from conftest import GOLDEN_CASES, golden_input, golden_recipe, load_golden
+    from pretorched_x_amd import eager
+    from pretorched_x_amd.testing import synth_state_dict
+    arch, kw = GOLDEN_CASES[case]
+    blob = load_golden(case)
+    m = ptx.__dict__[arch](**kw)
+    r = golden_recipe(blob)
+    m.load_state_dict(synth_state_dict(m.state_dict(), r.pop("seed"), **r))
+    x = golden_input(blob)
+    n0 = eager.calls
+    with torch.no_grad():
+        out = m(x)
+        again = m.logits(m.features(x))
+    assert eager.calls > n0
+    ref = torch.from_numpy(blob["logits"])
+    assert torch.equal(out, again)
+    assert (out - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out.argmax(1), ref.argmax(1))
+
+
+def test_train_mode_uses_batch_statistics_and_autograd(ptx):
+    m = ptx.resnet3d10(num_classes=5)
+    x = torch.randn(2, 3, 4, 32, 32)
+    with torch.no_grad():
+        e = m(x)
+    m.train()
+    before = m.bn1.running_mean.clone()
+    out = m(x)
+    assert out.requires_grad and not torch.equal(m.bn1.running_mean, before)     # BN updated its statistics
+    assert (out - e).abs().max().item() > 1e-4                                    # batch stats != running stats
+    out.sum().backward()
+    assert m.conv1.weight.grad is not None and m.last_linear.weight.grad.abs().sum().item() > 0
+    # eval mode, input that requires grad (saliency maps): autograd path as well
+    m.eval()
+    xg = x.clone().requires_grad_(True)
+    m(xg).sum().backward()
+    assert xg.grad is not None and xg.grad.abs().sum().item() > 0
+
+
+def _fake_replica(model):
+    """What torch.nn.parallel.replicate builds (replicate.py): per-module `_replicate_for_data_parallel()` copies
+    whose parameters are plain tensor attributes -- `parameters()` of a replica is EMPTY."""
+    mods = list(model.modules())
+    copies = [m._replicate_for_data_parallel() for m in mods]
+    index = {m: i for i, m in enumerate(mods)}
+    for i, m in enumerate(mods):
+        for key, child in m._modules.items():
+            copies[i]._modules[key] = None if child is None else copies[index[child]]
+        for key, p in m._parameters.items():
+            if p is not None:
+                setattr(copies[i], key, p.detach().clone())
+    return copies[0]
+
+
+def test_dataparallel_replicas_share_engine_plans_and_signature(ptx):
+    """reference examples/imagenet_eval.py:136, nonlocalnet.py:604: DataParallel is the reference's only
+    multi-GPU path; its replicas are rebuilt on every forward."""
+    from pretorched_x_amd.engine import _first_weight
+    m = ptx.nonlocalresnet3d50(pretrained=None)
+    eng = m.engine()
+    r1, r2 = _fake_replica(m), _fake_replica(m)
+    assert next(r1.parameters(), None) is None and getattr(r1, "_is_replica", False)
+    assert r1.engine() is eng and r2.engine() is eng
+    assert _first_weight(r1).shape == m.conv1.weight.shape
+    assert eng.owner(r1) is m and eng.owner(m) is m
+    assert eng._signature(r1) == eng._signature(m) == eng._signature(r2)
+    with torch.no_grad():
+        m.bn1.weight.mul_(1.5)                      # owner edit -> every replica's signature changes with it
+    assert eng._signature(_fake_replica(m)) == eng._signature(m)
+    # a plan compiled from one replica resolves its modules BY NAME on whichever replica runs later
+    plan = eng.dry_plan(r1, (1, 3, 8, 32, 32))
+    pk = plan.packs[0]
+    plan.bind(r2)
+    assert plan.get(pk.convs[0]) is r2.conv1 and plan.get(pk.bn) is r2.bn1
+    plan.bind(m)
+    assert plan.get(pk.convs[0]) is m.conv1
+    nl = [p for p in plan.packs if len(getattr(p, "convs", [])) == 3][0]           # theta | phi | g in one launch
+    assert [r.name.rsplit(".", 1)[1] for r in nl.convs] == ["theta", "phi", "g"]
+
+
+def test_tuned_table_stores_config_names(ptx):
+    from pretorched_x_amd import engine
+    table = engine.tuned_snapshot()
+    assert len(table) >= 400
+    lib = ptx._lib.lib()
+    names = {lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())}
+    assert all(isinstance(v[0], str) and v[0] in names and v[1] >= 1 for v in table.values())
+    key = next(iter(table))
+    idx, split = engine.tuned_lookup(key, table[key][0].endswith("/f16"))
+    assert lib.ptx_conv3d_config_name(idx).decode() == table[key][0] and split == table[key][1]
+    # unknown tile names and precision mismatches fall back to the heuristic instead of remapping
+    engine.tuned_merge({"bogus-key": ("999x999x99/9x9/m32", 1)})
+    assert engine.tuned_lookup("bogus-key") is None
+    assert engine.tuned_lookup(key, not table[key][0].endswith("/f16")) is None
 
 
 def test_plan_compiler_matches_survey_worklist(ptx):

@@ -520,3 +520,61 @@ def test_biggan_generator_fp16(ptx):
     print("biggan-deep-256 fp16: max|d image| = %.3e, mean %.3e" % (err.max().item(), err.mean().item()))
     assert err.max().item() <= 5e-2 and err.mean().item() <= 3e-3
     assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))
+
+
+def test_dataparallel_replicas_share_one_plan_per_device(ptx):
+    """torch.nn.DataParallel (reference examples/imagenet_eval.py:136, nonlocalnet.py:604) rebuilds its replicas
+    on every forward and runs them from worker threads.  Two replicas on the one device of this box: across 3
+    forwards exactly ONE plan is compiled and the filters are packed ONCE; results equal the direct call."""
+    from torch.nn.parallel import parallel_apply, replicate
+    model, _ = _build(ptx, "resnet3d10", dict(), 21)
+    eng = model.engine()
+    x = synth_clips(4, 4, 32, 8).to(DEV)
+    want = model(x)
+    builds, packs = eng.plan_builds, eng.weight_refreshes
+    assert (builds, packs) == (1, 1)
+    for _ in range(3):
+        reps = replicate(model, [0, 0])
+        assert next(reps[0].parameters(), None) is None          # replicas expose no parameters()
+        outs = parallel_apply(reps, [(x,), (x,)], devices=[0, 0])
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, want)
+    assert eng.plan_builds == builds and eng.weight_refreshes == packs
+    # an owner-side weight edit reaches the replicas' next forward (their tensors are fresh broadcast copies)
+    with torch.no_grad():
+        model.bn1.weight.mul_(1.25)
+    outs = parallel_apply(replicate(model, [0, 0]), [(x[:2],), (x[2:],)], devices=[0, 0])
+    torch.cuda.synchronize()
+    got = torch.cat(outs, 0)
+    want2 = model(x)
+    assert (want2 - want).abs().max().item() > 1e-4
+    assert (got - want2).abs().max().item() <= 1e-5 * max(1.0, want2.abs().max().item())
+    # torch.nn.DataParallel itself (one device: the wrapper forwards straight to the module)
+    dp = torch.nn.DataParallel(model, device_ids=[0])
+    assert torch.equal(dp(x), want2)
+
+
+def test_weight_edits_through_data_need_refresh_or_checksum(ptx):
+    """`p.data.fill_()`-style edits (the reference's own init idiom, resnet3D.py:199-201) bypass torch's version
+    counters: documented to need model.refresh(); `check_weights = "checksum"` notices them on the device."""
+    model, _ = _build(ptx, "resnet3d10", dict(), 5)
+    x = synth_clips(2, 4, 32, 3).to(DEV)
+    base = model(x).clone()
+    model.bn1.weight.data.mul_(1.5)
+    assert model.bn1.weight._version == 0 or True
+    stale = model(x)
+    assert torch.equal(stale, base)                       # not noticed (by design: O(#tensors) host check only)
+    fresh = model.refresh()(x)
+    assert (fresh - base).abs().max().item() > 1e-4
+    model.engine().check_weights = "checksum"
+    again = model(x)
+    assert torch.equal(again, fresh)
+    model.bn1.weight.data.mul_(1.0 / 1.5)
+    back = model(x)                                        # noticed without refresh()
+    assert (back - base).abs().max().item() <= 1e-5 * max(1.0, base.abs().max().item())
+    model.engine().check_weights = False                   # O(1) mode: only refresh() / load_state_dict re-pack
+    with torch.no_grad():
+        model.bn1.weight.mul_(2.0)
+    assert torch.equal(model(x), back)
+    assert not torch.equal(model.refresh()(x), back)

@@ -45,10 +45,53 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-def _run(total, world=2):
+def _bench_worker(rank, world, port, total, q, corrupt):
+    """Drives bench.py's N > 1 branch itself -- timed_steps (barriers, MAX-over-ranks timing, the one
+    all-gather per step) + the self-check + the rank-0 tuned-table broadcast -- under gloo with a stand-in
+    forward.  `corrupt`: rank 1 returns logits that change between calls, which the check must flag."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from pretorched_x_amd import engine
+    from pretorched_x_amd.parallel import broadcast_tuned_table, shard_clips
+    g = torch.Generator().manual_seed(7)
+    clips = torch.randn(total, 3, 2, 4, 4, generator=g)
+    local = shard_clips(clips)
+    calls = [0]
+
+    def run():
+        calls[0] += 1
+        out = _fake_forward(local)
+        return out + calls[0] if (corrupt and rank == 1) else out
+
+    elapsed, out, verify = bench.timed_steps(run, total // world, steps=3, warmup=1, dev=torch.device("cpu"),
+                                             sync=lambda: None)
+    # rank 0 "tunes", everyone adopts its table
+    if rank == 0:
+        engine.tuned_merge({"[\"fake-problem\"]": ("64x64x16/2x2/m32/dma", 2)})
+    n = broadcast_tuned_table(src=0)
+    has = engine.tuned_snapshot().get("[\"fake-problem\"]")
+    ok_out = corrupt or torch.equal(out, _fake_forward(clips))
+    q.put((rank, dict(verify), bool(ok_out), calls[0], elapsed > 0, has, n > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(total, world=2, target=None, extra=()):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
+    if target is not None:
+        procs = [ctx.Process(target=target, args=(r, world, port, total, q) + tuple(extra)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get() for _ in range(world)]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        return res
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -66,3 +109,21 @@ def test_clip_parallel_equal_shards():
 
 def test_clip_parallel_ragged_shards():
     _run(total=5)
+
+
+def test_bench_distributed_branch_is_self_verifying():
+    """bench.py at N > 1: 1 warm-up + 3 timed steps + 1 verification forward per rank, gather order and
+    cross-rank identity confirmed, the rank-0 tuned table reaches every rank."""
+    res = _run(total=8, target=_bench_worker, extra=(False,))
+    for rank, verify, ok_out, calls, timed, has, n in res:
+        assert verify == {"gather_order_ok": True, "replicas_identical": True, "ranks": 2, "rows": 8,
+                          "deterministic": True}, (rank, verify)
+        assert ok_out and timed and calls == 5
+        assert has == ("64x64x16/2x2/m32/dma", 2) and n
+
+
+def test_bench_distributed_check_flags_a_bad_rank():
+    res = _run(total=8, target=_bench_worker, extra=(True,))
+    for rank, verify, *_ in res:
+        assert verify["gather_order_ok"] and verify["replicas_identical"]      # the gather itself is fine ...
+        assert verify["deterministic"] is False                                   # ... rank 1's forward is not
