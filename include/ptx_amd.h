@@ -288,6 +288,27 @@ int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float*
 /* --------------------------------------------------------------------------------------------
  * Non-local block pieces (nonlocalnet.py:143-166).
  * ------------------------------------------------------------------------------------------ */
+/* The whole attention core of a non-local block in ONE launch, flash-style (online softmax): the [Nq][Nk]
+ * affinity f = theta^T phi (nonlocalnet.py:156) is never written to memory.
+ *   mode PTX_NL_SOFTMAX: y[b][i][:] = sum_j softmax_j(theta[b][i] . phi[b][j]) g[b][j][:]   (embedded_gaussian :143-166,
+ *                        gaussian :168-190 with theta = phi = x; no 1/sqrt(d) scaling, as upstream)
+ *   mode PTX_NL_SCALE:   y[b][i][:] = sum_j (theta[b][i] . phi[b][j] / Nk) g[b][j][:]        (dot_product :192-211)
+ * theta [batch][Nq][ld_theta] (d channels used), phi [batch][Nk][ld_phi] (d), g [batch][Nk][ld_g] (dv),
+ * y [batch][Nq][ld_y] (dv written); channels-last rows, so the operands may be channel slices of one fused
+ * theta|phi|g projection and Nk != Nq covers `sub_sample` (max-pooled phi / g, :126-131) and BigGAN's pooled keys.
+ * fp32 MFMA throughout; differs from softmax-then-matmul only by fp32 summation order (+ v_exp_f32 rounding).
+ * Limits: d, dv multiples of 4, d <= 512 (ptx_nonlocal_supported); larger d: ptx_bgemm_nt + ptx_softmax_rows. */
+#define PTX_NL_SOFTMAX 0
+#define PTX_NL_SCALE 1
+typedef struct ptx_nonlocal_desc {
+    int32_t batch, Nq, Nk, d, dv;
+    int32_t ld_theta, ld_phi, ld_g, ld_y;        /* row strides (floats)   */
+    int64_t bs_theta, bs_phi, bs_g, bs_y;        /* batch strides (floats) */
+    int32_t mode;
+} ptx_nonlocal_desc;
+int ptx_nonlocal_supported(const ptx_nonlocal_desc* desc);
+int ptx_nonlocal_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
+                     ptx_stream_t stream);
 /* Batched C[b] = op(A[b] x B[b]^T): A [batch][M][lda] (row-major, K contiguous),
  * B [batch][Nn][ldb] (row-major, K contiguous), C [batch][M][ldc]; fp32 MFMA.
  * Used for f = theta^T phi  (nonlocalnet.py:156) and y = softmax(f) g  (:160). */

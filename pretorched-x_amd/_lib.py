@@ -75,6 +75,14 @@ class RelationDesc(C.Structure):
                 ("idx", (C.c_int32 * PTX_REL_MAX_FRAMES) * PTX_REL_MAX_SETS)]
 
 
+class NonlocalDesc(C.Structure):
+    """ptx_nonlocal_desc: fused theta^T phi -> softmax -> . g (reference nonlocalnet.py:143-166)."""
+    _fields_ = [(n, C.c_int32) for n in ("batch", "Nq", "Nk", "d", "dv", "ld_theta", "ld_phi", "ld_g", "ld_y")] + \
+               [(n, C.c_int64) for n in ("bs_theta", "bs_phi", "bs_g", "bs_y")] + [("mode", C.c_int32)]
+
+
+PTX_NL_SOFTMAX, PTX_NL_SCALE = 0, 1
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
@@ -111,6 +119,8 @@ SIGNATURES = {
     "ptx_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _U, _P]),
     "ptx_relation_linear_fwd": (C.c_int, [C.POINTER(RelationDesc), _P, _I, _P, _P, _P, _I, _I, _U, _P]),
     "ptx_linear_setsum_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P]),
+    "ptx_nonlocal_supported": (C.c_int, [C.POINTER(NonlocalDesc)]),
+    "ptx_nonlocal_fwd": (C.c_int, [C.POINTER(NonlocalDesc), _P, _P, _P, _P, _P]),
     "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),
     "ptx_softmax_rows": (C.c_int, [_P, _L, _I, _I, _I, _P]),
     "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

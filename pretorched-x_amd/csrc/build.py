@@ -13,11 +13,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["conv_igemm.hip", "pack_layout.hip", "pool_head.hip"]
+SOURCES = ["conv_igemm.hip", "pack_layout.hip", "pool_head.hip", "nonlocal_attn.hip"]
 HEADERS = ["ptx_common.h", os.path.join("..", "..", "include", "ptx_amd.h")]
 LIB = os.path.join(PKG, "libptx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per-source extras.  nonlocal_attn: the online-softmax rescale multiplies the MFMA accumulators between tiles; with
+# the default AGPR accumulators hipcc copies all of them to VGPRs and back EVERY tile (128 v_accvgpr moves per 128
+# MFMAs).  gfx950's register file is unified, so keep the accumulators in VGPRs (0 moves, same occupancy).
+EXTRA_FLAGS = {"nonlocal_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):
@@ -32,7 +36,7 @@ def _compile(src, report):
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not _stale(obj, deps):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
           ["-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -1,0 +1,288 @@
+// Fused non-local (space-time self-attention) block core on the gfx950 fp32 matrix cores:
+//     y = softmax(theta . phi^T) . g          (embedded_gaussian / gaussian, nonlocalnet.py:143-190)
+//     y = (theta . phi^T / Nk) . g            (dot_product, nonlocalnet.py:192-211)
+// in ONE launch, flash-style: the [Nq, Nk] affinity `f` (78.7 MB per block at N = 1568, 315 MB at the
+// reference's usual N = 3136) never exists in HBM -- per 16-key tile it lives in 4 accumulator registers.
+//
+// Decomposition.  A wave owns 16 query rows for the whole kernel: their theta rows sit in registers
+// (D/4 VGPRs, loaded once), their output accumulator O[16][DV] sits in DV/4 accumulator registers.  The 4
+// waves of a workgroup (64 queries) share the key / value tiles -- 16 keys per step -- which arrive by LDS-DMA
+// (buffer_load ... lds, one 1-KiB piece per wave-instruction, double buffered, one barrier per tile).
+//
+// Per tile, per wave, on v_mfma_f32_16x16x4_f32 (exact fp32):
+//   S^T = phi_tile . theta^T   A = phi rows (keys) from LDS (ds_read_b128: 4 consecutive d per lane, the same
+//                              hardware-k permutation on both operands), B = theta from registers.  Computing
+//                              the TRANSPOSED tile puts one query per lane column (query = lane & 15, keys =
+//                              4 * (lane >> 4) + r): the row maximum / sum of the online softmax is 3 in-lane
+//                              ops + 2 cross-lane steps, and ...
+//   O  += P . g_tile           ... P is already laid out as the A operand of the second MFMA (A[row = lane % 16]
+//                              [k = lane / 16] is one float per lane): MFMA r contracts keys {r, 4+r, 8+r, 12+r},
+//                              its B operand is g[4 * (lane >> 4) + r][channels] read straight from the LDS tile
+//                              (ds_read_b128 = the operands of 4 MFMAs, conflict-free without a swizzle).
+// No shuffle, no LDS round trip between the two matmuls.  Online softmax (running max m, running sum l, O
+// rescaled by exp(m_old - m_new) only when some query's maximum moved).
+#include "ptx_common.h"
+#include <cfloat>
+
+namespace ptx {
+
+struct NlArgs {
+    const float* theta;
+    const float* phi;
+    const float* g;
+    float* y;
+    int batch, Nq, Nk, d, dv;
+    int ld_t, ld_p, ld_g, ld_y;
+    long long bs_t, bs_p, bs_g, bs_y;
+    int q_tiles, scale_only;
+    unsigned p_bytes, g_bytes, t_bytes;
+};
+
+// (inline asm with AMDGPU register constraints must live in a __device__ function: inside the __global__
+// template body the host pass silently drops the whole kernel stub)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// one 1-KiB LDS-DMA piece: 16 bytes per lane from `voffset` of the buffer to lds_base + 16 * lane
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, float* lds_base, unsigned voffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_base, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ void tile_barrier(int& a, int& b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("; ds_reads of this tile depend on these" : "+v"(a), "+v"(b)::"memory");
+}
+
+template <int D, int DV, bool SOFTMAX>
+__global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
+    constexpr int TK = 16;                   // keys per tile
+    constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
+    constexpr int CB = DV / 64;              // 64-channel output super-blocks (one ds_read_b128 + 4 MFMAs per key group)
+    constexpr int F4R = D / 4;               // 16-byte slots per key row
+    constexpr int NKP = TK * D / 256;        // 1-KiB DMA pieces of a key tile
+    constexpr int NVP = TK * DV / 256;
+    static_assert(D % 16 == 0 && DV % 64 == 0, "tile extents");
+    constexpr unsigned kOOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                        // [2][TK][D]   (16-byte slots XOR-swizzled by row)
+    float* Vs = smem + 2 * TK * D;           // [2][TK][DV]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, p.q_tiles * p.batch);     // one clip's tiles share an XCD's L2
+    const int b = tile / p.q_tiles, qt = tile - b * p.q_tiles;
+    const int c0 = blockIdx.y * DV;          // output-channel chunk of this workgroup
+    const int n = lane & 15, gq = lane >> 4;
+    const int q = qt * 64 + wave * 16 + n;   // this lane's query (as MFMA column / A row)
+
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.theta + (size_t)b * p.bs_t), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.phi + (size_t)b * p.bs_p), 0, p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.g + (size_t)b * p.bs_g), 0, p.g_bytes, 0x00020000);
+
+    // ---- theta rows of this wave's 16 queries -> registers (the B operand of S^T = phi . theta^T) ----
+    f32x4 qf[QJ];
+#pragma unroll
+    for (int j = 0; j < QJ; ++j) {
+        const int col = 16 * j + 4 * gq;
+        const unsigned off = ((unsigned)q * (unsigned)p.ld_t + (unsigned)col) * 4u;
+        qf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
+    }
+
+    // ---- per-lane DMA source offsets (tile independent) ----
+    auto swz = [&](int row, int slot) -> int {
+        return F4R >= 16 ? (slot ^ (row & 15)) : F4R == 8 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
+    };
+    constexpr int KPW = (NKP + 3) / 4, VPW = (NVP + 3) / 4;       // pieces per wave
+    unsigned koff[KPW], voff[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int f = (wave + 4 * i) * 256 + lane * 4;            // float index in the linear [TK][D] image
+        const int row = f / D, slot = (f % D) / 4;
+        const int col = swz(row, slot) * 4;                       // logical column this physical slot holds
+        koff[i] = col < p.d ? ((unsigned)row * (unsigned)p.ld_p + (unsigned)col) * 4u : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int f = (wave + 4 * i) * 256 + lane * 4;
+        const int row = f / DV, col = c0 + f % DV;
+        voff[i] = col < p.dv ? ((unsigned)row * (unsigned)p.ld_g + (unsigned)col) * 4u : kOOB;
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const unsigned kbase = (unsigned)t * TK * (unsigned)p.ld_p * 4u, vbase = (unsigned)t * TK * (unsigned)p.ld_g * 4u;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+            if (wave + 4 * i < NKP)
+                dma16(rs_p, Ks + buf * TK * D + (wave + 4 * i) * 256, koff[i] == kOOB ? kOOB : koff[i] + kbase);
+#pragma unroll
+        for (int i = 0; i < VPW; ++i)
+            if (wave + 4 * i < NVP)
+                dma16(rs_g, Vs + buf * TK * DV + (wave + 4 * i) * 256, voff[i] == kOOB ? kOOB : voff[i] + vbase);
+    };
+
+    f32x4 O[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) O[cb][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float inv_nk = 1.0f / (float)p.Nk;
+
+    const int n_tiles = (p.Nk + TK - 1) / TK;
+    issue_tile(0, 0);
+    // fragment read offsets (floats): phi row = n, slot (4j + gq) ^ swizzle;  g row = 4*gq + r, slot cb*16 + n
+    const int k_row_off = n * D;
+    const int v_row_off = (4 * gq) * DV + n * 4;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        // tile t landed: every wave waits for its own DMA pieces, then the barrier; buffer buf^1 is free (its last
+        // readers passed this barrier too).  The fragment offsets go through an asm the compiler cannot move
+        // above the barrier, so no ds_read of the new tile is scheduled early (cdna_hip_programming.md 5.7).
+        int ko = k_row_off, vo = v_row_off;
+        tile_barrier(ko, vo);
+        if (t + 1 < n_tiles) issue_tile(t + 1, buf ^ 1);
+        const float* Kb = Ks + buf * TK * D + ko;
+        const float* Vb = Vs + buf * TK * DV + vo;
+
+        // ---- S^T tile: two accumulators break the 40-cycle dependent-MFMA chain ----
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + swz(n, 4 * j + gq) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (j & 1) s1 = mfma16(kf[e], qf[j][e], s1);
+                else       s0 = mfma16(kf[e], qf[j][e], s0);
+            }
+        }
+        f32x4 s = s0 + s1;                    // s[r] = S[q = n][key = 16t + 4*gq + r]
+
+        float pr[4];
+        if constexpr (SOFTMAX) {
+            const int key0 = t * TK + 4 * gq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = (key0 + r < p.Nk) ? s[r] : -INFINITY;
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const bool moved = m_new > m_run;
+            const float alpha = __expf(m_run - m_new);         // exp(-inf) = 0 on the first tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = __expf(s[r] - m_new);
+            l_run = l_run * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+            m_run = m_new;
+            if (__any(moved)) {               // O rows are queries 4*gq + r: fetch their alpha from lane (4*gq + r)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = __shfl(alpha, 4 * gq + r, 64);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) O[cb][e][r] *= a;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = s[r] * inv_nk;   // keys >= Nk read as zero rows: no mask needed
+        }
+
+        // ---- O += P . g_tile ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vb + r * DV + cb * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[cb][e] = mfma16(pr[r], vf[e], O[cb][e]);
+            }
+        }
+    }
+
+    // ---- epilogue: 1 / l per query, 16-byte stores (lane: query 4*gq + r, channels cb*64 + 4*n .. +3) ----
+    float inv = 1.f;
+    if constexpr (SOFTMAX) {
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        inv = 1.0f / l_run;
+    }
+    float* yb = p.y + (size_t)b * p.bs_y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float iv = SOFTMAX ? __shfl(inv, 4 * gq + r, 64) : 1.f;
+        const int qo = qt * 64 + wave * 16 + 4 * gq + r;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int ch = c0 + cb * 64 + 4 * n;
+            if (qo < p.Nq && ch < p.dv) {
+                const f32x4 o = {O[cb][0][r] * iv, O[cb][1][r] * iv, O[cb][2][r] * iv, O[cb][3][r] * iv};
+                *reinterpret_cast<f32x4*>(yb + (size_t)qo * p.ld_y + ch) = o;
+            }
+        }
+    }
+}
+
+template <int D, int DV, bool SOFTMAX>
+static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 16 * (D + DV) * sizeof(float);
+    const dim3 grid((unsigned)(a.q_tiles * a.batch), (unsigned)cdiv(a.dv, DV));
+    static bool attr_set[64] = {};   // per device; benign race (idempotent call)
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX>), grid, dim3(256), lds, st, a);
+    return hip_check(hipGetLastError(), "nonlocal attention launch");
+}
+
+template <int D, int DV>
+static int launch_nl(const NlArgs& a, hipStream_t st) {
+    return a.scale_only ? launch_nl_mode<D, DV, false>(a, st) : launch_nl_mode<D, DV, true>(a, st);
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_nonlocal_supported(const ptx_nonlocal_desc* d) {
+    if (!d) return 0;
+    return d->batch > 0 && d->Nq > 0 && d->Nk > 0 && d->d > 0 && d->dv > 0 && d->d % 4 == 0 && d->dv % 4 == 0 && d->d <= 512 &&
+           d->batch * (int64_t)((d->Nq + 63) / 64) <= 0x7fffffffLL;
+}
+
+extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, const float* phi, const float* g, float* y,
+                                ptx_stream_t stream) {
+    if (!d || !theta || !phi || !g || !y) return fail(PTX_ERR_INVALID, "nonlocal: null pointer");
+    if (!ptx_nonlocal_supported(d))
+        return fail(PTX_ERR_UNSUPPORTED, "nonlocal: need d, dv multiples of 4 and d <= 512 (d=%d dv=%d); use the "
+                    "ptx_bgemm_nt / ptx_softmax_rows path", d->d, d->dv);
+    if (d->ld_theta < d->d || d->ld_phi < d->d || d->ld_g < d->dv || d->ld_y < d->dv || d->ld_theta % 4 || d->ld_phi % 4 ||
+        d->ld_g % 4 || d->ld_y % 4 || d->bs_theta % 4 || d->bs_phi % 4 || d->bs_g % 4 || d->bs_y % 4)
+        return fail(PTX_ERR_INVALID, "nonlocal: row / batch strides must be multiples of 4 floats and cover the extents");
+    if (((uintptr_t)theta | (uintptr_t)phi | (uintptr_t)g | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "nonlocal: misaligned pointer");
+    if (d->mode != PTX_NL_SOFTMAX && d->mode != PTX_NL_SCALE) return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
+    const uint64_t tb = (uint64_t)d->Nq * d->ld_theta * 4ull, pb = (uint64_t)d->Nk * d->ld_phi * 4ull, gb = (uint64_t)d->Nk * d->ld_g * 4ull;
+    if (tb >= 0x80000000ull || pb >= 0x80000000ull || gb >= 0x80000000ull)
+        return fail(PTX_ERR_UNSUPPORTED, "nonlocal: one batch item of theta / phi / g must be < 2 GiB");
+    NlArgs a{};
+    a.theta = theta; a.phi = phi; a.g = g; a.y = y;
+    a.batch = d->batch; a.Nq = d->Nq; a.Nk = d->Nk; a.d = d->d; a.dv = d->dv;
+    a.ld_t = d->ld_theta; a.ld_p = d->ld_phi; a.ld_g = d->ld_g; a.ld_y = d->ld_y;
+    a.bs_t = d->bs_theta; a.bs_p = d->bs_phi; a.bs_g = d->bs_g; a.bs_y = d->bs_y;
+    a.q_tiles = cdiv(d->Nq, 64);
+    a.scale_only = d->mode == PTX_NL_SCALE;
+    a.t_bytes = (unsigned)tb; a.p_bytes = (unsigned)pb; a.g_bytes = (unsigned)gb;
+    hipStream_t st = (hipStream_t)stream;
+    // smallest compiled (D, DV) covering the problem; dv > DV is split over blockIdx.y (S recomputed per chunk)
+    if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl<32, 128>(a, st);
+    if (d->d <= 64) return d->dv <= 64 ? launch_nl<64, 64>(a, st) : launch_nl<64, 256>(a, st);
+    if (d->d <= 256) return d->dv <= 128 ? launch_nl<256, 128>(a, st) : launch_nl<256, 256>(a, st);
+    return launch_nl<512, 256>(a, st);
+}

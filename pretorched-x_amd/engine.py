@@ -549,6 +549,28 @@ class Plan:
         self.steps.append(step)
         return y
 
+    def attention(self, th, ph, g, y, scale_only=False):
+        """y = softmax(th . ph^T) . g  (or (th . ph^T / Nk) . g) per sample, as one ptx_nonlocal_fwd launch.
+        th [N, Sq, d], ph [N, Sk, d], g [N, Sk, dv], y [N, Sq, dv]: channels-last activations (possibly channel
+        slices).  Returns False -- nothing emitted -- when the fused kernel does not cover the shape (d > 512)
+        or PTX_NL_FUSED=0 asks for the unfused bgemm / softmax / bgemm chain."""
+        from ._lib import NonlocalDesc, PTX_NL_SCALE, PTX_NL_SOFTMAX
+        d = NonlocalDesc()
+        d.batch, d.Nq, d.Nk, d.d, d.dv = th.N, th.S, ph.S, th.C, g.C
+        d.ld_theta, d.ld_phi, d.ld_g, d.ld_y = th.ld, ph.ld, g.ld, y.ld
+        d.bs_theta, d.bs_phi, d.bs_g, d.bs_y = th.S * th.ld, ph.S * ph.ld, g.S * g.ld, y.S * y.ld
+        d.mode = PTX_NL_SCALE if scale_only else PTX_NL_SOFTMAX
+        if os.environ.get("PTX_NL_FUSED", "1") == "0" or not self.lib.ptx_nonlocal_supported(C.byref(d)):
+            return False
+        lib, tp, pp, gp, yp = self.lib, _ptr(th.t), _ptr(ph.t), _ptr(g.t), _ptr(y.t)
+        self.keepalive.append(d)
+
+        def step(st):
+            check(lib.ptx_nonlocal_fwd(C.byref(d), tp, pp, gp, yp, st), "ptx_nonlocal_fwd")
+        self.steps.append(step)
+        self.attn_steps = getattr(self, "attn_steps", 0) + 1
+        return True
+
     def nonlocal_block(self, x, nl, label):
         """Non-local block (nonlocalnet.py:139-243): pointwise projections in one launch, f = theta^T phi on
         MFMA, row softmax (or 1/N scaling), y = f g on MFMA, W projection (+BN) + residual in one launch.
@@ -577,10 +599,15 @@ class Plan:
             ph_act = self.maxpool(ph_act, *pool)
             g_act = self.maxpool(g_act, *pool)
         N, Sq, Sk, K = x.N, x.S, ph_act.S, th_act.C
+        yatt = self.act(x.N, x.T, x.H, x.W, ci)
+        if mode != "concatenation" and self.attention(th_act, ph_act, g_act, yatt, scale_only=(mode == "dot_product")):
+            # theta^T phi -> softmax (or 1/N) -> . g in ONE launch: the [N, Sq, Sk] affinity never reaches HBM
+            if getattr(nl, "bn_layer", True):
+                return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
+            return self.conv(yatt, self.pack(nl.W, None), one, zero, res=x, label=label + ".W")
         ldf = _r4(Sk)
         f = torch.empty((N, Sq, ldf), device=self.dev, dtype=torch.float32)
         gT = torch.empty((N, ci, ldf), device=self.dev, dtype=torch.float32)
-        yatt = self.act(x.N, x.T, x.H, x.W, ci)
         self.keepalive += [f, gT]
         th, ph, gp = _ptr(th_act.t), _ptr(ph_act.t), _ptr(g_act.t)
         lda, ldb, ldg = th_act.ld, ph_act.ld, g_act.ld

@@ -290,10 +290,12 @@ def biggan_attention(self, x, att, name):
     phi = self.maxpool(tpg.slice(c8, c8), (1, 2, 2), (1, 2, 2), (0, 0, 0))
     g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
     S4 = HW // 4
+    yatt = self.act(N, 1, x.H, x.W, c2)
+    if self.attention(tpg.slice(0, c8), phi, g, yatt):
+        return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma")), one, zero, res=x, label=name + ".o")
     ldf = _r4(S4)
     f = torch.empty((N, HW, ldf), device=self.dev, dtype=torch.float32)
     gT = torch.empty((N, c2, ldf), device=self.dev, dtype=torch.float32)
-    yatt = self.act(N, 1, x.H, x.W, c2)
     self.keepalive += [f, gT]
     th, ph, gp, fp, gtp, yp = _ptr(tpg.t), _ptr(phi.t), _ptr(g.t), _ptr(f), _ptr(gT), _ptr(yatt.t)
     ld3, ldp, ldg, yld = tpg.ld, phi.ld, g.ld, yatt.ld

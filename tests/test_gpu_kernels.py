@@ -855,3 +855,51 @@ def test_conv_f16_operands(ptx):
             close(from_cl(yd, Co), want, tol=1e-4)
         assert lib.ptx_conv3d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
                                   _p(rd) if rd is not None else None, _p(yd), None, 0, 28, 1, _st()) == 2      # fp32 tile
+
+
+@pytest.mark.parametrize("case", [
+    # B, Nq, Nk, d, dv, mode, description
+    (2, 100, 100, 16, 16, "softmax", "tiny channels on the <64,64> tile, ragged query / key tails"),
+    (2, 196, 196, 512, 512, "softmax", "layer3 of config 3: d = 512, dv = 512 split over blockIdx.y"),
+    (1, 300, 300, 256, 256, "softmax", "layer2 width (config 3: N = 1568)"),
+    (2, 256, 64, 32, 128, "softmax", "BigGAN attention: pooled keys, d = ch/8, dv = ch/2"),
+    (3, 130, 17, 64, 192, "softmax", "sub_sample-style Nk != Nq, dv not a multiple of 64"),
+    (2, 90, 90, 40, 24, "scale", "dot_product mode (f / N, no softmax)"),
+    (1, 64, 1568, 256, 256, "softmax", "many key tiles: online-softmax rescaling"),
+])
+def test_fused_nonlocal_attention(ptx, case):
+    """ptx_nonlocal_fwd against the reference's op sequence (nonlocalnet.py:143-166 / :192-211): matmul ->
+    softmax (or / N) -> matmul in torch fp32 on the CPU.  Operands are channel SLICES of one fused projection
+    tensor (row stride > d), as the engine passes them.  Tolerance: fp32 summation order + v_exp_f32."""
+    L, lib = ptx._lib, _lib(ptx)
+    B, Nq, Nk, d, dv, mode, _ = case
+    g_ = torch.Generator().manual_seed(1000 + Nq + d)
+    ld = _r4(2 * d + dv) + 4
+    tpg_q = torch.randn(B, Nq, ld, generator=g_)
+    tpg_k = torch.randn(B, Nk, ld, generator=g_)
+    scale = 3.0 / d ** 0.5                   # logits of a few units: a peaky but non-degenerate softmax
+    theta, phi, gv = tpg_q[..., :d] * scale, tpg_k[..., d:2 * d].clone(), tpg_k[..., 2 * d:2 * d + dv].clone()
+    tpg_q[..., :d] = theta
+    f = torch.matmul(theta, phi.transpose(1, 2))
+    f = F.softmax(f, dim=-1) if mode == "softmax" else f / f.size(-1)
+    want = torch.matmul(f, gv)
+    tq, tk = tpg_q.to(DEV), tpg_k.to(DEV)
+    ldy = _r4(dv) + 8
+    y = torch.full((B, Nq, ldy), float("nan"), device=DEV)
+    desc = L.NonlocalDesc()
+    desc.batch, desc.Nq, desc.Nk, desc.d, desc.dv = B, Nq, Nk, d, dv
+    desc.ld_theta = desc.ld_phi = desc.ld_g = ld
+    desc.ld_y = ldy
+    desc.bs_theta, desc.bs_phi, desc.bs_g, desc.bs_y = Nq * ld, Nk * ld, Nk * ld, Nq * ldy
+    desc.mode = L.PTX_NL_SOFTMAX if mode == "softmax" else L.PTX_NL_SCALE
+    assert lib.ptx_nonlocal_supported(C.byref(desc))
+    L.check(lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()), "nonlocal")
+    torch.cuda.synchronize()
+    got = y.cpu()
+    assert torch.isnan(got[..., dv:]).all()                 # columns beyond dv are left untouched
+    err = (got[..., :dv] - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, err)
+    # unsupported widths are refused, not mis-computed
+    desc.d = 1024
+    assert not lib.ptx_nonlocal_supported(C.byref(desc))
+    assert lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()) != 0
