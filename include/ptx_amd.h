@@ -52,6 +52,19 @@ typedef void* ptx_stream_t; /* hipStream_t */
                                 ".../f16" tile configurations (BigGAN generator, BASELINE config 5)            */
 #define PTX_ACT_OUT_F16 0x100 /* ptx_affine_act_upsample: OR into `act` -- y is written as halfs (ldy in halfs,
                                 multiple of 8): the cBN -> ReLU -> upsample pass feeds an fp16-operand conv      */
+/* Fused generator stage (BigGAN-deep GBlock: cBN -> ReLU -> [nearest x2] -> conv, BASELINE config 5), on the
+ * fp16-operand tiles through ptx_conv3d_fused_fwd.  The class-conditional BN that FOLLOWS a conv is applied in that
+ * conv's epilogue as a per-sample affine (tables from ptx_cbn_fold), the upsampling that precedes a conv is done by
+ * its loader, so no cBN / ReLU / upsample pass touches HBM and activations stay halfs between the convs. */
+#define PTX_EPI_OUT_F16 0x200u  /* y is written as halfs (ldy counts halfs, multiple of 8; Co even)                 */
+#define PTX_EPI_AFFINE 0x400u   /* v = v * scale[n][co] + shift[n][co] after bias (+ skip), before ReLU / tanh;
+                                   n = sample of the output row; tables in ptx_conv_fused_ext                      */
+#define PTX_EPI_DUAL_RAW 0x800u /* additionally store the pre-affine value as halfs to ext->y_raw (the next block's
+                                   skip operand)                                                                   */
+#define PTX_RES_F16 0x1000u     /* the residual / skip operand `res` holds halfs (ldr counts halfs)               */
+#define PTX_PRO_UP2 0x2000u     /* the input is read through a nearest 2x upsample in H and W: desc.Hi / Wi are the
+                                   UPSAMPLED extents the filter slides over, x stores [N][1][Hi/2][Wi/2][ldx]      */
+#define PTX_EPI_TANH 0x4000u    /* tanh on the output (the generator's image conv)                                 */
 #define PTX_PRO_RELU 8u      /* ptx_linear_fwd only: ReLU on the input while loading (trn.py:39-45) */
 #define PTX_EPI_ACCUM 16u    /* ptx_linear_fwd only: y += result (trn.py:110 stack(...).sum(0))   */
 
@@ -120,6 +133,21 @@ int ptx_conv3d_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_p
 int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* desc, const float* x, const float* x2,
                         const float* w_packed, const float* bias, float* y, void* workspace,
                         size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
+
+/* Operands of the fused generator-stage epilogue (see PTX_EPI_AFFINE / PTX_EPI_DUAL_RAW). */
+typedef struct ptx_conv_fused_ext {
+    const float* scale;   /* [N][ld_affine] per-sample, per-output-channel scale (ptx_cbn_fold)  */
+    const float* shift;   /* [N][ld_affine]                                                      */
+    int32_t ld_affine;
+    int32_t ld_raw;       /* row stride of y_raw in halfs                                        */
+    void* y_raw;          /* [M][ld_raw] halfs: the pre-affine output                            */
+} ptx_conv_fused_ext;
+/* ptx_conv3d_fwd for fp16-operand descriptors (PTX_F16_OPERANDS) with the fused-stage flags: x / w_packed hold
+ * halfs, res halfs (PTX_RES_F16) or fp32, y halfs (PTX_EPI_OUT_F16) or fp32.  ext may be NULL when neither
+ * PTX_EPI_AFFINE nor PTX_EPI_DUAL_RAW is set. */
+int ptx_conv3d_fused_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias,
+                         const void* res, void* y, const ptx_conv_fused_ext* ext, void* workspace,
+                         size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Weight packing: fold eval-mode BatchNorm (+ conv bias) into the filter and re-lay it out

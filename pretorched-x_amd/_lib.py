@@ -20,6 +20,7 @@ PTX_EPI_ACCUM = 16
 PTX_EPI_RES_UP = 64
 PTX_F16_OPERANDS = 128
 PTX_ACT_OUT_F16 = 0x100
+PTX_EPI_OUT_F16, PTX_EPI_AFFINE, PTX_EPI_DUAL_RAW, PTX_RES_F16, PTX_PRO_UP2, PTX_EPI_TANH = 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000
 
 
 class PtxError(RuntimeError):
@@ -37,6 +38,12 @@ class ConvDesc(C.Structure):
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class ConvFusedExt(C.Structure):
+    """ptx_conv_fused_ext: operands of the fused generator-stage epilogue."""
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("ld_affine", C.c_int32), ("ld_raw", C.c_int32),
+                ("y_raw", C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -99,6 +106,8 @@ SIGNATURES = {
     "ptx_conv3d_pick_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
     "ptx_conv3d_workspace_bytes": (_Z, [C.POINTER(ConvDesc), C.c_int]),
     "ptx_conv3d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
+    "ptx_conv3d_fused_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(ConvFusedExt), _P, _Z, C.c_int,
+                                       C.c_int, _P]),
     "ptx_conv3d_dual_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
     "ptx_packed_weight_elems": (_Z, [C.POINTER(PackDesc)]),
     "ptx_pack_conv_weight": (C.c_int, [C.POINTER(PackDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),

@@ -62,7 +62,19 @@ struct ConvArgs {
     int groups, cig, cog;  // grouped conv: input / output channels per group
     int f16;               // A / B operands are halfs; K extents count 32-bit words
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
+    // fused generator stage (ptx_conv3d_fused_fwd, fp16-operand tiles): a per-sample affine after bias (+ skip) -- the
+    // NEXT layer's class-conditional BN folded to scale/shift tables -- halfs out, a second pre-affine output, a
+    // half-precision skip operand, and an input read through a nearest 2x upsample in H and W
+    const float* aff_scale;
+    const float* aff_shift;
+    int ld_aff, pps;       // table row stride; output positions per sample (sample of row m = m / pps)
+    void* y_raw;           // second output: the pre-affine value, halfs, row stride ld_raw
+    int ld_raw;
+    unsigned raw_bytes;
+    int up2, Hp, Wp;       // up2: (Hi, Wi) are the UPSAMPLED extents the filter slides over, (Hp, Wp) the stored ones
 };
+
+constexpr unsigned kFusedEpiFlags = PTX_EPI_OUT_F16 | PTX_EPI_AFFINE | PTX_EPI_DUAL_RAW | PTX_RES_F16 | PTX_EPI_TANH;
 
 // Step barrier.  hipcc may schedule LDS reads of the NEXT buffer above a plain __syncthreads() when it
 // sees no aliasing store in this thread (observed on the LDS-DMA variant, whose only LDS writers are
@@ -127,6 +139,126 @@ __device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m
     }
     if (p.flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
     return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused generator-stage epilogue (fp16-operand tiles, ptx_conv3d_fused_fwd).  For one accumulator element:
+//     v    = acc + bias[co] (+ skip)                  skip: same-shape add, or the nearest-upsampled, channel-truncated
+//                                                     GBlock skip up(x[:, :Co]); fp32 or halfs (PTX_RES_F16)
+//     raw  = v                                        -> y_raw as halfs (PTX_EPI_DUAL_RAW: the next block's skip operand)
+//     v    = v * scale[n][co] + shift[n][co]          (PTX_EPI_AFFINE: the NEXT layer's class-conditional BN, folded)
+//     v    = relu(v) | tanh(v)
+//     y    = v as halfs (PTX_EPI_OUT_F16) or fp32
+// so the cBN -> ReLU (-> upsample) passes between a generator block's convs never touch HBM: the producer applies
+// the consumer's normalisation, and the consumer's loader does the upsampling (PTX_PRO_UP2).
+// Half outputs are stored two columns per lane: neighbouring lanes hold neighbouring columns of the accumulator
+// tile, so an xor-1 lane exchange turns two 2-byte stores into one 4-byte store.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fused_skip(const ConvArgs& p, int m, int co) {
+    const bool r16 = (p.flags & PTX_RES_F16) != 0;
+    size_t idx;
+    if (p.flags & PTX_EPI_RES_ADD) {
+        idx = (size_t)m * p.ldr + co;
+    } else {
+        if (co >= ((p.flags & PTX_EPI_RES_UP) ? p.Co : p.res_C)) return 0.f;
+        const int wo = m % p.Wo;
+        int t = m / p.Wo;
+        const int ho = t % p.Ho;
+        t /= p.Ho;
+        const int to = t % p.To;
+        const int n = t / p.To;
+        const bool up = (p.flags & PTX_EPI_RES_UP) != 0;
+        const int rt = up ? to >> p.res_sT : to * p.res_sT, rh = up ? ho >> p.res_sH : ho * p.res_sH,
+                  rw = up ? wo >> p.res_sW : wo * p.res_sW;
+        idx = ((((size_t)n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw) * p.ldr + co;
+    }
+    return r16 ? (float)reinterpret_cast<const _Float16*>(p.res)[idx] : p.res[idx];
+}
+
+// bias + skip -> raw; affine + activation -> out   (shared with the split-K reduce kernel)
+__device__ __forceinline__ void fused_value(const ConvArgs& p, float acc, int m, int co, float bias, float sc, float sh,
+                                            float& raw, float& out) {
+    float v = acc + bias;
+    if (p.flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) v += fused_skip(p, m, co);
+    raw = v;
+    if (p.flags & PTX_EPI_AFFINE) v = fmaf(v, sc, sh);
+    if (p.flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
+    if (p.flags & PTX_EPI_TANH) v = tanhf(v);
+    out = v;
+}
+
+template <class MF, int NACC, int MT>
+__device__ __forceinline__ void store_half_pairs(const __amdgpu_buffer_rsrc_t rs, const float (&v)[NACC], int mrow, int co,
+                                                 int lane, unsigned ld_halfs, int M, int ncol) {
+    const bool odd = (lane & 1) != 0;
+    const int cbase = co - (odd ? 1 : 0);
+#pragma unroll
+    for (int r = 0; r < NACC; r += 2) {
+        const float send = odd ? v[r] : v[r + 1];
+        const float recv = __shfl_xor(send, 1, 64);
+        const half2_t pk = {(_Float16)(odd ? recv : v[r]), (_Float16)(odd ? v[r + 1] : recv)};
+        const int m = mrow + MF::row(odd ? r + 1 : r, lane);
+        const unsigned off = ((unsigned)m * ld_halfs + (unsigned)cbase) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs,
+                                              (cbase < ncol && m < M) ? off : 0x80000000u, 0, 0);
+    }
+}
+
+template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+__device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename MF::acc_t (&acc)[TM][TN], int m0, int n0,
+                                                     int wm, int wn, int lane) {
+    constexpr int NACC = MF::NACC;
+    constexpr unsigned kOOB = 0x80000000u;
+    const bool out16 = (p.flags & PTX_EPI_OUT_F16) != 0, dual = (p.flags & PTX_EPI_DUAL_RAW) != 0;
+    const bool affine = (p.flags & PTX_EPI_AFFINE) != 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_raw =
+        __builtin_amdgcn_make_buffer_rsrc(dual ? p.y_raw : (void*)p.y, 0, dual ? p.raw_bytes : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * WTN + j * MT + (lane % MT);
+        const bool co_ok = co < p.ncol;
+        const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m0 + wm * WTM + i * MT;
+            // the tile's rows usually belong to ONE sample: its scale / shift are then one load per column
+            const int n_lo = mrow / p.pps, n_hi = min(mrow + MT - 1, p.M - 1) / p.pps;
+            const bool one = n_lo == n_hi;
+            float sc = 1.f, sh = 0.f;
+            if (affine && one && co_ok && mrow < p.M) {
+                sc = p.aff_scale[(size_t)n_lo * p.ld_aff + co];
+                sh = p.aff_shift[(size_t)n_lo * p.ld_aff + co];
+            }
+            float raw[NACC], out[NACC];
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                const int m = mrow + MF::row(r, lane);
+                const bool ok = co_ok && m < p.M;
+                float s1 = sc, s0 = sh;
+                if (affine && !one && ok) {
+                    const int n = m / p.pps;
+                    s1 = p.aff_scale[(size_t)n * p.ld_aff + co];
+                    s0 = p.aff_shift[(size_t)n * p.ld_aff + co];
+                }
+                fused_value(p, acc[i][j][r], ok ? m : 0, ok ? co : 0, bv, s1, s0, raw[r], out[r]);
+            }
+            if (out16) {
+                store_half_pairs<MF, NACC, MT>(rs_y, out, mrow, co, lane, (unsigned)p.ldy, p.M, p.ncol);
+            } else {
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    const int m = mrow + MF::row(r, lane);
+                    const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, out[r]), rs_y,
+                                                          (co_ok && m < p.M) ? off : kOOB, 0, 0);
+                }
+            }
+            if (dual) store_half_pairs<MF, NACC, MT>(rs_raw, raw, mrow, co, lane, (unsigned)p.ld_raw, p.M, p.ncol);
+        }
+    }
 }
 
 // F16: the A / B operands are IEEE halfs.  Everything that MOVES data (buffer loads, LDS-DMA, swizzle, tap
@@ -227,7 +359,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         for (int k = 0; k < p.kT; ++k) mask |= ((unsigned)(tc - p.pT + k) < (unsigned)p.Ti ? 1u : 0u) << k;
         for (int k = 0; k < p.kH; ++k) mask |= ((unsigned)(hc - p.pH + k) < (unsigned)p.Hi ? 1u : 0u) << (8 + k);
         for (int k = 0; k < p.kW; ++k) mask |= ((unsigned)(wc - p.pW + k) < (unsigned)p.Wi ? 1u : 0u) << (16 + k);
-        const unsigned cpos = (unsigned)(((n * p.Ti + tc) * p.Hi + hc) * p.Wi + wc);
+        unsigned cpos = (unsigned)(((n * p.Ti + tc) * p.Hi + hc) * p.Wi + wc);
+        if constexpr (F16) {
+            if (p.up2) {     // stored position of the centre tap; tap offsets then depend on the parity of (hc, wc)
+                cpos = (unsigned)(((n * p.Ti + tc) * p.Hp + (hc >> 1)) * p.Wp + (wc >> 1));
+                mask |= ((unsigned)(hc & 1) << 24) | ((unsigned)(wc & 1) << 25);
+            }
+        }
         a_off[i] = ok ? (cpos * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
         a_mask[i] = ok ? mask : 0u;
     }
@@ -341,12 +479,29 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const unsigned sel = valid ? ((1u << kt) | (1u << (8 + kh)) | (1u << (16 + kw))) : 0xFFFFFFFFu;
         const unsigned s_off =
             (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.ldx + c0) * 4);
+        // nearest-2x upsampled input: the tap's stored offset is floor((par + k - p) / 2) rows / columns from the
+        // centre's, i.e. one of two uniform values per axis, selected by the row's parity bits
+        unsigned up_h0 = 0, up_h1 = 0, up_w0 = 0, up_w1 = 0;
+        bool up2 = false;
+        if constexpr (F16) {
+            up2 = p.up2 != 0;
+            if (up2) {
+                const int row_b = p.Wp * p.ldx * 4, col_b = p.ldx * 4;
+                up_h0 = (unsigned)(((kh - p.pH) >> 1) * row_b + c0 * 4);
+                up_h1 = (unsigned)(((kh - p.pH + 1) >> 1) * row_b + c0 * 4);
+                up_w0 = (unsigned)(((kw - p.pW) >> 1) * col_b);
+                up_w1 = (unsigned)(((kw - p.pW + 1) >> 1) * col_b);
+            }
+        }
         auto issue_a = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&base)[A_IT], unsigned soff, int klim) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 bool ok = (a_mask[i] & sel) == sel;
                 if (KTAIL) ok = ok && (c0 + swz_col(tid + NT * i)) < klim;
-                const unsigned off = base[i] + soff;
+                unsigned off = base[i] + soff;
+                if constexpr (F16) {
+                    if (up2) off = base[i] + ((a_mask[i] & (1u << 24)) ? up_h1 : up_h0) + ((a_mask[i] & (1u << 25)) ? up_w1 : up_w0);
+                }
                 if constexpr (DMA) {
                     // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
                     if (wave_u * 64 + NT * i < A_F4)
@@ -406,8 +561,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // ---- residual prefetch: for same-shape residual adds with few accumulator tiles per wave the
     // residual values are requested BEFORE the k-loop, so their HBM latency hides under it ----
     const bool to_partial = p.split_k > 1;
-    const bool res_add = !to_partial && (p.flags & PTX_EPI_RES_ADD);
+    const bool res_add = !to_partial && (p.flags & PTX_EPI_RES_ADD) && !(F16 && (p.flags & kFusedEpiFlags));
     constexpr bool kResEarly = (TM * TN * MF::NACC) <= 16;   // keeps multi-tile waves (stem) under 128 regs
+    // fp16-operand tiles with any fused-stage flag take their own epilogue below (kFusedEpiFlags)
+    const bool fused_epi = F16 && p.split_k <= 1 && (p.flags & kFusedEpiFlags) != 0;
     const __amdgpu_buffer_rsrc_t rsrc_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, res_add ? p.r_bytes : 0u, 0x00020000);
     float rv[TM][TN][MF::NACC];
@@ -606,6 +763,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         }
     }
 
+    if constexpr (F16) {
+        if (fused_epi) {          // generator stage: per-sample affine / halfs out / dual output / half skip / tanh
+            fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane);
+            return;
+        }
+    }
     // ---- epilogue: bias + residual + ReLU, branch-free through buffer resources (out-of-range
     // stores are dropped, out-of-range loads read 0); residual values of a tile are requested in
     // one batch before they are consumed. ----
@@ -663,6 +826,28 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
         const size_t e = i * 4;
         const int m = (int)(e / p.ncol);
         const int co = (int)(e - (size_t)m * p.ncol);
+        if (p.flags & kFusedEpiFlags) {       // generator stage (see fused_stage_epilogue)
+            const float acc4[4] = {v.x, v.y, v.z, v.w};
+            float raw[4], out[4];
+            const int n = m / p.pps;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool aff = (p.flags & PTX_EPI_AFFINE) != 0;
+                const float sc = aff ? p.aff_scale[(size_t)n * p.ld_aff + co + c] : 1.f;
+                const float sh = aff ? p.aff_shift[(size_t)n * p.ld_aff + co + c] : 0.f;
+                fused_value(p, acc4[c], m, co + c, p.bias ? p.bias[co + c] : 0.f, sc, sh, raw[c], out[c]);
+            }
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            if (p.flags & PTX_EPI_OUT_F16)
+                *reinterpret_cast<half4_t*>(reinterpret_cast<_Float16*>(p.y) + (size_t)m * p.ldy + co) =
+                    half4_t{(_Float16)out[0], (_Float16)out[1], (_Float16)out[2], (_Float16)out[3]};
+            else
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + co) = f32x4{out[0], out[1], out[2], out[3]};
+            if (p.flags & PTX_EPI_DUAL_RAW)
+                *reinterpret_cast<half4_t*>(reinterpret_cast<_Float16*>(p.y_raw) + (size_t)m * p.ld_raw + co) =
+                    half4_t{(_Float16)raw[0], (_Float16)raw[1], (_Float16)raw[2], (_Float16)raw[3]};
+            continue;
+        }
         f32x4 o;
         o.x = conv_epilogue(p, v.x, m, co);
         o.y = conv_epilogue(p, v.y, m, co + 1);
@@ -969,6 +1154,12 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_F16(32, 64, 32, 2, 2, 16),    // 80
     PTX_CFG_F16(64, 32, 32, 2, 2, 16),    // 81 narrow outputs (the 3-channel image conv)
     PTX_CFG_F16(256, 128, 32, 4, 2, 32),  // 82
+    // bigger per-wave tiles (64x64: 4 fragment reads feed 4 MFMAs) for the LDS-read-bound generator convs
+    PTX_CFG_F16(128, 128, 32, 2, 2, 32),  // 83
+    PTX_CFG_F16(256, 64, 32, 4, 1, 32),   // 84 hidden width 64 (the 128^2 / 256^2 stages)
+    PTX_CFG_F16(128, 64, 32, 2, 2, 32),   // 85
+    PTX_CFG_F16(256, 16, 32, 8, 1, 16),   // 86 the 3-channel image conv: 16-wide N on 16x16x32 MFMA
+    PTX_CFG_F16(128, 16, 32, 4, 1, 16),   // 87
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1008,6 +1199,14 @@ static int validate_desc(const ptx_conv3d_desc* d) {
         return fail(PTX_ERR_INVALID, "conv3d: more than 2^31 positions");
     if ((d->flags & PTX_EPI_RES_ADD) && (d->flags & PTX_EPI_RES_PADA))
         return fail(PTX_ERR_INVALID, "conv3d: RES_ADD and RES_PADA are exclusive");
+    if ((d->flags & (kFusedEpiFlags | PTX_PRO_UP2)) && !(d->flags & PTX_F16_OPERANDS))
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: the fused generator-stage flags (halfs out, affine, dual output, half skip, "
+                    "tanh, upsampling loader) run on the fp16-operand tiles only");
+    if (d->flags & PTX_PRO_UP2) {
+        if (d->kT != 1 || d->Ti != 1 || d->sH != 1 || d->sW != 1 || (d->Hi & 1) || (d->Wi & 1) || d->groups > 1)
+            return fail(PTX_ERR_INVALID, "conv3d: PTX_PRO_UP2 needs a unit-stride 2-D conv over even (upsampled) extents");
+    }
+    if ((d->flags & PTX_EPI_RELU) && (d->flags & PTX_EPI_TANH)) return fail(PTX_ERR_INVALID, "conv3d: RELU and TANH are exclusive");
     return PTX_OK;
 }
 
@@ -1037,7 +1236,7 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     int cfg;
     if (d->flags & PTX_F16_OPERANDS) {
         const int64_t Mrows = (int64_t)d->N * d->To * d->Ho * d->Wo;
-        return ncol <= 32 ? 81 : (Mrows < 8192 ? 80 : (ncol >= 128 ? 74 : 75));
+        return ncol <= 16 ? 86 : ncol <= 32 ? 81 : (Mrows < 8192 ? 80 : (ncol >= 128 ? 74 : 75));
     }
     if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
         const int cog = d->Co / d->groups;
@@ -1104,7 +1303,7 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     if (batch > 1 || c.direct) split_k = 1;
     a.split_k = split_k;
     {
-        const uint64_t yb = (uint64_t)a.M * a.ldy * 4ull;
+        const uint64_t yb = (uint64_t)a.M * a.ldy * ((a.flags & PTX_EPI_OUT_F16) ? 2ull : 4ull);
         uint64_t rb = 0;
         if (a.flags & PTX_EPI_RES_ADD) rb = (uint64_t)a.M * a.ldr * 4ull;
         if (yb >= 0x80000000ull || rb >= 0x80000000ull)
@@ -1138,9 +1337,11 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
 
 static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed,
                          const float* bias, const float* res, float* y, void* workspace, size_t workspace_bytes,
-                         int config, int split_k, ptx_stream_t stream) {
+                         int config, int split_k, ptx_stream_t stream, const ptx_conv_fused_ext* ext = nullptr) {
     int s = validate_desc(d);
     if (s != PTX_OK) return s;
+    if ((d->flags & (PTX_EPI_AFFINE | PTX_EPI_DUAL_RAW)) && !ext)
+        return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_AFFINE / PTX_EPI_DUAL_RAW take their operands through ptx_conv3d_fused_fwd");
     if (!x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv3d: null tensor pointer");
     if ((d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) && !res)
         return fail(PTX_ERR_INVALID, "conv3d: residual flag set but res == NULL");
@@ -1184,7 +1385,8 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     a.M = d->N * d->To * d->Ho * d->Wo;
     a.flags = d->flags;
     {
-        const uint64_t xb = (uint64_t)d->N * d->Ti * d->Hi * d->Wi * d->ldx * 4ull;
+        const int up = (d->flags & PTX_PRO_UP2) ? 2 : 1;       // the stored input is (Hi/2, Wi/2) behind an upsampling loader
+        const uint64_t xb = (uint64_t)d->N * d->Ti * (d->Hi / up) * (d->Wi / up) * d->ldx * 4ull;
         const uint64_t wb = (uint64_t)d->kT * d->kH * d->kW * d->Co_pad * d->Kc * 4ull;
         if (xb >= 0x80000000ull || wb >= 0x80000000ull)
             return fail(PTX_ERR_UNSUPPORTED, "conv3d: input (%llu B) and packed filter (%llu B) must each be < 2 GiB "
@@ -1194,6 +1396,27 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     }
     a.f16 = (d->flags & PTX_F16_OPERANDS) ? 1 : 0;
     if (a.f16 && (x2 || d->groups > 1)) return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16 operands: single-source dense convs only");
+    a.up2 = (d->flags & PTX_PRO_UP2) ? 1 : 0;
+    a.Hp = a.up2 ? d->Hi / 2 : d->Hi;
+    a.Wp = a.up2 ? d->Wi / 2 : d->Wi;
+    a.pps = d->To * d->Ho * d->Wo;
+    if (d->flags & PTX_EPI_OUT_F16) {
+        if (d->Co % 2 || d->ldy % 8 || ((uintptr_t)y & 15))
+            return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_OUT_F16 needs an even Co and ldy (halfs) %% 8 == 0");
+    }
+    if (d->flags & PTX_EPI_AFFINE) {
+        if (!ext->scale || !ext->shift || ext->ld_affine < d->Co)
+            return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_AFFINE needs scale / shift tables with ld_affine >= Co");
+        a.aff_scale = ext->scale; a.aff_shift = ext->shift; a.ld_aff = ext->ld_affine;
+    }
+    if (d->flags & PTX_EPI_DUAL_RAW) {
+        const int nc = (d->Co + 3) / 4 * 4;
+        if (!ext->y_raw || ext->ld_raw < nc || ext->ld_raw % 8 || d->Co % 2 || ((uintptr_t)ext->y_raw & 15))
+            return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_DUAL_RAW needs y_raw (halfs) with ld_raw >= round_up(Co, 4), ld_raw %% 8 == 0");
+        const uint64_t rawb = (uint64_t)d->N * d->To * d->Ho * d->Wo * ext->ld_raw * 2ull;
+        if (rawb >= 0x80000000ull) return fail(PTX_ERR_UNSUPPORTED, "conv3d: y_raw of one launch must be < 2 GiB");
+        a.y_raw = ext->y_raw; a.ld_raw = ext->ld_raw; a.raw_bytes = (unsigned)rawb;
+    }
     a.groups = d->groups > 1 ? d->groups : 1;
     a.cig = d->Ci / a.groups; a.cog = d->Co / a.groups;
     if (a.groups > 1) {
@@ -1270,4 +1493,14 @@ extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t ba
     const int64_t blocks128 = cdiv64(M, 128) * cdiv(ldc, 128) * batch;
     const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 26 : 24;
     return launch_conv(a, config, 1, batch, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int ptx_conv3d_fused_fwd(const ptx_conv3d_desc* d, const void* x, const void* w_packed, const float* bias,
+                                    const void* res, void* y, const ptx_conv_fused_ext* ext, void* workspace,
+                                    size_t workspace_bytes, int config, int split_k, ptx_stream_t stream) {
+    if (!d || !(d->flags & PTX_F16_OPERANDS))
+        return fail(PTX_ERR_INVALID, "conv3d_fused: an fp16-operand descriptor (PTX_F16_OPERANDS) is required");
+    return conv3d_common(d, static_cast<const float*>(x), nullptr, static_cast<const float*>(w_packed), bias,
+                         static_cast<const float*>(res), static_cast<float*>(y), workspace, workspace_bytes, config, split_k,
+                         stream, ext);
 }

@@ -297,11 +297,15 @@ class PackedDual:
 class ConvStep:
     """One ptx_conv3d_fwd (or, with a second source, ptx_conv3d_dual_fwd) launch with everything but
     the stream frozen."""
-    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs")
+    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused")
 
     def __call__(self, st):
         p = self.plan
-        if self.x2 is not None:
+        if self.fused:        # fp16 generator stage: per-sample affine / halfs out / dual output / upsampling loader
+            check(_lib.lib().ptx_conv3d_fused_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
+                                                  C.byref(self.ext) if self.ext is not None else None,
+                                                  p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
+        elif self.x2 is not None:
             check(_lib.lib().ptx_conv3d_dual_fwd(C.byref(self.d), self.x, self.x2, self.w, self.b, self.y,
                                                  p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
         else:
@@ -384,26 +388,35 @@ class Plan:
         return a
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
-             label="conv", y=None, x2=None, x2_stride=1, same=False):
+             label="conv", y=None, x2=None, x2_stride=1, same=False, up2=False, affine=None, out_f16=False,
+             raw=False, tanh=False):
+        """Fused generator-stage extras (fp16-operand convs only, ptx_conv3d_fused_fwd):
+        up2      the conv slides over the nearest-2x upsampled input (the loader does the upsampling);
+        affine   (scale_ptr, shift_ptr, ld): per-sample affine after bias (+ skip) -- the NEXT layer's cBN, folded;
+        out_f16  y is written as halfs;  raw: also return the pre-affine output as a second (halfs) activation;
+        tanh     tanh on the output."""
         kT, kH, kW = pk.k_eff
         sT, sH, sW = stride
+        xT, xH, xW = x.T, x.H * (2 if up2 else 1), x.W * (2 if up2 else 1)
         if same:        # TF-"SAME": out = ceil(in/stride), `padding` is ignored, front pad = total // 2
-            (To, Ho, Wo), padding = _same_geometry((x.T, x.H, x.W), (kT, kH, kW), stride)
+            (To, Ho, Wo), padding = _same_geometry((xT, xH, xW), (kT, kH, kW), stride)
         pT, pH, pW = padding
         if not same:
-            To = (x.T + 2 * pT - kT) // sT + 1
-            Ho = (x.H + 2 * pH - kH) // sH + 1
-            Wo = (x.W + 2 * pW - kW) // sW + 1
+            To = (xT + 2 * pT - kT) // sT + 1
+            Ho = (xH + 2 * pH - kH) // sH + 1
+            Wo = (xW + 2 * pW - kW) // sW + 1
         if y is None:
-            y = self.act(x.N, To, Ho, Wo, pk.Co)
+            y = self.act(x.N, To, Ho, Wo, pk.Co, f16=out_f16)
+        if bool(y.f16) != bool(out_f16):
+            raise PtxError("%s: output precision mismatch" % label)
         if (y.N, y.T, y.H, y.W, y.C) != (x.N, To, Ho, Wo, pk.Co):
             raise PtxError("%s: output target %s does not match the conv result %s" % (
                 label, (y.N, y.T, y.H, y.W, y.C), (x.N, To, Ho, Wo, pk.Co)))
-        if y.ld != _r4(pk.Co) and pk.Co % 4:
+        if y.ld != _r4(pk.Co) and pk.Co % 4 and not out_f16:
             raise PtxError("%s: a channel-slice output needs Co %% 4 == 0" % label)
         flags = PTX_EPI_RELU if relu else 0
         d = ConvDesc()
-        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, xT, xH, xW, x.C, x.ld
         half = bool(getattr(x, "f16", False))
         if half != bool(getattr(pk, "f16", False)):
             raise PtxError("%s: activation and filter precisions differ" % label)
@@ -412,6 +425,25 @@ class Plan:
                 raise PtxError("%s: fp16 operands need an even channel count and 16-byte rows" % label)
             flags |= PTX_F16_OPERANDS
             d.Ci, d.ldx = x.C // 2, x.ld // 2
+        fused = bool(up2 or affine is not None or out_f16 or raw or tanh or (res is not None and getattr(res, "f16", False)))
+        if fused and not half:
+            raise PtxError("%s: the fused generator-stage options need fp16 operands" % label)
+        ext, raw_act = None, None
+        if fused:
+            from ._lib import (ConvFusedExt, PTX_EPI_AFFINE, PTX_EPI_DUAL_RAW, PTX_EPI_OUT_F16, PTX_EPI_TANH,
+                               PTX_PRO_UP2, PTX_RES_F16)
+            flags |= (PTX_PRO_UP2 if up2 else 0) | (PTX_EPI_OUT_F16 if out_f16 else 0) | (PTX_EPI_TANH if tanh else 0)
+            if res is not None and getattr(res, "f16", False):
+                flags |= PTX_RES_F16
+            if affine is not None or raw:
+                ext = ConvFusedExt()
+                if affine is not None:
+                    flags |= PTX_EPI_AFFINE
+                    ext.scale, ext.shift, ext.ld_affine = affine[0], affine[1], int(affine[2])
+                if raw:
+                    raw_act = self.act(x.N, To, Ho, Wo, pk.Co, f16=True)
+                    flags |= PTX_EPI_DUAL_RAW
+                    ext.y_raw, ext.ld_raw = raw_act.t.data_ptr(), raw_act.ld
         d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, y.ld
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
         d.Kc, d.Co_pad = (pk.Kc // 2 if half else pk.Kc), pk.Co_pad
@@ -439,6 +471,7 @@ class Plan:
         st.plan, st.label = self, label
         st.macs = x.N * To * Ho * Wo * pk.Co * getattr(pk, "real_ci", pk.Ci) * pk.d.kT * pk.d.kH * pk.d.kW
         st.x2 = None
+        st.ext, st.fused = ext, fused
         if x2 is not None:                      # K-concatenated second activation source (shortcut B)
             d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = x2.C, x2.ld, x2.T, x2.H, x2.W
             d.x2_sT, d.x2_sH, d.x2_sW = _t3(x2_stride)
@@ -458,7 +491,7 @@ class Plan:
         self.ws_bytes = max(self.ws_bytes, int(self.lib.ptx_conv3d_workspace_bytes(C.byref(d), want)))
         self.steps.append(st)
         self.conv_steps.append(st)
-        return y
+        return (y, raw_act) if raw else y
 
     def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv", y=None):
         """nn.Conv{2,3}d or a (2+1)D pair, followed by `bn`, with the epilogue fused."""
@@ -1236,6 +1269,8 @@ class Engine:
                     if stp.d.groups > 1 and not name.endswith("/direct") and (stp.d.Co // stp.d.groups) % bn_:
                         continue                         # grouped: direct tiles, or MFMA tiles inside one group
                     if bn_ > 64 and ncol <= 64:
+                        continue
+                    if bn_ < 32 and ncol > 32 and name.endswith("/f16"):
                         continue
                     if bn_ % 48 == 0 and ncol % 48 != 0:          # 48/96-wide tiles: (2+1)D widths only
                         continue

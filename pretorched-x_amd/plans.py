@@ -260,24 +260,80 @@ def build_biggan(self, model):
         return affine(x, _ptr(scale_all, o), _ptr(shift_all, o), tot, up)
 
     one, zero = (1, 1, 1), (0, 0, 0)
+    if half:
+        return _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all, tot, oscale, oshift)
     for si, stage in enumerate(model.blocks):
         for bi, blk in enumerate(stage):
             name = "blocks.%d.%d" % (si, bi)
             if blk.kind == "gblock":
                 up = 2 if blk.upsample else 1
-                t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None, f16=half), one, zero, label=name + ".conv1")
-                t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None, f16=half), one, (0, 1, 1), label=name + ".conv2")
-                t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None, f16=half), one, (0, 1, 1), label=name + ".conv3")
+                t = self.conv(cbn(h, blk.bn1), self.pack(blk.conv1, None), one, zero, label=name + ".conv1")
+                t = self.conv(cbn(t, blk.bn2, up), self.pack(blk.conv2, None), one, (0, 1, 1), label=name + ".conv2")
+                t = self.conv(cbn(t, blk.bn3), self.pack(blk.conv3, None), one, (0, 1, 1), label=name + ".conv3")
                 if up == 1 and blk.in_channels == blk.out_channels:
-                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None, f16=half), one, zero, res=h, label=name + ".conv4")
+                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, label=name + ".conv4")
                 else:   # skip = upsample(x[:, :Cout]) gathered in the epilogue
-                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None, f16=half), one, zero, res=h, res_kind="up",
+                    h = self.conv(cbn(t, blk.bn4), self.pack(blk.conv4, None), one, zero, res=h, res_kind="up",
                                   res_stride=(0, up // 2, up // 2), label=name + ".conv4")
             else:
                 h = biggan_attention(self, h, blk, name)
     a = affine(h, _ptr(oscale), _ptr(oshift), obn.channels, 1)
-    img = self.conv(a, self.pack(model.output_layer[2], None, f16=half), one, (0, 1, 1), label="output_layer.2")
+    img = self.conv(a, self.pack(model.output_layer[2], None), one, (0, 1, 1), label="output_layer.2")
     self.feat = affine(img, None, None, 0, 1, act=2)            # tanh
+    self.pooled = None
+
+
+def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all, tot, oscale, oshift):
+    """precision='fp16' (BASELINE.json config 5 "fp16 MFMA"): the fused cBN + upsample + conv generator stage.
+
+    Between the convs of a GBlock the activations are halfs and no normalisation / ReLU / upsampling pass exists:
+      * the class-conditional BN + ReLU that FOLLOWS a conv runs in that conv's epilogue as a per-sample affine
+        (scale / shift tables folded from the one cBN GEMV pair) and the result is stored as halfs;
+      * the nearest 2x upsample that PRECEDES the first 3x3 conv of an upsampling block is the conv's loader
+        (PTX_PRO_UP2: address arithmetic in the implicit GEMM, the upsampled tensor never exists);
+      * a block's last conv adds the skip up(x[:, :Cout]) in its epilogue and writes BOTH what the next block
+        consumes: relu(cBN1_next(out)) for its first conv and the raw sum for its skip connection, as halfs;
+      * the image conv applies tanh in its epilogue (16-wide N tile on 16x16x32 MFMA for its 3 channels).
+    HBM passes left: the first cBN of the network (4x4 input of the linear layer), the pass around the 64x64
+    self-attention block (fp32, on the non-local kernels), the NHWC -> NCHW edge of the 3-channel image."""
+    one, zero = (1, 1, 1), (0, 0, 0)
+    flat = [(si, bi, blk) for si, stage in enumerate(model.blocks) for bi, blk in enumerate(stage)]
+    obn = model.output_layer[0]
+
+    def tab(bn):
+        o = offs[id(bn)]
+        return (_ptr(scale_all, o), _ptr(shift_all, o), tot)
+
+    xa, xr = cbn(h, flat[0][2].bn1), h          # activated input of the first block (halfs), its skip operand (fp32)
+    for k, (si, bi, blk) in enumerate(flat):
+        name = "blocks.%d.%d" % (si, bi)
+        nxt = flat[k + 1][2] if k + 1 < len(flat) else None
+        if blk.kind != "gblock":                 # self-attention on the fp32 raw map, then re-enter the fp16 chain
+            h32 = biggan_attention(self, xr, blk, name)
+            xa, xr = (cbn(h32, nxt.bn1), h32) if nxt is not None else (None, h32)
+            continue
+        up = bool(blk.upsample)
+        pk = lambda c: self.pack(c, None, f16=True)            # noqa: E731
+        t = self.conv(xa, pk(blk.conv1), one, zero, relu=True, affine=tab(blk.bn2), out_f16=True, label=name + ".conv1")
+        t = self.conv(t, pk(blk.conv2), one, (0, 1, 1), relu=True, affine=tab(blk.bn3), out_f16=True, up2=up,
+                      label=name + ".conv2")
+        t = self.conv(t, pk(blk.conv3), one, (0, 1, 1), relu=True, affine=tab(blk.bn4), out_f16=True, label=name + ".conv3")
+        skip = dict(res=xr) if (not up and blk.in_channels == blk.out_channels) else \
+            dict(res=xr, res_kind="up", res_stride=(0, int(up), int(up)))
+        if nxt is None:                          # last block: the output layer's BN + ReLU in the epilogue
+            xa = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=(_ptr(oscale), _ptr(oshift), obn.channels),
+                           out_f16=True, label=name + ".conv4", **skip)
+            xr = None
+        elif nxt.kind == "gblock":               # next block's cBN1 + ReLU, plus the raw sum for its skip
+            xa, xr = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=tab(nxt.bn1), out_f16=True, raw=True,
+                               label=name + ".conv4", **skip)
+        else:                                    # attention next: it wants the raw fp32 map
+            xr = self.conv(t, pk(blk.conv4), one, zero, label=name + ".conv4", **skip)
+            xa = None
+    if xa is None:                               # the network ended on an attention block (not a published layout)
+        xa = affine(xr, _ptr(oscale), _ptr(oshift), obn.channels, 1)
+    self.feat = self.conv(xa, self.pack(model.output_layer[2], None, f16=True), one, (0, 1, 1), tanh=True,
+                          label="output_layer.2")
     self.pooled = None
 
 def biggan_attention(self, x, att, name):

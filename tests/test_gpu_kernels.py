@@ -903,3 +903,110 @@ def test_fused_nonlocal_attention(ptx, case):
     desc.d = 1024
     assert not lib.ptx_nonlocal_supported(C.byref(desc))
     assert lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()) != 0
+
+
+def _fused_stage_case(ptx, N, H, W, Ci, Co, k, up2, affine, relu, tanh, out16, dual, skip, cfgs):
+    """One ptx_conv3d_fused_fwd launch per tile configuration against the op sequence it replaces, in torch fp32 on
+    the CPU with the SAME half-rounded operands: [nearest x2] -> conv -> (+ skip) -> [raw] -> affine -> relu | tanh."""
+    L, lib = ptx._lib, _lib(ptx)
+    pad = k // 2
+    x = rnd(N, Ci, 1, H, W, seed=300 + Ci).half().float()
+    w = rnd(Co, Ci, 1, k, k, seed=301, scale=(Ci * k * k) ** -0.5).half().float()
+    bias = rnd(Co, seed=302)
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    xin = F.interpolate(x[:, :, 0], scale_factor=2, mode="nearest").unsqueeze(2) if up2 else x
+    v = F.conv3d(xin, w, bias, 1, (0, pad, pad))
+    res_t, res_flags, res_ld = None, 0, 0
+    d = L.ConvDesc()
+    if skip is not None:
+        kind, r16 = skip                                    # ("same" | "up", halfs?)
+        if kind == "same":
+            r = rnd(N, Co, 1, Ho, Wo, seed=303)
+            r = r.half().float() if r16 else r
+            v = v + r
+            res_flags = L.PTX_EPI_RES_ADD
+        else:                                               # GBlock skip: up(x_prev[:, :Co]) with more channels stored
+            Cr = Co + 8
+            r = rnd(N, Cr, 1, Ho // 2, Wo // 2, seed=304)
+            r = r.half().float() if r16 else r
+            v = v + F.interpolate(r[:, :Co, 0], scale_factor=2, mode="nearest").unsqueeze(2)
+            res_flags = L.PTX_EPI_RES_PADA | L.PTX_EPI_RES_UP
+            d.res_C, d.res_T, d.res_H, d.res_W = Cr, 1, Ho // 2, Wo // 2
+            d.res_sT, d.res_sH, d.res_sW = 0, 1, 1
+        C_r = r.shape[1]
+        res_ld = (C_r + 7) // 8 * 8 if r16 else _r4(C_r)
+        rt = torch.zeros(N, 1, r.shape[3], r.shape[4], res_ld, dtype=torch.float16 if r16 else torch.float32)
+        rt[..., :C_r] = r.permute(0, 2, 3, 4, 1).to(rt.dtype)
+        res_t = rt.to(DEV)
+        res_flags |= L.PTX_RES_F16 if r16 else 0
+    raw_want = v
+    ld_aff = Co + 5
+    sc = torch.rand(N, ld_aff, generator=torch.Generator().manual_seed(305)) + 0.5
+    sh = rnd(N, ld_aff, seed=306, scale=0.3)
+    if affine:
+        v = v * sc[:, :Co, None, None, None] + sh[:, :Co, None, None, None]
+    v = F.relu(v) if relu else v
+    v = torch.tanh(v) if tanh else v
+    # operands on the device
+    ldh = (Ci + 7) // 8 * 8
+    xh = torch.zeros(N, 1, H, W, ldh, dtype=torch.float16)
+    xh[..., :Ci] = x.permute(0, 2, 3, 4, 1).half()
+    xd = xh.to(DEV)
+    pd = L.PackDesc(Co, Ci, 1, k, k, ldh, (Co + 127) // 128 * 128, 0, 0, 0, 0, 0, 0, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV, dtype=torch.float16)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd, bd, scd, shd = w.to(DEV), bias.to(DEV), sc.to(DEV), sh.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0),
+                                     C.c_void_p(wp.data_ptr()), _p(bp), _st()), "pack f16")
+    ldy = (Co + 7) // 8 * 8 if out16 else _r4(Co)
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, Ho, Wo, Ci // 2, ldh // 2      # (Hi, Wi): the UPSAMPLED extents under up2
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, Ho, Wo, Co, ldy
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 1, k, k, 1, 1, 1, 0, pad, pad
+    d.Kc, d.Co_pad, d.groups, d.ldr = ldh // 2, pd.Co_pad, 1, res_ld
+    d.flags = (L.PTX_F16_OPERANDS | res_flags | (L.PTX_PRO_UP2 if up2 else 0) | (L.PTX_EPI_AFFINE if affine else 0) |
+               (L.PTX_EPI_RELU if relu else 0) | (L.PTX_EPI_TANH if tanh else 0) | (L.PTX_EPI_OUT_F16 if out16 else 0) |
+               (L.PTX_EPI_DUAL_RAW if dual else 0))
+    ld_raw = (_r4(Co) + 7) // 8 * 8
+    ext = L.ConvFusedExt()
+    ext.scale, ext.shift, ext.ld_affine = scd.data_ptr(), shd.data_ptr(), ld_aff
+    ws = torch.empty(4 * N * Ho * Wo * _r4(Co), device=DEV)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    tol_out = 2e-3 if out16 else 2e-4                       # halfs out: 2^-11 relative rounding of the stored value
+    for cfg, split in cfgs:
+        yd = torch.full((N, 1, Ho, Wo, ldy), float("nan"), device=DEV, dtype=torch.float16 if out16 else torch.float32)
+        rawd = torch.full((N, 1, Ho, Wo, ld_raw), float("nan"), device=DEV, dtype=torch.float16)
+        ext.y_raw, ext.ld_raw = rawd.data_ptr(), ld_raw
+        L.check(lib.ptx_conv3d_fused_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
+                                         C.c_void_p(res_t.data_ptr()) if res_t is not None else None,
+                                         C.c_void_p(yd.data_ptr()), C.byref(ext), _p(ws), ws.numel() * 4, cfg, split, _st()),
+                "fused conv cfg %s" % (names[cfg] if cfg >= 0 else "auto"))
+        torch.cuda.synchronize()
+        got = yd.float().cpu()[..., :Co].permute(0, 4, 1, 2, 3)
+        close(got, v, tol=tol_out)
+        if dual:
+            close(rawd.float().cpu()[..., :Co].permute(0, 4, 1, 2, 3), raw_want, tol=2e-3)
+
+
+def test_conv_fused_generator_stage(ptx):
+    """BASELINE.json config 5's "fused cBN + upsample + conv generator stage": every piece of
+    ptx_conv3d_fused_fwd's epilogue / loader, each on several fp16 tiles (and split-K through the reduce kernel)."""
+    lib = _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    f16 = [i for i, n in enumerate(names) if n.endswith("/f16")]
+    wide = [(c, 1) for c in f16 if int(names[c].split("x")[1]) >= 32]
+    every = [(-1, 0)] + wide + [(wide[0][0], 3)]
+    some = [(-1, 0), wide[1], wide[-1], (wide[2][0], 2)]
+    # conv1 of a GBlock: 1x1, next cBN + ReLU, halfs out
+    _fused_stage_case(ptx, 3, 6, 6, 64, 32, 1, False, True, True, False, True, False, None, every)
+    # conv2 of an upsampling GBlock: the loader upsamples; several samples inside one 32-row tile (4x4 maps)
+    _fused_stage_case(ptx, 2, 7, 5, 32, 32, 3, True, True, True, False, True, False, None, every)
+    _fused_stage_case(ptx, 5, 2, 2, 48, 40, 3, True, True, True, False, True, False, None, some)
+    # conv4: + upsampled, channel-truncated half skip, dual output (next block's input and skip)
+    _fused_stage_case(ptx, 2, 8, 8, 32, 64, 1, False, True, True, False, True, True, ("up", True), every)
+    _fused_stage_case(ptx, 2, 6, 6, 32, 64, 1, False, True, True, False, True, True, ("same", True), some)
+    # first block after the linear layer / attention: fp32 skip operand; block before attention: raw fp32 out
+    _fused_stage_case(ptx, 2, 8, 8, 32, 64, 1, False, True, True, False, True, True, ("up", False), some)
+    _fused_stage_case(ptx, 2, 6, 6, 32, 64, 1, False, False, False, False, False, False, ("same", False), some)
+    # image conv: 3 channels, tanh, fp32 out, 16-wide N tiles
+    narrow = [(c, 1) for c in f16 if int(names[c].split("x")[1]) <= 32]
+    _fused_stage_case(ptx, 2, 9, 9, 64, 3, 3, False, False, False, True, False, False, None, [(-1, 0)] + narrow)
