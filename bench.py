@@ -205,6 +205,12 @@ def main():
         # ---- per-kernel roofline: every conv launch timed with HIP events on the launch stream ----
         plan = list(eng._plans.values())[-1]
         rows = eng.profile_convs(model, x, iters=5, plan=plan)
+        if os.environ.get("PTX_BENCH_ROWS"):       # per-launch detail for tuning sessions
+            with open(os.environ["PTX_BENCH_ROWS"], "w") as f:
+                for (label, macs, ms, cfg, split), stp in zip(rows, plan.conv_steps):
+                    f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
+                        label, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
+                        stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, split, ms, 2e-9 * macs / ms))
         by_kernel = {}
         for label, macs, ms, cfg, split in rows:
             k = by_kernel.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))

@@ -70,9 +70,24 @@ struct ConvArgs {
     int ld_aff, pps;       // table row stride; output positions per sample (sample of row m = m / pps)
     void* y_raw;           // second output: the pre-affine value, halfs, row stride ld_raw
     int ld_raw;
-    unsigned raw_bytes;
+    unsigned raw_bytes, aff_bytes;
     int up2, Hp, Wp;       // up2: (Hi, Wi) are the UPSAMPLED extents the filter slides over, (Hp, Wp) the stored ones
+    unsigned dv_wo[2], dv_ho[2], dv_to[2];   // fast division by Wo / Ho / To (mul, shift): the epilogue's row decode
 };
+
+// n / d for n < 2^31 without the ~30-instruction integer division sequence: d == 1 -> mul == 0; else
+// l = ceil(log2 d), mul = ceil(2^(31+l) / d) (< 2^32), q = umulhi(n, mul) >> (l - 1).  Exact: the rounding error of
+// mul adds less than 2^-l <= 1/d to n / d.
+inline void fastdiv_make(unsigned d, unsigned (&out)[2]) {
+    if (d <= 1) { out[0] = 0; out[1] = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    out[0] = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+    out[1] = l - 1;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const unsigned (&dv)[2]) {
+    return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
+}
 
 constexpr unsigned kFusedEpiFlags = PTX_EPI_OUT_F16 | PTX_EPI_AFFINE | PTX_EPI_DUAL_RAW | PTX_RES_F16 | PTX_EPI_TANH;
 
@@ -163,12 +178,12 @@ __device__ __forceinline__ float fused_skip(const ConvArgs& p, int m, int co) {
         idx = (size_t)m * p.ldr + co;
     } else {
         if (co >= ((p.flags & PTX_EPI_RES_UP) ? p.Co : p.res_C)) return 0.f;
-        const int wo = m % p.Wo;
-        int t = m / p.Wo;
-        const int ho = t % p.Ho;
-        t /= p.Ho;
-        const int to = t % p.To;
-        const int n = t / p.To;
+        unsigned t = fastdiv((unsigned)m, p.dv_wo);
+        const int wo = m - (int)t * p.Wo;
+        unsigned t2 = fastdiv(t, p.dv_ho);
+        const int ho = (int)t - (int)t2 * p.Ho;
+        const int n = (int)fastdiv(t2, p.dv_to);
+        const int to = (int)t2 - n * p.To;
         const bool up = (p.flags & PTX_EPI_RES_UP) != 0;
         const int rt = up ? to >> p.res_sT : to * p.res_sT, rh = up ? ho >> p.res_sH : ho * p.res_sH,
                   rw = up ? wo >> p.res_sW : wo * p.res_sW;
@@ -213,9 +228,19 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
     constexpr unsigned kOOB = 0x80000000u;
     const bool out16 = (p.flags & PTX_EPI_OUT_F16) != 0, dual = (p.flags & PTX_EPI_DUAL_RAW) != 0;
     const bool affine = (p.flags & PTX_EPI_AFFINE) != 0;
+    const bool res_same = (p.flags & PTX_EPI_RES_ADD) != 0, res_gather = (p.flags & PTX_EPI_RES_PADA) != 0;
+    const bool res_up = (p.flags & PTX_EPI_RES_UP) != 0, r16 = (p.flags & PTX_RES_F16) != 0;
+    const int res_lim = res_up ? p.Co : p.res_C;
+    const unsigned esz = r16 ? 2u : 4u;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_raw =
         __builtin_amdgcn_make_buffer_rsrc(dual ? p.y_raw : (void*)p.y, 0, dual ? p.raw_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.res ? p.res : p.y), 0, (res_same || res_gather) ? p.r_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(affine ? p.aff_scale : p.y), 0, affine ? p.aff_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(affine ? p.aff_shift : p.y), 0, affine ? p.aff_bytes : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn * WTN + j * MT + (lane % MT);
@@ -224,26 +249,65 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mrow = m0 + wm * WTM + i * MT;
-            // the tile's rows usually belong to ONE sample: its scale / shift are then one load per column
-            const int n_lo = mrow / p.pps, n_hi = min(mrow + MT - 1, p.M - 1) / p.pps;
+            // Every load of the tile is issued before the first is consumed, branch-free: anything that must read as
+            // zero gets a byte offset >= num_records of its buffer resource (an exec-masked branch around each guarded
+            // load would serialise them -- DESIGN.md finding 2).
+            // The tile's rows usually belong to ONE sample: its scale / shift are then one load per column.
+            const int n_lo = (int)((unsigned)mrow / (unsigned)p.pps), n_hi = (int)((unsigned)min(mrow + MT - 1, p.M - 1) / (unsigned)p.pps);
             const bool one = n_lo == n_hi;
-            float sc = 1.f, sh = 0.f;
-            if (affine && one && co_ok && mrow < p.M) {
-                sc = p.aff_scale[(size_t)n_lo * p.ld_aff + co];
-                sh = p.aff_shift[(size_t)n_lo * p.ld_aff + co];
+            float sc1 = 1.f, sh1 = 0.f;
+            if (affine && one) {
+                const unsigned off = ((unsigned)n_lo * (unsigned)p.ld_aff + (unsigned)co) * 4u;
+                sc1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, (co_ok && mrow < p.M) ? off : kOOB, 0, 0));
+                sh1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, (co_ok && mrow < p.M) ? off : kOOB, 0, 0));
             }
-            float raw[NACC], out[NACC];
+            float skip[NACC], scv[NACC], shv[NACC];
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int m = mrow + MF::row(r, lane);
                 const bool ok = co_ok && m < p.M;
-                float s1 = sc, s0 = sh;
-                if (affine && !one && ok) {
-                    const int n = m / p.pps;
-                    s1 = p.aff_scale[(size_t)n * p.ld_aff + co];
-                    s0 = p.aff_shift[(size_t)n * p.ld_aff + co];
+                skip[r] = 0.f;
+                if (res_same || res_gather) {
+                    unsigned pos = (unsigned)m;
+                    bool rok = ok;
+                    if (res_gather) {
+                        const unsigned t = fastdiv((unsigned)m, p.dv_wo);
+                        const int wo = m - (int)t * p.Wo;
+                        const unsigned t2 = fastdiv(t, p.dv_ho);
+                        const int ho = (int)t - (int)t2 * p.Ho;
+                        const int n = (int)fastdiv(t2, p.dv_to);
+                        const int to = (int)t2 - n * p.To;
+                        const int rt = res_up ? to >> p.res_sT : to * p.res_sT, rh = res_up ? ho >> p.res_sH : ho * p.res_sH,
+                                  rw = res_up ? wo >> p.res_sW : wo * p.res_sW;
+                        pos = (unsigned)(((n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw);
+                        rok = ok && co < res_lim;
+                    }
+                    const unsigned off = rok ? (pos * (unsigned)p.ldr + (unsigned)co) * esz : kOOB;
+                    if (r16) {
+                        const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_res, off, 0, 0);
+                        skip[r] = (float)__builtin_bit_cast(_Float16, h);
+                    } else {
+                        skip[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
+                    }
                 }
-                fused_value(p, acc[i][j][r], ok ? m : 0, ok ? co : 0, bv, s1, s0, raw[r], out[r]);
+                scv[r] = sc1;
+                shv[r] = sh1;
+                if (affine && !one) {
+                    const unsigned n = (unsigned)m / (unsigned)p.pps;
+                    const unsigned off = ok ? (n * (unsigned)p.ld_aff + (unsigned)co) * 4u : kOOB;
+                    scv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, off, 0, 0));
+                    shv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, off, 0, 0));
+                }
+            }
+            float raw[NACC], out[NACC];
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                float v = acc[i][j][r] + bv + skip[r];
+                raw[r] = v;
+                if (affine) v = fmaf(v, scv[r], shv[r]);
+                if (p.flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
+                if (p.flags & PTX_EPI_TANH) v = tanhf(v);
+                out[r] = v;
             }
             if (out16) {
                 store_half_pairs<MF, NACC, MT>(rs_y, out, mrow, co, lane, (unsigned)p.ldy, p.M, p.ncol);
@@ -277,7 +341,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // XOR swizzle of the 16-byte slot index that is applied to the per-lane SOURCE address when
     // loading and to the fragment read address (cdna_hip_programming.md rule 21).
     constexpr int LDK = DMA ? BK : BK + 4;
-    static_assert(!DMA || (!K22 && (BK == 64 || BK == 32 || BK == 16)), "DMA staging: BK 64, 32 or 16");
+    static_assert(!DMA || (BK == 64 || BK == 32 || BK == 16), "DMA staging: BK 64, 32 or 16");
+    static_assert(!(DMA && K22) || (BK == 32 && NSTAGE == 2), "the LDS-DMA K22 stem tile stages 32-float rows, 2 buffers");
     static_assert(NSTAGE == 2 || (NSTAGE >= 3 && NSTAGE <= 6 && DMA), "deeper rings need DMA staging");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MT, TN = WTN / MT;
@@ -589,28 +654,36 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // fragment registers, rotated across sub-steps.  The slot sequence must close on itself at the
     // step boundary with compile-time indices: 2 slots for an even sub-step count, KSUB for odd.
     static_assert(KSUB >= 2, "at least two sub-steps per k-step");
-    constexpr int NSLOT = (KSUB % 2) ? KSUB : 2;
-    f32x4 fa[NSLOT][TM], fb[NSLOT][TN];
     // K22 (kW-folded stem: only 21 of the 24 k of a chunk carry data): the last sub-step covers
     // k = 16..21 with two 8-byte reads per row -- lane group g gets (16+2g, 17+2g) and (20+2g, 21+2g)
     // -- and 3 MFMAs pairing (16,18) (17,19) (20,22); the pair (21,23) is all padding and is dropped:
     // 11 instead of 12 MFMAs per tap.
-    static_assert(!K22 || (BK == 24 && MT == 32), "K22 is the BK = 24 / 32x32x2 stem path");
+    static_assert(!K22 || ((BK == 24 || (DMA && BK == 32)) && MT == 32), "K22 is the 32x32x2 stem path (BK 24, or 32 under DMA)");
+    // live sub-steps of a k-step: the LDS-DMA K22 tile stages 32-float rows of which 22 carry data -- sub-steps 0, 1
+    // (k 0..15), the 3-MFMA sub-step 2 (k 16..21), nothing for k 24..31
+    constexpr int KLIVE = (K22 && DMA) ? 3 : KSUB;
+    constexpr int NSLOT = (KLIVE % 2) ? KLIVE : 2;
+    f32x4 fa[NSLOT][TM], fb[NSLOT][TN];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto read_frags = [&](int buf, int ks, int slot, int offa, int offb) {
-        if (K22 && ks == KSUB - 1) {
-            const float* Ab = As + buf * BM * LDK + offa + 16 + (lane / MT) * 2 - (lane / MT) * 4;
-            const float* Bb = Bs + buf * BN * LDK + offb + 16 + (lane / MT) * 2 - (lane / MT) * 4;
+        if (K22 && ks == KLIVE - 1) {
+            // floats (16 + 2g, 17 + 2g) and (20 + 2g, 21 + 2g) of the row; under DMA they sit in the swizzled
+            // 16-byte slots 4 and 5 (offa / offb then carry no lane-group term)
+            const int g = lane / MT;
+            const int lo_off = DMA ? ((4 ^ frag_sw) * 4 + 2 * g) : (16 + 2 * g - 4 * g);
+            const int hi_off = DMA ? ((5 ^ frag_sw) * 4 + 2 * g) : (20 + 2 * g - 4 * g);
+            const float* Ab = As + buf * BM * LDK + offa;
+            const float* Bb = Bs + buf * BN * LDK + offb;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK);
-                const f32x2 hi = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + 4);
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + lo_off);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + hi_off);
                 fa[slot][i] = f32x4{lo.x, lo.y, hi.x, hi.y};
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const f32x2 lo = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK);
-                const f32x2 hi = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + 4);
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + lo_off);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + hi_off);
                 fb[slot][j] = f32x4{lo.x, lo.y, hi.x, hi.y};
             }
             return;
@@ -717,8 +790,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int it = 0; it < my_steps; ++it) {
                 const int buf = it & 1;
 #pragma unroll
-                for (int ks = 0; ks < KSUB; ++ks) {
-                    if (ks == KSUB - 1) {
+                for (int ks = 0; ks < KLIVE; ++ks) {
+                    if (ks == KLIVE - 1) {
                         step_barrier();
                         post_barrier_offsets(offa, offb);
                         load_tiles(it + 2 < my_steps, buf);
@@ -727,7 +800,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     } else {
                         read_frags(buf, ks + 1, (ks + 1) % NSLOT, offa, offb);
                     }
-                    mma_frags(ks % NSLOT, 4);
+                    mma_frags(ks % NSLOT, (K22 && ks == KLIVE - 1) ? 3 : 4);
                 }
             }
         }
@@ -890,6 +963,11 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
         // kW-folded stem: one 24-wide chunk per tap of which at most 22 columns are live
         if (a.k_live <= 22 && a.kA == 24 && a.kB == 24)
             return launch_one<BM, BN, BK, WM, WN, MT, false, true, false, 2>(a, grid, st);
+    }
+    if constexpr (BK == 32 && MT == 32 && DMA && NSTAGE == 2 && BN == 64) {
+        // kW-folded stem on 32-float rows (fold ld = 32): LDS-DMA staging, 11 MFMAs per tap as on the BK = 24 tiles
+        if (a.k_live <= 22 && a.kA == 32 && a.kB == 32 && !a.dual && a.groups <= 1)
+            return launch_one<BM, BN, BK, WM, WN, MT, false, true, true, 2>(a, grid, st);
     }
     if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
         return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE>(a, grid, st);
@@ -1310,10 +1388,19 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
             return fail(PTX_ERR_UNSUPPORTED, "conv3d: output / residual of one launch must be < 2 GiB; split the batch");
         a.y_bytes = (unsigned)yb;
         a.r_bytes = (unsigned)rb;
+        if (a.f16 && (a.flags & kFusedEpiFlags)) {           // fused epilogue: residual extent in its own element size
+            const uint64_t esz = (a.flags & PTX_RES_F16) ? 2ull : 4ull;
+            uint64_t rtot = 0;
+            if (a.flags & PTX_EPI_RES_ADD) rtot = (uint64_t)a.M * a.ldr * esz;
+            if (a.flags & PTX_EPI_RES_PADA) rtot = (uint64_t)a.N * a.res_T * a.res_H * a.res_W * a.ldr * esz;
+            if (rtot >= 0x80000000ull) return fail(PTX_ERR_UNSUPPORTED, "conv3d: skip operand of one launch must be < 2 GiB");
+            a.r_bytes = (unsigned)rtot;
+        }
+        if (split_k > 1) a.y_bytes = (unsigned)std::min<uint64_t>((uint64_t)a.M * a.ncol * 4ull, 0x7fffffffull);   // fp32 partial slab
     }
     a.partial = nullptr;
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
-                        a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo) ? 1 : 0;
+                        a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && !a.up2) ? 1 : 0;
     if (split_k > 1) {
         const size_t need = (size_t)split_k * a.M * a.ncol * sizeof(float);
         if (!workspace || workspace_bytes < need)
@@ -1400,6 +1487,9 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     a.Hp = a.up2 ? d->Hi / 2 : d->Hi;
     a.Wp = a.up2 ? d->Wi / 2 : d->Wi;
     a.pps = d->To * d->Ho * d->Wo;
+    fastdiv_make((unsigned)d->Wo, a.dv_wo);
+    fastdiv_make((unsigned)d->Ho, a.dv_ho);
+    fastdiv_make((unsigned)d->To, a.dv_to);
     if (d->flags & PTX_EPI_OUT_F16) {
         if (d->Co % 2 || d->ldy % 8 || ((uintptr_t)y & 15))
             return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_OUT_F16 needs an even Co and ldy (halfs) %% 8 == 0");
@@ -1408,6 +1498,7 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
         if (!ext->scale || !ext->shift || ext->ld_affine < d->Co)
             return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_AFFINE needs scale / shift tables with ld_affine >= Co");
         a.aff_scale = ext->scale; a.aff_shift = ext->shift; a.ld_aff = ext->ld_affine;
+        a.aff_bytes = (unsigned)std::min<uint64_t>(((uint64_t)(d->N - 1) * ext->ld_affine + d->Co) * 4ull, 0x7fffffffull);
     }
     if (d->flags & PTX_EPI_DUAL_RAW) {
         const int nc = (d->Co + 3) / 4 * 4;

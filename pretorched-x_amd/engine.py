@@ -98,6 +98,12 @@ def _r4(v):
     return (v + 3) // 4 * 4
 
 
+def _stem_ld():
+    """Row length (floats) of the kW-folded stem operand: 24 = 96-byte rows for the register-staged BK = 24 tiles,
+    32 = 128-byte rows, which the conflict-free LDS-DMA K22 tile can stage (the fold writes 33 % more)."""
+    return 32 if os.environ.get("PTX_STEM_LD", "24") == "32" else 24
+
+
 def _r128(v):
     return (v + 127) // 128 * 128
 
@@ -218,7 +224,7 @@ class Packed:
         if self.f16 and (fold_kw or self.groups > 1 or self.Ci % 2):
             raise PtxError("fp16 filters: dense, unfolded convs with an even channel count only")
         if fold_kw:
-            self.Kc = max(self.Kc, 24) if keff <= 24 else self.Kc
+            self.Kc = max(self.Kc, _stem_ld()) if keff <= 24 else self.Kc
         self.Co_pad = _r128(self.Co)
         self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
         self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw), 0, 0, 0,
@@ -525,7 +531,7 @@ class Plan:
             pW, Wo = same_pad, -(-raw.W // sW)
         else:
             Wo = (raw.W + 2 * pW - kW) // sW + 1
-        ld = max(_r4(kW * raw.C), 24) if kW * raw.C <= 24 else _r4(kW * raw.C)
+        ld = max(_r4(kW * raw.C), _stem_ld()) if kW * raw.C <= 24 else _r4(kW * raw.C)
         # C = live folded columns (kW * Cin = 21 for the RGB stem); the kernel drops the MFMAs that
         # would only multiply the zero pad columns [C, ld)
         y = self.act(raw.N, raw.T, raw.H, Wo, kW * raw.C, ld)
