@@ -204,123 +204,136 @@ __device__ __forceinline__ void fused_value(const ConvArgs& p, float acc, int m,
     out = v;
 }
 
-template <class MF, int NACC, int MT>
-__device__ __forceinline__ void store_half_pairs(const __amdgpu_buffer_rsrc_t rs, const float (&v)[NACC], int mrow, int co,
-                                                 int lane, unsigned ld_halfs, int M, int ncol) {
-    const bool odd = (lane & 1) != 0;
-    const int cbase = co - (odd ? 1 : 0);
-#pragma unroll
-    for (int r = 0; r < NACC; r += 2) {
-        const float send = odd ? v[r] : v[r + 1];
-        const float recv = __shfl_xor(send, 1, 64);
-        const half2_t pk = {(_Float16)(odd ? recv : v[r]), (_Float16)(odd ? v[r + 1] : recv)};
-        const int m = mrow + MF::row(odd ? r + 1 : r, lane);
-        const unsigned off = ((unsigned)m * ld_halfs + (unsigned)cbase) * 2u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs,
-                                              (cbase < ncol && m < M) ? off : 0x80000000u, 0, 0);
-    }
-}
+// The epilogue runs row-major through LDS: a wave parks one MT-row block of its accumulator tile (fp32, [MT][WTN + 4])
+// in its own slice of the (now idle) tile buffers, then every lane owns 8 consecutive channels of one output row:
+// the skip operand, the scale / shift rows and both outputs move as 16-byte accesses over whole 64..256-byte row
+// segments.  (Straight from the MFMA layout -- one column per lane -- the same work was 2-byte skip loads and
+// 4-byte stores: config-5's 1x1 convs, which are all epilogue, ran at 1.6-2.1 TB/s.)
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 template <class MF, int TM, int TN, int WTM, int WTN, int MT>
 __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename MF::acc_t (&acc)[TM][TN], int m0, int n0,
-                                                     int wm, int wn, int lane) {
+                                                     int wm, int wn, int lane, float* smem, int wave) {
     constexpr int NACC = MF::NACC;
     constexpr unsigned kOOB = 0x80000000u;
+    constexpr int LDT = WTN + 4;                 // staged row stride (floats): 16-byte aligned rows, rows 4 banks apart
+    constexpr int LPR = WTN / 8;                 // lanes per output row (8 channels each)
+    constexpr int RPP = 64 / LPR;                // rows per pass
+    constexpr int NP = (MT + RPP - 1) / RPP;
+    static_assert(WTN % 8 == 0 && 64 % LPR == 0, "wave tile width");
     const bool out16 = (p.flags & PTX_EPI_OUT_F16) != 0, dual = (p.flags & PTX_EPI_DUAL_RAW) != 0;
     const bool affine = (p.flags & PTX_EPI_AFFINE) != 0;
     const bool res_same = (p.flags & PTX_EPI_RES_ADD) != 0, res_gather = (p.flags & PTX_EPI_RES_PADA) != 0;
     const bool res_up = (p.flags & PTX_EPI_RES_UP) != 0, r16 = (p.flags & PTX_RES_F16) != 0;
-    const int res_lim = res_up ? p.Co : p.res_C;
-    const unsigned esz = r16 ? 2u : 4u;
+    const bool has_res = res_same || res_gather;
+    const int res_lim = res_gather ? (res_up ? p.Co : p.res_C) : p.ncol;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_raw =
         __builtin_amdgcn_make_buffer_rsrc(dual ? p.y_raw : (void*)p.y, 0, dual ? p.raw_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.res ? p.res : p.y), 0, (res_same || res_gather) ? p.r_bytes : 0u, 0x00020000);
+        const_cast<float*>(has_res ? p.res : p.y), 0, has_res ? p.r_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(affine ? p.aff_scale : p.y), 0, affine ? p.aff_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(affine ? p.aff_shift : p.y), 0, affine ? p.aff_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : p.y), 0, p.bias ? (unsigned)p.w_rows * 4u : 0u, 0x00020000);
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t rs, unsigned off) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    };
+    float* Ls = smem + wave * (MT * LDT);
+    const int cl = (lane % LPR) * 8;             // this lane's first column inside the wave tile (row-major phase)
+    const int co8 = n0 + wn * WTN + cl;          // ... its first output channel
+    const bool c_lo = co8 < p.ncol, c_hi = co8 + 4 < p.ncol;     // ncol is a multiple of 4: two 4-channel halves
+    const f32x4 b0 = ld4(rs_b, c_lo ? (unsigned)co8 * 4u : kOOB), b1 = ld4(rs_b, c_hi ? (unsigned)(co8 + 4) * 4u : kOOB);
+    __syncthreads();                             // every wave is done reading the operand tiles
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * WTN + j * MT + (lane % MT);
-        const bool co_ok = co < p.ncol;
-        const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int mrow = m0 + wm * WTM + i * MT;
+        // ---- park the row block: MFMA layout (lane = column) -> LDS ----
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mrow = m0 + wm * WTM + i * MT;
-            // Every load of the tile is issued before the first is consumed, branch-free: anything that must read as
-            // zero gets a byte offset >= num_records of its buffer resource (an exec-masked branch around each guarded
-            // load would serialise them -- DESIGN.md finding 2).
-            // The tile's rows usually belong to ONE sample: its scale / shift are then one load per column.
-            const int n_lo = (int)((unsigned)mrow / (unsigned)p.pps), n_hi = (int)((unsigned)min(mrow + MT - 1, p.M - 1) / (unsigned)p.pps);
-            const bool one = n_lo == n_hi;
-            float sc1 = 1.f, sh1 = 0.f;
-            if (affine && one) {
-                const unsigned off = ((unsigned)n_lo * (unsigned)p.ld_aff + (unsigned)co) * 4u;
-                sc1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, (co_ok && mrow < p.M) ? off : kOOB, 0, 0));
-                sh1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, (co_ok && mrow < p.M) ? off : kOOB, 0, 0));
-            }
-            float skip[NACC], scv[NACC], shv[NACC];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                const int m = mrow + MF::row(r, lane);
-                const bool ok = co_ok && m < p.M;
-                skip[r] = 0.f;
-                if (res_same || res_gather) {
-                    unsigned pos = (unsigned)m;
-                    bool rok = ok;
-                    if (res_gather) {
-                        const unsigned t = fastdiv((unsigned)m, p.dv_wo);
-                        const int wo = m - (int)t * p.Wo;
-                        const unsigned t2 = fastdiv(t, p.dv_ho);
-                        const int ho = (int)t - (int)t2 * p.Ho;
-                        const int n = (int)fastdiv(t2, p.dv_to);
-                        const int to = (int)t2 - n * p.To;
-                        const int rt = res_up ? to >> p.res_sT : to * p.res_sT, rh = res_up ? ho >> p.res_sH : ho * p.res_sH,
-                                  rw = res_up ? wo >> p.res_sW : wo * p.res_sW;
-                        pos = (unsigned)(((n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw);
-                        rok = ok && co < res_lim;
-                    }
-                    const unsigned off = rok ? (pos * (unsigned)p.ldr + (unsigned)co) * esz : kOOB;
-                    if (r16) {
-                        const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_res, off, 0, 0);
-                        skip[r] = (float)__builtin_bit_cast(_Float16, h);
-                    } else {
-                        skip[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
-                    }
+            for (int r = 0; r < NACC; ++r) Ls[MF::row(r, lane) * LDT + j * MT + (lane % MT)] = acc[i][j][r];
+        // the block's rows usually belong to ONE sample: its scale / shift are then loaded once per block
+        const int n_lo = (int)((unsigned)mrow / (unsigned)p.pps), n_hi = (int)((unsigned)min(mrow + MT - 1, p.M - 1) / (unsigned)p.pps);
+        const bool one = n_lo == n_hi;
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+        if (affine && one && mrow < p.M) {
+            const unsigned off = ((unsigned)n_lo * (unsigned)p.ld_aff + (unsigned)co8) * 4u;
+            sc0 = ld4(rs_sc, c_lo ? off : kOOB); sc1 = ld4(rs_sc, c_hi ? off + 16u : kOOB);
+            sh0 = ld4(rs_sh, c_lo ? off : kOOB); sh1 = ld4(rs_sh, c_hi ? off + 16u : kOOB);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int m = mrow + row;
+            const bool rok = row < MT && m < p.M;
+            const bool ok0 = rok && c_lo, ok1 = rok && c_hi;
+            // ---- skip operand: 8 channels of one (possibly upsampled-from) position ----
+            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+            if (has_res) {
+                unsigned pos = (unsigned)m;
+                if (res_gather) {
+                    const unsigned t = fastdiv((unsigned)m, p.dv_wo);
+                    const int wo = m - (int)t * p.Wo;
+                    const unsigned t2 = fastdiv(t, p.dv_ho);
+                    const int ho = (int)t - (int)t2 * p.Ho;
+                    const int n = (int)fastdiv(t2, p.dv_to);
+                    const int to = (int)t2 - n * p.To;
+                    const int rt = res_up ? to >> p.res_sT : to * p.res_sT, rh = res_up ? ho >> p.res_sH : ho * p.res_sH,
+                              rw = res_up ? wo >> p.res_sW : wo * p.res_sW;
+                    pos = (unsigned)(((n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw);
                 }
-                scv[r] = sc1;
-                shv[r] = sh1;
-                if (affine && !one) {
-                    const unsigned n = (unsigned)m / (unsigned)p.pps;
-                    const unsigned off = ok ? (n * (unsigned)p.ld_aff + (unsigned)co) * 4u : kOOB;
-                    scv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, off, 0, 0));
-                    shv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, off, 0, 0));
+                const unsigned e = pos * (unsigned)p.ldr + (unsigned)co8;
+                const bool q0 = ok0 && co8 < res_lim, q1 = ok1 && co8 + 4 < res_lim;
+                if (r16) {               // 8 halfs = one 16-byte load (channels beyond res_lim inside it are masked below)
+                    const half8_t h = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_res, q0 ? e * 2u : kOOB, 0, 0));
+                    k0 = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                    k1 = q1 ? f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    k0 = ld4(rs_res, q0 ? e * 4u : kOOB);
+                    k1 = ld4(rs_res, q1 ? e * 4u + 16u : kOOB);
                 }
             }
-            float raw[NACC], out[NACC];
+            f32x4 s0 = sc0, s1 = sc1, t0 = sh0, t1 = sh1;
+            if (affine && !one) {
+                const unsigned n = (unsigned)m / (unsigned)p.pps;
+                const unsigned off = (n * (unsigned)p.ld_aff + (unsigned)co8) * 4u;
+                s0 = ld4(rs_sc, ok0 ? off : kOOB); s1 = ld4(rs_sc, ok1 ? off + 16u : kOOB);
+                t0 = ld4(rs_sh, ok0 ? off : kOOB); t1 = ld4(rs_sh, ok1 ? off + 16u : kOOB);
+            }
+            const float* lrow = Ls + (row < MT ? row : 0) * LDT + cl;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(lrow) + b0 + k0;
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(lrow + 4) + b1 + k1;
+            const f32x4 r0 = v0, r1 = v1;
+            if (affine) { v0 = v0 * s0 + t0; v1 = v1 * s1 + t1; }
+            if (p.flags & PTX_EPI_RELU) {
 #pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                float v = acc[i][j][r] + bv + skip[r];
-                raw[r] = v;
-                if (affine) v = fmaf(v, scv[r], shv[r]);
-                if (p.flags & PTX_EPI_RELU) v = fmaxf(v, 0.f);
-                if (p.flags & PTX_EPI_TANH) v = tanhf(v);
-                out[r] = v;
+                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+            }
+            if (p.flags & PTX_EPI_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = tanhf(v0[e]); v1[e] = tanhf(v1[e]); }
             }
             if (out16) {
-                store_half_pairs<MF, NACC, MT>(rs_y, out, mrow, co, lane, (unsigned)p.ldy, p.M, p.ncol);
+                const half8_t h = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                                   (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                // ldy % 8 == 0 halfs and co8 % 8 == 0: the 16-byte store stays inside the row (pad columns get
+                // the affine of zero -- finite, and multiplied by zero filter columns downstream)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, h), rs_y,
+                                                       ok0 ? ((unsigned)m * (unsigned)p.ldy + (unsigned)co8) * 2u : kOOB, 0, 0);
             } else {
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    const int m = mrow + MF::row(r, lane);
-                    const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, out[r]), rs_y,
-                                                          (co_ok && m < p.M) ? off : kOOB, 0, 0);
-                }
+                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co8) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v0), rs_y, ok0 ? off : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v1), rs_y, ok1 ? off + 16u : kOOB, 0, 0);
             }
-            if (dual) store_half_pairs<MF, NACC, MT>(rs_raw, raw, mrow, co, lane, (unsigned)p.ld_raw, p.M, p.ncol);
+            if (dual) {
+                const half8_t h = {(_Float16)r0[0], (_Float16)r0[1], (_Float16)r0[2], (_Float16)r0[3],
+                                   (_Float16)r1[0], (_Float16)r1[1], (_Float16)r1[2], (_Float16)r1[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, h), rs_raw,
+                                                       ok0 ? ((unsigned)m * (unsigned)p.ld_raw + (unsigned)co8) * 2u : kOOB, 0, 0);
+            }
         }
     }
 }
@@ -838,7 +851,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 
     if constexpr (F16) {
         if (fused_epi) {          // generator stage: per-sample affine / halfs out / dual output / half skip / tanh
-            fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane);
+            fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane, smem, wave_u);
             return;
         }
     }
@@ -937,7 +950,10 @@ typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    // fp16 tiles: the fused epilogue parks one MT-row block per wave ([MT][BN / WN + 4] floats) in the tile buffers
+    constexpr size_t lds_tiles = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    constexpr size_t lds_epi = F16 ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0;
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
@@ -1495,11 +1511,14 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
             return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_OUT_F16 needs an even Co and ldy (halfs) %% 8 == 0");
     }
     if (d->flags & PTX_EPI_AFFINE) {
-        if (!ext->scale || !ext->shift || ext->ld_affine < d->Co)
-            return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_AFFINE needs scale / shift tables with ld_affine >= Co");
+        if (!ext->scale || !ext->shift || ext->ld_affine < d->Co || ext->ld_affine % 4 ||
+            (((uintptr_t)ext->scale | (uintptr_t)ext->shift) & 15))
+            return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_AFFINE needs 16-byte aligned scale / shift tables, ld_affine >= Co, %% 4 == 0");
         a.aff_scale = ext->scale; a.aff_shift = ext->shift; a.ld_aff = ext->ld_affine;
         a.aff_bytes = (unsigned)std::min<uint64_t>(((uint64_t)(d->N - 1) * ext->ld_affine + d->Co) * 4ull, 0x7fffffffull);
     }
+    if ((d->flags & PTX_RES_F16) && (d->ldr % 8 || ((uintptr_t)res & 15)))
+        return fail(PTX_ERR_INVALID, "conv3d: a half-precision skip operand needs ldr (halfs) %% 8 == 0");
     if (d->flags & PTX_EPI_DUAL_RAW) {
         const int nc = (d->Co + 3) / 4 * 4;
         if (!ext->y_raw || ext->ld_raw < nc || ext->ld_raw % 8 || d->Co % 2 || ((uintptr_t)ext->y_raw & 15))

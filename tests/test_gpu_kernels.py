@@ -940,7 +940,7 @@ def _fused_stage_case(ptx, N, H, W, Ci, Co, k, up2, affine, relu, tanh, out16, d
         res_t = rt.to(DEV)
         res_flags |= L.PTX_RES_F16 if r16 else 0
     raw_want = v
-    ld_aff = Co + 5
+    ld_aff = _r4(Co) + 4
     sc = torch.rand(N, ld_aff, generator=torch.Generator().manual_seed(305)) + 0.5
     sh = rnd(N, ld_aff, seed=306, scale=0.3)
     if affine:
