@@ -31,6 +31,8 @@ CLIPS_PER_GPU, FRAMES, SIZE, CLASSES = 8, 16, 224, 339
 GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, padding taps counted
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md HBM3E peak
+TRAFFIC_FILE = "r01_pmc_traffic.json"   # newest committed PMC traffic table (profiles/), replayed in roofline.traffic
 
 
 def other_workload(name, rank):
@@ -125,6 +127,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-x3", action="store_true", help="skip the secondary split-precision (x3) leg")
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5-fp32"])
     args = ap.parse_args()
 
@@ -204,13 +207,20 @@ def main():
     if rank == 0:
         # ---- per-kernel roofline: every conv launch timed with HIP events on the launch stream ----
         plan = list(eng._plans.values())[-1]
-        rows = eng.profile_convs(model, x, iters=5, plan=plan)
+        plan.bind(model)
+        with torch.cuda.device(dev):
+            all_rows = eng.profile_steps(plan, iters=5)         # EVERY launch of the plan, convs and HBM passes alike
+        rows = [(lab, macs, ms, cfg, stp.split) for (lab, kind, nb, macs, ms, cfg), stp in
+                zip([r for r in all_rows if r[1] == "conv"], plan.conv_steps)]
         if os.environ.get("PTX_BENCH_ROWS"):       # per-launch detail for tuning sessions
             with open(os.environ["PTX_BENCH_ROWS"], "w") as f:
                 for (label, macs, ms, cfg, split), stp in zip(rows, plan.conv_steps):
                     f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
                         label, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
                         stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, split, ms, 2e-9 * macs / ms))
+                for lab, kind, nb, macs, ms, _ in all_rows:
+                    if kind != "conv":
+                        f.write("%-34s %-5s bytes=%-12d macs=%-14d %8.4f ms %8.1f GB/s\n" % (lab, kind, nb, macs, ms, nb / ms / 1e6))
         by_kernel = {}
         for label, macs, ms, cfg, split in rows:
             k = by_kernel.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
@@ -220,14 +230,31 @@ def main():
         dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in by_kernel.values())
-        # HBM-side traffic of the dominant kernel: fabric bytes from the last rocprofv3 PMC passes of this
-        # command (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE are collected in separate
-        # passes; KiB per dispatch; FETCH_SIZE includes Infinity-Cache hits and, per the MI355X guide,
-        # may under-report wide streaming reads by up to 2x on gfx950 -- reported uncorrected)
-        traffic = None
+        # HBM-bound passes (fold, max-pool, cBN / affine passes ...): algorithmic bytes (compulsory reads + writes of one
+        # launch) / HIP-event time of that launch, against the 8 TB/s HBM3E peak
+        roofline_hbm, other_ms = {}, 0.0
+        for lab, kind, nb, macs, ms, _ in all_rows:
+            if kind == "mem":
+                h = roofline_hbm.setdefault(lab, dict(ms=0.0, bytes=0, launches=0))
+                h["ms"] += ms
+                h["bytes"] += nb
+                h["launches"] += 1
+            elif kind != "conv":
+                other_ms += ms
+        roofline_hbm = {k: {"bound": "hbm", "launches": v["launches"], "ms": round(v["ms"], 4),
+                            "algorithmic_MB": round(v["bytes"] / 1e6, 2),
+                            "achieved": round(v["bytes"] / v["ms"] / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(v["bytes"] / v["ms"] / 1e6 / PEAK_HBM_GBS, 4)} for k, v in roofline_hbm.items()}
+        # HBM-side traffic of the dominant kernel: NOT measured by this command (PMC passes need rocprofv3 around
+        # it).  The value replayed here comes from the committed PMC summary named in `traffic_source`, collected in
+        # separate --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; KiB per dispatch, UNCORRECTED
+        # (MI355X_MICROARCH.md: FETCH_SIZE may under-report wide streaming reads by up to 2x on gfx950, so the true
+        # figure lies in [traffic, traffic + fetch]); null when that file has no row for the dominant tile.
+        traffic, traffic_source = None, None
         try:
             import re
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            tpath = os.path.join("profiles", TRAFFIC_FILE)
+            tj = json.load(open(os.path.join(ROOT, tpath)))
             tile, waves, mt = dom_name.split("/")[:3]
             stage = dom_name.split("/")[3] if dom_name.count("/") >= 3 else ""
             want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
@@ -240,13 +267,16 @@ def main():
                 targs = [a.strip() for a in m.group(1).split(",")]
                 if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
                     traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+                    traffic_source = {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0,
+                                      "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0, "fetch_correction": "none applied "
+                                      "(guide: up to 2x under-report on streaming reads)", "measured_in_this_run": False}
                     break
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         roofline = {
             "bound": "mfma", "kernel": "conv_igemm_kernel<%s>" % dom_name,
             "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": round(achieved / peak_tf, 4), "traffic": traffic,
+            "frac": round(achieved / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_source,
             "launches_per_step": dom["launches"],
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
@@ -308,6 +338,68 @@ def main():
                       "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
                       "tolerance": tolerance}
 
+        # ---- secondary leg: the same workload with Engine.precision = "x3" (fp32 operands split into half pairs,
+        # three fp16 MFMAs per product block, fp32 accumulate -- fp32-ACCURATE).  Reported next to
+        # the headline with its own |d output| vs the CPU path and its own denominator (the fp16 dense MFMA peak / 3
+        # issued MFMAs per algorithmic product); the headline `value` above stays the plain fp32-MFMA path.
+        split = None
+        if world == 1 and not f16 and args.workload != "cfg5-fp32" and not args.no_x3:
+            eng.precision = "x3"
+            if not args.no_autotune:
+                if headline:
+                    eng.autotune(model, x, iters=2, verbose=args.verbose)
+                else:
+                    run()
+            for _ in range(args.warmup):
+                out3 = run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out3 = run()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t0
+            plan3 = list(eng._plans.values())[-1]
+            plan3.bind(model)
+            with torch.cuda.device(dev):
+                rows3 = eng.profile_steps(plan3, iters=5)
+            if os.environ.get("PTX_BENCH_ROWS"):
+                with open(os.environ["PTX_BENCH_ROWS"] + ".x3", "w") as f:
+                    for (lab, kind, nb, macs, ms, cfg), stp in zip([r for r in rows3 if r[1] == "conv"], plan3.conv_steps):
+                        f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
+                            lab, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
+                            stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, stp.split, ms, 2e-9 * macs / ms))
+            conv3 = [r for r in rows3 if r[1] == "conv"]
+            byk = {}
+            for lab, kind, nb, macs, ms, cfg in conv3:
+                k = byk.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
+                k["ms"] += ms
+                k["flop"] += 2.0 * macs
+                k["launches"] += 1
+            dn, dv = max(byk.items(), key=lambda kv: kv[1]["ms"])
+            rate3 = units_per_gpu * args.steps / el3
+            peak3 = PEAK_F16_MFMA_TF / 3.0
+            tf3 = gflop_per_unit * 1e9 * rate3 / 1e12
+            split = {"precision": "fp32 operands as half (hi, lo) pairs: a.b = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, "
+                                  "fp32 accumulate; activations / epilogues / outputs fp32",
+                     "value": round(rate3, 2), "unit": "%s/s" % unit, "ms_per_step": round(1e3 * el3 / args.steps, 4),
+                     "speedup_vs_fp32_mfma": round(rate3 / (clips_per_s / world), 3),
+                     "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<%s>" % dn,
+                                  "achieved": round(dv["flop"] / dv["ms"] / 1e9, 2), "peak": round(peak3, 1),
+                                  "unit": "TFLOP/s (algorithmic fp32-equivalent; peak = 2500 dense f16 / 3 MFMAs per product)",
+                                  "frac": round(dv["flop"] / dv["ms"] / 1e9 / peak3, 4), "launches_per_step": dv["launches"],
+                                  "avg_launch_ms": round(dv["ms"] / dv["launches"], 4)},
+                     "roofline_net": {"achieved": round(tf3, 2), "peak": round(peak3, 1), "frac": round(tf3 / peak3, 4),
+                                      "vs_fp32_mfma_peak": round(tf3 / PEAK_F32_MFMA_TF, 4),
+                                      "conv_ms_sum": round(sum(r[4] for r in conv3), 3),
+                                      "non_conv_ms": round(sum(r[4] for r in rows3 if r[1] != "conv"), 3)},
+                     "parity": None}
+            if parity is not None:
+                got3 = out3.cpu()[:want.shape[0]]
+                split["parity"] = {"max_abs_dlogits": float((got3 - want).abs().max().item()),
+                                   "argmax_equal": bool(torch.equal(got3.argmax(1), want.argmax(1))) if got3.dim() == 2 else None,
+                                   "tolerance": tolerance}
+            eng.precision = "fp32"
+
         result = {
             "metric": ("clips/sec, resnet3d50 forward 8x3x16x224x224 per GPU (+ max|dlogits| vs CPU)" if headline else
                        "%s/sec, %s (+ max|d output| vs CPU)" % (unit, args.workload)),
@@ -317,7 +409,9 @@ def main():
             "config": {"workload": workload_label,
                        "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
-            "roofline": roofline, "roofline_net": roofline_net, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
+            "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
+            "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
             "distributed_check": verify, "ranks_seen": ranks_seen,
         }
     if world > 1:

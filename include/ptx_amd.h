@@ -52,6 +52,16 @@ typedef void* ptx_stream_t; /* hipStream_t */
                                 ".../f16" tile configurations (BigGAN generator, BASELINE config 5)            */
 #define PTX_ACT_OUT_F16 0x100 /* ptx_affine_act_upsample: OR into `act` -- y is written as halfs (ldy in halfs,
                                 multiple of 8): the cBN -> ReLU -> upsample pass feeds an fp16-operand conv      */
+#define PTX_F16X3_OPERANDS 0x8000u /* ptx_conv3d_fwd / ptx_conv3d_dual_fwd: fp32-ACCURATE products on the fp16 matrix
+                                cores.  x stays fp32 (same layout as the default path); w_packed is packed with
+                                ptx_pack_desc.f16 == 2: every 8-channel block of a filter row is stored as 8 "hi" halfs then 8
+                                "lo" halfs (hi = half(w), lo = half(w - hi); the same 32 bytes).  The kernel splits the
+                                activations the same way in registers and issues a_hi.b_lo + a_lo.b_hi + a_hi.b_hi as three
+                                v_mfma_f32_32x32x16_f16 with fp32 accumulate: each half product is exact in fp32, the dropped
+                                a_lo.b_lo term is <= 2^-22 of the product, so results match the fp32 path to ~1e-6 relative
+                                (measured: same |dlogits| vs the CPU reference as fp32 MFMA) at 3 / 16 of its matrix-core
+                                time.  Needs Kc % 8 == 0, groups == 1 and operand magnitudes inside the half range (< 65504).
+                                Runs on the ".../x3" tile configurations.                                          */
 /* Fused generator stage (BigGAN-deep GBlock: cBN -> ReLU -> [nearest x2] -> conv, BASELINE config 5), on the
  * fp16-operand tiles through ptx_conv3d_fused_fwd.  The class-conditional BN that FOLLOWS a conv is applied in that
  * conv's epilogue as a per-sample affine (tables from ptx_cbn_fold), the upsampling that precedes a conv is done by
@@ -176,8 +186,10 @@ typedef struct ptx_pack_desc {
      * coalesced LDS-staged operands instead of per-lane 16-byte gathers.  co_per_super = output channels
      * of one super-group (rows [s*co_per_super, (s+1)*co_per_super) share the input columns of super-group s). */
     int32_t sub_groups, co_per_super;
-    /* != 0: w_packed is written as IEEE halfs (Kc counts halfs, multiple of 8; ptx_packed_weight_elems counts
-     * halfs) for PTX_F16_OPERANDS convs.  bias_out stays fp32. */
+    /* 1: w_packed is written as IEEE halfs (Kc counts halfs, multiple of 8; ptx_packed_weight_elems counts
+     * halfs) for PTX_F16_OPERANDS convs.  2: split halfs for PTX_F16X3_OPERANDS convs -- Kc, ld_k, k_off count
+     * channels as in the fp32 layout (multiples of 8) and the buffer has the fp32 layout's size, but every 8-channel
+     * block of a row holds 8 hi halfs then 8 lo halfs (hi = half(w), lo = half(w - hi)).  bias_out stays fp32. */
     int32_t f16;
 } ptx_pack_desc;
 

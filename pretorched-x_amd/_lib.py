@@ -19,6 +19,7 @@ PTX_PRO_RELU = 8
 PTX_EPI_ACCUM = 16
 PTX_EPI_RES_UP = 64
 PTX_F16_OPERANDS = 128
+PTX_F16X3_OPERANDS = 0x8000
 PTX_ACT_OUT_F16 = 0x100
 PTX_EPI_OUT_F16, PTX_EPI_AFFINE, PTX_EPI_DUAL_RAW, PTX_RES_F16, PTX_PRO_UP2, PTX_EPI_TANH = 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000
 

@@ -61,6 +61,7 @@ struct ConvArgs {
     unsigned x2_bytes;
     int groups, cig, cog;  // grouped conv: input / output channels per group
     int f16;               // A / B operands are halfs; K extents count 32-bit words
+    int x3;                // fp32 A split into half (hi, lo) pairs on the fly, B packed as (hi8 | lo8) blocks: 3 f16 MFMAs
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
     // fused generator stage (ptx_conv3d_fused_fwd, fp16-operand tiles): a per-sample affine after bias (+ skip) -- the
     // NEXT layer's class-conditional BN folded to scale/shift tables -- halfs out, a second pre-affine output, a
@@ -342,9 +343,21 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
 // pruning, K tails) works on 32-bit words and does not care; the descriptor then counts channel PAIRS.  Only
 // the fragment -> MFMA step differs: the 16-byte fragment a lane reads is 8 halfs, consumed by ONE
 // v_mfma_f32_32x32x16_f16 / 16x16x32_f16 instead of four fp32 MFMAs.  Accumulators, epilogue and output stay fp32.
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false>
+// X3 ("split" operands, PTX_F16X3_OPERANDS): fp32-accurate products on the fp16 matrix cores.  An fp32 value v is the
+// exact sum of two halfs up to 2^-22 |v|: hi = half(v), lo = half(v - hi).  a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
+// (+ a_lo.b_lo, <= 2^-22 |a.b|, dropped): every product of two halfs is exact in the fp32 accumulator, so the result
+// carries ~22 mantissa bits per product -- the same class as the fp32 fma chain -- at 3 x 32x32x16_f16 MFMAs per 16 k
+// (96 clk) instead of 8 x 32x32x2_f32 (512 clk).  The activations stay fp32 in HBM and in the LDS tile (so every other
+// kernel, the residual and the epilogue are untouched); a lane splits its 8-channel A fragment in registers (24 VALU
+// per 3 x TN MFMAs).  The filter is split once, at pack time (ptx_pack_desc.f16 == 2: each 8-channel block of a row is
+// stored as 8 hi halfs then 8 lo halfs -- the same 32 bytes), so B fragments are two 16-byte reads, no VALU.
+// Operand values must lie inside the half range (|v| < 65504); values below 2^-14 lose relative precision (their
+// lo part goes subnormal) but not absolute precision.
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
+          bool X3 = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
+    static_assert(!X3 || (DMA && !F16 && !K22 && NSTAGE == 2), "split operands: LDS-DMA tiles, 2 buffers");
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
     constexpr int NT = 64 * WM * WN;         // threads per workgroup (4 or 8 waves)
@@ -361,8 +374,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     constexpr int TM = WTM / MT, TN = WTN / MT;
     static_assert(TM * MT * WM == BM && TN * MT * WN == BN, "tile must split evenly");
     constexpr int KG = 64 / MT;              // lane groups along k
-    constexpr int KSUB = BK / (4 * KG);      // ds_read_b128 sub-steps per k-step
-    static_assert(KSUB * 4 * KG == BK, "BK must be a multiple of 4*KG");
+    constexpr int KPL = X3 ? 8 : 4;          // 32-bit words of K a lane consumes per sub-step
+    constexpr int KSUB = BK / (KPL * KG);    // sub-steps per k-step
+    static_assert(KSUB * KPL * KG == BK, "BK must be a multiple of KPL*KG");
     constexpr int F4R = BK / 4;              // float4 per tile row
     constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
     constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
@@ -676,7 +690,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // (k 0..15), the 3-MFMA sub-step 2 (k 16..21), nothing for k 24..31
     constexpr int KLIVE = (K22 && DMA) ? 3 : KSUB;
     constexpr int NSLOT = (KLIVE % 2) ? KLIVE : 2;
-    f32x4 fa[NSLOT][TM], fb[NSLOT][TN];
+    constexpr int NF = X3 ? 2 : 1;           // 16-byte reads per operand row per sub-step
+    f32x4 fa[NSLOT][TM][NF], fb[NSLOT][TN][NF];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto read_frags = [&](int buf, int ks, int slot, int offa, int offb) {
         if (K22 && ks == KLIVE - 1) {
@@ -691,13 +706,32 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int i = 0; i < TM; ++i) {
                 const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + lo_off);
                 const f32x2 hi = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + hi_off);
-                fa[slot][i] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                fa[slot][i][0] = f32x4{lo.x, lo.y, hi.x, hi.y};
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const f32x2 lo = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + lo_off);
                 const f32x2 hi = *reinterpret_cast<const f32x2*>(Bb + j * MT * LDK + hi_off);
-                fb[slot][j] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                fb[slot][j][0] = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+            return;
+        }
+        if constexpr (X3) {
+            // lane group g owns the 8 channels of block b = ks * KG + g: swizzled 16-byte slots 2b and 2b + 1
+            // (A: floats 8b..8b+3 | 8b+4..8b+7;  B: 8 hi halfs | 8 lo halfs)
+            const int b2 = (ks * KG + lane / MT) * 2;
+            const int k0 = ((b2 ^ frag_sw) * 4), k1 = (((b2 + 1) ^ frag_sw) * 4);
+            const float* Ab = As + buf * BM * LDK + offa;
+            const float* Bb = Bs + buf * BN * LDK + offb;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + k0);
+                fa[slot][i][NF - 1] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + k1);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + k0);
+                fb[slot][j][NF - 1] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK + k1);
             }
             return;
         }
@@ -705,16 +739,45 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const float* Ab = As + buf * BM * LDK + offa + koff;
         const float* Bb = Bs + buf * BN * LDK + offb + koff;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
+        for (int i = 0; i < TM; ++i) fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
+        for (int j = 0; j < TN; ++j) fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
     };
     auto mma_frags = [&](int slot, int nr) {
         if constexpr (F16) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(fa[slot][i], fb[slot][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(fa[slot][i][0], fb[slot][j][0], acc[i][j]);
+            return;
+        }
+        if constexpr (X3) {
+            // split the lane's 8 fp32 A values into (hi, lo) halfs: v_cvt_pk_f16_f32 (round to nearest even),
+            // lo = half(v - float(hi)) -- the difference is exact in fp32
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            f32x4 ahi[TM], alo[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 r0 = fa[slot][i][0], r1 = fa[slot][i][NF - 1];
+                const f32x8 v = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                const half8 h = __builtin_convertvector(v, half8);
+                const half8 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x8), half8);
+                ahi[i] = __builtin_bit_cast(f32x4, h);
+                alo[i] = __builtin_bit_cast(f32x4, l);
+            }
+            // term-major order: consecutive MFMAs write different accumulators
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(ahi[i], fb[slot][j][NF - 1], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(alo[i], fb[slot][j][0], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(ahi[i], fb[slot][j][0], acc[i][j]);
             return;
         }
 #pragma unroll
@@ -723,7 +786,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[slot][i][r], fb[slot][j][r], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(fa[slot][i][0][r], fb[slot][j][0][r], acc[i][j]);
             }
         }
     };
@@ -948,13 +1011,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
+          bool X3 = false>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     // fp16 tiles: the fused epilogue parks one MT-row block per wave ([MT][BN / WN + 4] floats) in the tile buffers
     constexpr size_t lds_tiles = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
     constexpr size_t lds_epi = F16 ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0;
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -968,8 +1032,13 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE, bool F16 = false>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE, bool F16 = false, bool X3 = false>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr (X3) {
+        if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
+            return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, 2, false, true>(a, grid, st);
+        return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, 2, false, true>(a, grid, st);
+    }
     if constexpr (F16) {
         if ((a.kA % BK) || (a.kB % BK))
             return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE, true>(a, grid, st);
@@ -1137,22 +1206,26 @@ struct ConvConfig {
     launch_fn launch;
     bool direct;      // VALU kernel: no split-K, own grid
     bool f16;         // fp16 operands (PTX_F16_OPERANDS)
+    bool x3;          // split fp32 operands on the fp16 matrix cores (PTX_F16X3_OPERANDS)
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false, false, false }
 #define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false, false, false }
 #define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false, false, false }
 #define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false, false }
 
 #define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
-    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false }
+    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false, false }
 #define PTX_CFG_F16(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/f16", \
-      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, true>, false, true }
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, true>, false, true, false }
+#define PTX_CFG_X3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/x3", \
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, false, true>, false, false, true }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -1254,6 +1327,21 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_F16(128, 64, 32, 2, 2, 32),   // 85
     PTX_CFG_F16(256, 16, 32, 8, 1, 16),   // 86 the 3-channel image conv: 16-wide N on 16x16x32 MFMA
     PTX_CFG_F16(128, 16, 32, 4, 1, 16),   // 87
+    // split fp32 operands (x3): 3 f16 MFMAs per 16 k; BK 32 / 64 on 32x32x16, BK 64 on 16x16x32
+    PTX_CFG_X3(128, 128, 32, 4, 2, 32),   // 88
+    PTX_CFG_X3(128, 64, 32, 4, 2, 32),    // 89
+    PTX_CFG_X3(256, 64, 32, 8, 1, 32),    // 90 stem (folded rows of 32 floats)
+    PTX_CFG_X3(64, 64, 32, 2, 2, 32),     // 91
+    PTX_CFG_X3(64, 128, 32, 2, 2, 32),    // 92
+    PTX_CFG_X3(64, 64, 64, 2, 2, 32),     // 93
+    PTX_CFG_X3(32, 64, 64, 2, 2, 16),     // 94 small M
+    PTX_CFG_X3(32, 128, 64, 2, 2, 16),    // 95 small M, wide
+    PTX_CFG_X3(128, 128, 32, 2, 2, 32),   // 96 64x64 per wave: 8 fragment reads feed 12 MFMAs
+    PTX_CFG_X3(256, 128, 32, 4, 2, 32),   // 97
+    PTX_CFG_X3(128, 64, 32, 2, 2, 32),    // 98
+    PTX_CFG_X3(64, 32, 64, 2, 2, 16),     // 99
+    PTX_CFG_X3(256, 64, 32, 4, 1, 32),    // 100 stem, 64x64 per wave
+    PTX_CFG_X3(128, 64, 64, 4, 2, 32),    // 101
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1301,6 +1389,12 @@ static int validate_desc(const ptx_conv3d_desc* d) {
             return fail(PTX_ERR_INVALID, "conv3d: PTX_PRO_UP2 needs a unit-stride 2-D conv over even (upsampled) extents");
     }
     if ((d->flags & PTX_EPI_RELU) && (d->flags & PTX_EPI_TANH)) return fail(PTX_ERR_INVALID, "conv3d: RELU and TANH are exclusive");
+    if (d->flags & PTX_F16X3_OPERANDS) {
+        if (d->flags & PTX_F16_OPERANDS) return fail(PTX_ERR_INVALID, "conv3d: PTX_F16_OPERANDS and PTX_F16X3_OPERANDS are exclusive");
+        if (d->Kc % 8 || d->groups > 1)
+            return fail(PTX_ERR_INVALID, "conv3d: split operands (PTX_F16X3_OPERANDS) need a dense conv whose filter rows hold "
+                        "whole 8-channel (hi8 | lo8) blocks (Kc %% 8 == 0, got %d)", d->Kc);
+    }
     return PTX_OK;
 }
 
@@ -1331,6 +1425,23 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     if (d->flags & PTX_F16_OPERANDS) {
         const int64_t Mrows = (int64_t)d->N * d->To * d->Ho * d->Wo;
         return ncol <= 16 ? 86 : ncol <= 32 ? 81 : (Mrows < 8192 ? 80 : (ncol >= 128 ? 74 : 75));
+    }
+    if (d->flags & PTX_F16X3_OPERANDS) {           // split operands: defaults; the tuner refines them
+        if (M < 8192) cfg = ncol >= 128 ? 95 : 94;
+        else if (ncol >= 128 && cdiv64(M, 128) * cdiv(ncol, 128) >= 2 * kNumCU) cfg = 96;
+        else if (M >= 256 * 1024 && ncol <= 64) cfg = 100;
+        else cfg = ncol >= 128 ? 92 : 91;
+        const ConvConfig& c = kConfigs[cfg];
+        const int64_t blocks = cdiv64(M, c.BM) * cdiv(ncol, c.BN);
+        const int steps = taps * cdiv(d->Kc, c.BK);
+        int sk = 1;
+        if (blocks < 2 * kNumCU) {
+            sk = (int)((3 * kNumCU + blocks - 1) / blocks);
+            if (sk > 8) sk = 8;
+            while (sk > 1 && steps / sk < 8) --sk;
+        }
+        if (split_k) *split_k = sk;
+        return cfg;
     }
     if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
         const int cog = d->Co / d->groups;
@@ -1372,6 +1483,8 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     const ConvConfig& c = kConfigs[config];
     if ((a.f16 != 0) != c.f16)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16-operand problems run on the /f16 tile configurations only (and vice versa)");
+    if ((a.x3 != 0) != c.x3)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: split-operand problems run on the /x3 tile configurations only (and vice versa)");
     if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
     a.m_tiles = cdiv(a.M, c.BM);
@@ -1498,6 +1611,7 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
         a.w_bytes = (unsigned)wb;
     }
     a.f16 = (d->flags & PTX_F16_OPERANDS) ? 1 : 0;
+    a.x3 = (d->flags & PTX_F16X3_OPERANDS) ? 1 : 0;
     if (a.f16 && (x2 || d->groups > 1)) return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16 operands: single-source dense convs only");
     a.up2 = (d->flags & PTX_PRO_UP2) ? 1 : 0;
     a.Hp = a.up2 ? d->Hi / 2 : d->Hi;
@@ -1546,7 +1660,7 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
             return fail(PTX_ERR_INVALID, "conv3d_dual: second-source geometry out of range");
         if ((uintptr_t)x2 & 15) return fail(PTX_ERR_INVALID, "conv3d_dual: x2 must be 16-byte aligned");
         const uint64_t xb2 = (uint64_t)d->N * d->x2_T * d->x2_H * d->x2_W * d->x2_ld * 4ull;
-        const int kc2 = (d->x2_C + 3) / 4 * 4;
+        const int kc2 = (d->flags & PTX_F16X3_OPERANDS) ? (d->x2_C + 7) / 8 * 8 : (d->x2_C + 3) / 4 * 4;
         if (xb2 >= 0x80000000ull) return fail(PTX_ERR_UNSUPPORTED, "conv3d_dual: x2 must be < 2 GiB");
         a.dual = 1; a.x2 = x2; a.x2_bytes = (unsigned)xb2;
         a.ldx2 = d->x2_ld; a.kA2 = d->x2_ld; a.wcol2 = d->Kc;

@@ -58,7 +58,15 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const
         }
         const size_t ld = d.ld_k > 0 ? (size_t)d.ld_k : (size_t)d.Kc;
         const size_t dst = ((size_t)tap * d.Co_pad + co) * ld + d.k_off + k;
-        if (d.f16) reinterpret_cast<_Float16*>(out)[dst] = (_Float16)v;     // round-to-nearest-even
+        if (d.f16 == 2) {
+            // split operands (PTX_F16X3_OPERANDS): the 8-channel block of column k holds 8 hi halfs then 8 lo halfs
+            const size_t row_h = (((size_t)tap * d.Co_pad + co) * ld + d.k_off) * 2;      // row start, in halfs
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            _Float16* o = reinterpret_cast<_Float16*>(out) + row_h + (size_t)(k >> 3) * 16 + (k & 7);
+            o[0] = hi;
+            o[8] = lo;
+        } else if (d.f16) reinterpret_cast<_Float16*>(out)[dst] = (_Float16)v;     // round-to-nearest-even
         else out[dst] = v;
     }
 }
@@ -317,8 +325,11 @@ extern "C" int ptx_pack_conv_weight(const ptx_pack_desc* d, const float* w, cons
                               d->co_per_super % d->sub_groups || d->Co % d->co_per_super))
         return fail(PTX_ERR_INVALID, "pack: super-group packing needs sub_groups | Ci, sub_groups | co_per_super | Co, no kW fold");
     const int keff = d->fold_kw ? d->kW * d->Ci : d->Ci;
-    if (d->f16 && (d->Kc % 8 || d->ld_k || d->k_off))
+    if (d->f16 == 1 && (d->Kc % 8 || d->ld_k || d->k_off))
         return fail(PTX_ERR_INVALID, "pack: fp16 filters need Kc %% 8 == 0 and no K-concatenation window");
+    if (d->f16 == 2 && (d->Kc % 8 || d->ld_k % 8 || d->k_off % 8 || d->sub_groups > 1))
+        return fail(PTX_ERR_INVALID, "pack: split (hi8 | lo8) filters need Kc, ld_k and k_off %% 8 == 0, no super-groups");
+    if (d->f16 < 0 || d->f16 > 2) return fail(PTX_ERR_INVALID, "pack: f16 must be 0 (fp32), 1 (halfs) or 2 (split halfs)");
     if (d->Kc < keff || d->Kc % 4 || d->Co_pad < d->Co || d->Co_pad % 128)
         return fail(PTX_ERR_INVALID, "pack: Kc=%d must cover K=%d (multiple of 4); Co_pad=%d must cover Co=%d (multiple of 128)",
                     d->Kc, keff, d->Co_pad, d->Co);

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
-                   PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
+                   PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_F16X3_OPERANDS, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None                    # conv problem key -> (tile configuration NAME, split-K)
@@ -57,11 +57,21 @@ def _tuned_table():
         return _tuned
 
 
-def tuned_lookup(key, f16=False):
+def _tile_kind(name):
+    """Operand flavour of a tile configuration by name: "f16" (halfs), "x3" (split fp32 on f16 MFMA) or "" (fp32)."""
+    return "f16" if name.endswith("/f16") else "x3" if name.endswith("/x3") else ""
+
+
+def _flags_kind(flags):
+    return "f16" if flags & PTX_F16_OPERANDS else "x3" if flags & PTX_F16X3_OPERANDS else ""
+
+
+def tuned_lookup(key, kind=""):
     """(config index, split-K) of a tuned conv problem, or None: unknown keys, tiles this build does not
-    have and entries of the wrong operand precision all fall back to ptx_conv3d_pick_config."""
+    have and entries of the wrong operand flavour all fall back to ptx_conv3d_pick_config."""
+    kind = "f16" if kind is True else "" if kind is False else kind
     ent = _tuned_table().get(key)
-    if ent is None or ent[0].endswith("/f16") != bool(f16):
+    if ent is None or _tile_kind(ent[0]) != kind:
         return None
     idx = _config_index(ent[0])
     return None if idx is None else (idx, ent[1])
@@ -102,6 +112,10 @@ def _stem_ld():
     """Row length (floats) of the kW-folded stem operand: 24 = 96-byte rows for the register-staged BK = 24 tiles,
     32 = 128-byte rows, which the conflict-free LDS-DMA K22 tile can stage (the fold writes 33 % more)."""
     return 32 if os.environ.get("PTX_STEM_LD", "24") == "32" else 24
+
+
+def _r8(v):
+    return (v + 7) // 8 * 8
 
 
 def _r128(v):
@@ -196,6 +210,7 @@ class Packed:
         dev = plan.dev
         self.plan = plan
         self.f16 = bool(f16)         # filter stored as halfs for an fp16-operand conv
+        # split operands (Engine.precision == "x3"): every dense fp32 filter is packed as (hi8 | lo8) half blocks
         convs = list(convs)          # >1: concatenated along Co (non-local g/theta/phi)
         self.convs = [plan.ref(c) for c in convs]
         self.bn = plan.ref(bn) if bn is not None else None
@@ -219,16 +234,17 @@ class Packed:
             self.groups //= self.sub_groups
             self.Ci = SUPER
         self.fold_kw = bool(fold_kw)
+        self.x3 = bool(getattr(plan, "x3", False)) and not self.f16 and self.groups == 1
         keff = kW * self.Ci if fold_kw else self.Ci
-        self.Kc = (keff + 7) // 8 * 8 if self.f16 else _r4(keff)
+        self.Kc = (keff + 7) // 8 * 8 if (self.f16 or self.x3) else _r4(keff)
         if self.f16 and (fold_kw or self.groups > 1 or self.Ci % 2):
             raise PtxError("fp16 filters: dense, unfolded convs with an even channel count only")
         if fold_kw:
-            self.Kc = max(self.Kc, _stem_ld()) if keff <= 24 else self.Kc
+            self.Kc = max(self.Kc, 32 if self.x3 else _stem_ld()) if keff <= 24 else self.Kc
         self.Co_pad = _r128(self.Co)
         self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
         self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw), 0, 0, 0,
-                          self.sub_groups, self.Ci if self.sub_groups else 0, int(self.f16))
+                          self.sub_groups, self.Ci if self.sub_groups else 0, 2 if self.x3 else int(self.f16))
         n = _lib.lib().ptx_packed_weight_elems(C.byref(self.d))
         self.w = torch.empty(n, device=dev, dtype=torch.float16 if self.f16 else torch.float32)
         self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
@@ -277,12 +293,15 @@ class PackedDual:
         self.parts = [(plan.ref(conv), plan.ref(bn)), (plan.ref(conv2), plan.ref(bn2))]
         self.Co, self.Ci, self.Ci2 = conv.out_channels, conv.in_channels, conv2.in_channels
         assert conv2.out_channels == self.Co
-        self.Kc, self.Kc2 = _r4(self.Ci), _r4(self.Ci2)
+        self.x3 = bool(getattr(plan, "x3", False))
+        rk = _r8 if self.x3 else _r4
+        self.Kc, self.Kc2 = rk(self.Ci), rk(self.Ci2)
         self.Co_pad = _r128(self.Co)
         self.k_eff = (1, 1, 1)
         ld = self.Kc + self.Kc2
-        self.descs = [PackDesc(self.Co, self.Ci, 1, 1, 1, self.Kc, self.Co_pad, 0, ld, 0, 0),
-                      PackDesc(self.Co, self.Ci2, 1, 1, 1, self.Kc2, self.Co_pad, 0, ld, self.Kc, 1)]
+        sp = 2 if self.x3 else 0
+        self.descs = [PackDesc(self.Co, self.Ci, 1, 1, 1, self.Kc, self.Co_pad, 0, ld, 0, 0, 0, 0, sp),
+                      PackDesc(self.Co, self.Ci2, 1, 1, 1, self.Kc2, self.Co_pad, 0, ld, self.Kc, 1, 0, 0, sp)]
         self.d = self.descs[0]
         self.w = torch.zeros(self.Co_pad * ld, device=dev, dtype=torch.float32)
         self.b = torch.empty(self.Co_pad, device=dev, dtype=torch.float32)
@@ -343,6 +362,7 @@ class Plan:
         self.tuned = False
         self.graph = None
         self.fuse_shortcut = os.environ.get("PTX_FUSE_SHORTCUT", "1") != "0"
+        self.x3 = getattr(engine, "precision", "fp32") == "x3"     # split fp32 operands on the fp16 matrix cores
         # qualified names of the model's modules: everything the plan keeps from the model is a _Ref
         self._names = {id(m): n for n, m in model.named_modules()}
         self._cur = model                # the model (or DataParallel replica) whose tensors are valid right now
@@ -431,6 +451,8 @@ class Plan:
                 raise PtxError("%s: fp16 operands need an even channel count and 16-byte rows" % label)
             flags |= PTX_F16_OPERANDS
             d.Ci, d.ldx = x.C // 2, x.ld // 2
+        if getattr(pk, "x3", False):
+            flags |= PTX_F16X3_OPERANDS
         fused = bool(up2 or affine is not None or out_f16 or raw or tanh or (res is not None and getattr(res, "f16", False)))
         if fused and not half:
             raise PtxError("%s: the fused generator-stage options need fp16 operands" % label)
@@ -484,7 +506,7 @@ class Plan:
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
-        tuned = tuned_lookup(key, half)
+        tuned = tuned_lookup(key, _flags_kind(flags))
         if tuned is not None:
             st.cfg, st.split = tuned
         else:
@@ -531,7 +553,7 @@ class Plan:
             pW, Wo = same_pad, -(-raw.W // sW)
         else:
             Wo = (raw.W + 2 * pW - kW) // sW + 1
-        ld = max(_r4(kW * raw.C), _stem_ld()) if kW * raw.C <= 24 else _r4(kW * raw.C)
+        ld = max(_r4(kW * raw.C), 32 if self.x3 else _stem_ld()) if kW * raw.C <= 24 else (_r8 if self.x3 else _r4)(kW * raw.C)
         # C = live folded columns (kW * Cin = 21 for the RGB stem); the kernel drops the MFMAs that
         # would only multiply the zero pad columns [C, ld)
         y = self.act(raw.N, raw.T, raw.H, Wo, kW * raw.C, ld)
@@ -552,7 +574,8 @@ class Plan:
             def step(st, self=self):
                 check(lib.ptx_fold_kw_strided(self.in_ptr, yp, N, C_, T, H, W, sn, sc, stt, kW, sW, pW, Wo, ld, st),
                       "ptx_fold_kw_strided")
-        self.steps.append(step)
+        in_bytes = N * C_ * T * H * W * (1 if raw.norm is not None else 4)
+        self.steps.append(_tag(step, "fold_kw", in_bytes + 4 * y.t.numel()))
         return y
 
     def to_channels_last(self, raw):
@@ -562,7 +585,7 @@ class Plan:
 
         def step(st, self=self):
             check(lib.ptx_ncdhw_to_ndhwc(self.in_ptr, yp, N, C_, S, ld, st), "ptx_ncdhw_to_ndhwc")
-        self.steps.append(step)
+        self.steps.append(_tag(step, "ncdhw_to_ndhwc", 4 * N * C_ * S + 4 * y.t.numel()))
         return y
 
     def maxpool(self, x, k, s, p=None, y=None, same=False):
@@ -585,7 +608,8 @@ class Plan:
 
         def step(st):
             check(lib.ptx_maxpool3d_fwd(C.byref(d), xp, yp, st), "ptx_maxpool3d_fwd")
-        self.steps.append(step)
+        esz = 2 if getattr(x, "f16", False) else 4
+        self.steps.append(_tag(step, "maxpool3d", esz * (x.N * x.S * x.C + y.N * To * Ho * Wo * x.C)))
         return y
 
     def attention(self, th, ph, g, y, scale_only=False):
@@ -606,7 +630,8 @@ class Plan:
 
         def step(st):
             check(lib.ptx_nonlocal_fwd(C.byref(d), tp, pp, gp, yp, st), "ptx_nonlocal_fwd")
-        self.steps.append(step)
+        self.steps.append(_tag(step, "nonlocal_attention", 4 * th.N * (th.S * th.C + ph.S * ph.C + g.S * g.C + th.S * g.C),
+                               macs=th.N * th.S * ph.S * (th.C + g.C)))
         self.attn_steps = getattr(self, "attn_steps", 0) + 1
         return True
 
@@ -669,7 +694,7 @@ class Plan:
                 check(lib.ptx_softmax_rows(fp, N * Sq, Sk, ldf, scale_only, st), "softmax")
             check(lib.ptx_transpose_last2(gp, gtp, N, Sk, ci, ldg, ldf, st), "transpose g")
             check(lib.ptx_bgemm_nt(fp, gtp, yp, N, Sq, ci, Sk, ldf, ldf, yld, Sq * ldf, ci * ldf, Sq * yld, st), "bgemm y")
-        self.steps.append(step)
+        self.steps.append(_tag(step, "nonlocal_unfused", macs=N * Sq * Sk * (K + ci)))
         if getattr(nl, "bn_layer", True):
             return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
         return self.conv(yatt, self.pack(nl.W, None), one, zero, res=x, label=label + ".W")
@@ -767,7 +792,7 @@ class Plan:
         def step(st):
             # [N*T*H, W] rows: the kernel's (n, h, w) decomposition only matters for upsampling
             check(lib.ptx_affine_act_upsample(xp, yp, scp, shp, 0, 1, rows, x.W, C_, ldx, ldy, 1, 1, st), label)
-        self.steps.append(step)
+        self.steps.append(_tag(step, "affine_act", 8 * x.N * x.S * x.C))
         return y
 
     def _block_preact(self, arch, blk, x, name):
@@ -841,6 +866,13 @@ class Plan:
         return self.feat
 
 
+def _tag(step, label, nbytes=0, macs=0):
+    """Measurement metadata of a non-conv plan step: the ALGORITHMIC HBM bytes (compulsory reads + writes) or MACs of
+    one launch -- what Engine.profile_steps / bench.py's `roofline_hbm` divide the HIP-event time into."""
+    step.label, step.hbm_bytes, step.macs = label, int(nbytes), int(macs)
+    return step
+
+
 class RawInput:
     """Shape of the user's NCDHW (or NCHW, T == 1) input; its pointer is bound at run time."""
     __slots__ = ("N", "C", "T", "H", "W", "t_step", "T_full", "norm")
@@ -910,6 +942,26 @@ class Engine:
         # (shape, device) and replayed -- one host call instead of ~90 launches.  Pays off for
         # launch-bound shapes (small clips / batch 1); neutral at config-2 size.
         self.use_graph = os.environ.get("PTX_GRAPH", "0") == "1"
+        # Arithmetic of the dense convolutions:
+        #   "fp32"  (default) fp32 operands on v_mfma_f32_32x32x2_f32 -- the reference's own arithmetic;
+        #   "x3"    fp32-accurate split operands on the fp16 matrix cores (PTX_F16X3_OPERANDS: a = hi + lo halfs,
+        #           a.b = hi.hi + hi.lo + lo.hi, fp32 accumulate): same |dlogits| vs the CPU reference as "fp32"
+        #           (1e-5 class), 3 / 16 of its matrix-core time.  Activations, epilogues and every other kernel stay
+        #           fp32.  Operand magnitudes must stay inside the half range (|v| < 65504).
+        # Changing it drops the compiled plans (set it before the first forward, or call invalidate()).
+        self._precision = os.environ.get("PTX_PRECISION", "fp32")
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("fp32", "x3"):
+            raise PtxError("Engine.precision must be 'fp32' or 'x3' (got %r)" % (value,))
+        if value != self._precision:
+            self._precision = value
+            self.invalidate()
 
     def __deepcopy__(self, memo):
         return Engine()
@@ -1103,7 +1155,7 @@ class Engine:
         with plan.exclusive():
             if plan.tuned:
                 return
-            if any(tuned_lookup(json.dumps(s.d.key()), bool(s.d.flags & PTX_F16_OPERANDS)) is None
+            if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
                    for s in plan.conv_steps):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
@@ -1252,7 +1304,8 @@ class Engine:
                 if key in seen:
                     stp.cfg, stp.split = seen[key]
                     continue
-                if only_untuned and tuned_lookup(key, bool(stp.d.flags & PTX_F16_OPERANDS)) is not None:
+                kind = _flags_kind(stp.d.flags)
+                if only_untuned and tuned_lookup(key, kind) is not None:
                     continue
                 best = None
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
@@ -1260,15 +1313,15 @@ class Engine:
                 ncol = _r4(stp.d.Co)                          # columns written (ldy is only the row stride)
                 for cfg in range(ncfg):
                     name = lib.ptx_conv3d_config_name(cfg).decode()
-                    if name.endswith("/f16") != bool(stp.d.flags & PTX_F16_OPERANDS):
-                        continue                         # fp16-operand problems <-> fp16 tiles
+                    if _tile_kind(name) != kind:
+                        continue                         # fp16-operand / split-operand problems <-> their own tiles
                     bm, bn_, bk = [int(v) for v in name.split("/")[0].split("x")]
                     narrow = bn_ <= 32 and bk == 32 and bm >= 128 and not name.endswith("/dma")   # Mx16 / Mx32 tiles
                     if (bk == 24) != (stp.d.Kc == 24) and not (stp.d.Kc == 24 and narrow):
                         continue                         # BK = 24 tiles are for the kW-folded stem only
                     if narrow and ncol > 32 and stp.d.groups <= 1:
                         continue
-                    if bk == 64 and stp.d.Kc % 64:            # BK = 64 tiles: long, 64-aligned K only
+                    if bk == 64 and stp.d.Kc % 64 and kind != "x3":     # BK = 64 tiles: long, 64-aligned K only
                         continue
                     if name.endswith("/direct") and ncol > 32 and stp.d.groups <= 1:   # VALU kernels: narrow outputs
                         continue
@@ -1346,6 +1399,30 @@ class Engine:
                 e1.synchronize()
                 rows.append((stp.label, stp.macs, e0.elapsed_time(e1) / iters,
                              _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp.split))
+        return rows
+
+
+    def profile_steps(self, plan, iters=5):
+        """HIP-event time of EVERY launch of a compiled (and run) plan on the current stream, convs and HBM-bound
+        passes alike: rows of (label, kind, algorithmic bytes, MACs, ms, tile / kernel name).  kind is "conv" for the
+        implicit-GEMM launches, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
+        rows = []
+        st = _stream()
+        for stp in plan.steps:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            stp(st)
+            e0.record()
+            for _ in range(iters):
+                stp(st)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            if isinstance(stp, ConvStep):
+                rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode()))
+            else:
+                nb, macs = getattr(stp, "hbm_bytes", 0), getattr(stp, "macs", 0)
+                kind = "mem" if nb and not macs else "mfma" if macs else "other"
+                rows.append((getattr(stp, "label", getattr(stp, "__name__", "step")), kind, nb, macs, ms, ""))
         return rows
 
 

@@ -252,7 +252,8 @@ def build_biggan(self, model):
         def step(st):
             check(lib.ptx_affine_act_upsample(xp, yp, sc, sh, ld_s, N, H_, W_, C_, ldx, ldy, up, act, st),
                   "ptx_affine_act_upsample")
-        self.steps.append(step)
+        from .engine import _tag
+        self.steps.append(_tag(step, "affine_act_upsample", 4 * N * H_ * W_ * C_ + (2 if f16_out else 4) * N * H_ * W_ * C_ * up * up))
         return y
 
     def cbn(x, bn, up=1):

@@ -42,15 +42,17 @@ def from_cl(y, c):
 
 
 def hip_conv(ptx, x, w, stride, padding, bias=None, bn=None, relu=False, res=None, res_pad=None, res_stride=1,
-             cfg=-1, split=0, pro_relu=False):
-    """x NCDHW cpu, w [Co,Ci,kT,kH,kW] cpu.  Returns NCDHW cpu output of ptx_conv3d_fwd."""
+             cfg=-1, split=0, pro_relu=False, x3=False):
+    """x NCDHW cpu, w [Co,Ci,kT,kH,kW] cpu.  Returns NCDHW cpu output of ptx_conv3d_fwd.
+    x3: split operands (PTX_F16X3_OPERANDS) -- the filter packed as (hi8 | lo8) half blocks."""
     L, lib = ptx._lib, _lib(ptx)
     Co, Ci, kT, kH, kW = w.shape
     N, _, T, H, W = x.shape
     sT, sH, sW = stride
     pT, pH, pW = padding
     To, Ho, Wo = (T + 2 * pT - kT) // sT + 1, (H + 2 * pH - kH) // sH + 1, (W + 2 * pW - kW) // sW + 1
-    pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, (Ci + 7) // 8 * 8 if x3 else _r4(Ci), (Co + 127) // 128 * 128, 0)
+    pd.f16 = 2 if x3 else 0
     wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
     bp = torch.empty(pd.Co_pad, device=DEV)
     wd = w.contiguous().to(DEV)
@@ -72,7 +74,7 @@ def hip_conv(ptx, x, w, stride, padding, bias=None, bn=None, relu=False, res=Non
     d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, ldy
     d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
     d.Kc, d.Co_pad = pd.Kc, pd.Co_pad
-    flags = (L.PTX_EPI_RELU if relu else 0) | (L.PTX_PRO_RELU if pro_relu else 0)
+    flags = (L.PTX_EPI_RELU if relu else 0) | (L.PTX_PRO_RELU if pro_relu else 0) | (L.PTX_F16X3_OPERANDS if x3 else 0)
     rd = None
     if res is not None:
         rd = to_cl(res)
@@ -152,8 +154,13 @@ def test_conv_geometries_auto_config(ptx, g):
 
 
 def fp32_configs(lib):
-    """Tile configurations that take fp32 operands (the '/f16' ones have their own test)."""
-    return [i for i in range(lib.ptx_conv3d_num_configs()) if not lib.ptx_conv3d_config_name(i).decode().endswith("/f16")]
+    """Tile configurations that take fp32 operands (the '/f16' and '/x3' ones have their own tests)."""
+    return [i for i in range(lib.ptx_conv3d_num_configs())
+            if not lib.ptx_conv3d_config_name(i).decode().endswith(("/f16", "/x3"))]
+
+
+def x3_configs(lib):
+    return [i for i in range(lib.ptx_conv3d_num_configs()) if lib.ptx_conv3d_config_name(i).decode().endswith("/x3")]
 
 
 def test_conv_every_config_and_split(ptx):
@@ -1010,3 +1017,121 @@ def test_conv_fused_generator_stage(ptx):
     # image conv: 3 channels, tanh, fp32 out, 16-wide N tiles
     narrow = [(c, 1) for c in f16 if int(names[c].split("x")[1]) <= 32]
     _fused_stage_case(ptx, 2, 9, 9, 64, 3, 3, False, False, False, True, False, False, None, [(-1, 0)] + narrow)
+
+
+def test_conv_x3_split_operands(ptx):
+    """PTX_F16X3_OPERANDS: fp32 operands split into (hi, lo) halfs, three fp16 MFMAs, fp32 accumulate -- must agree
+    with the fp32 reference to fp32-class accuracy (NOT fp16 accuracy): bound 2e-5 of the output scale, ten times
+    tighter than the bar of the fp32-MFMA tiles and ~200x below what plain fp16 operands give (4e-3)."""
+    lib = _lib(ptx)
+    cfgs = x3_configs(lib)
+    assert len(cfgs) >= 8
+    worst = 0.0
+    # every x3 tile x split-K on a 3x3x3 conv with residual + BN + ReLU
+    N, T, H, W, Ci, Co = 2, 3, 9, 10, 64, 160
+    x, w = rnd(N, Ci, T, H, W, seed=4), rnd(Co, Ci, 3, 3, 3, seed=5, scale=0.03)
+    bn, res = make_bn(Co, 6), rnd(N, Co, T, H, W, seed=7)
+    want = ref_conv(x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res)
+    for cfg in cfgs:
+        for split in (1, 2, 5):
+            got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res, cfg=cfg, split=split, x3=True)
+            err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+            worst = max(worst, err)
+            assert err <= 2e-5, (lib.ptx_conv3d_config_name(cfg).decode(), split, err)
+    # ragged channel counts (K tails inside an 8-channel block, N tails), strides, 1x1x1, temporal filters
+    for g in GEOMS:
+        name, N, T, H, W, Ci, Co, k, s_, p = g
+        x, w = rnd(N, Ci, T, H, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 3)
+        want = ref_conv(x, w, s_, p, bn=bn, relu=True)
+        for cfg in [-1] + cfgs:
+            got = hip_conv(ptx, x, w, s_, p, bn=bn, relu=True, cfg=cfg, split=1, x3=True)
+            err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+            worst = max(worst, err)
+            assert err <= 2e-5, (name, cfg, err)
+    # wide dynamic range: large and tiny magnitudes in one reduction (the lo halfs of tiny values go subnormal:
+    # absolute, not relative, accuracy is what the split guarantees)
+    x = rnd(1, 64, 2, 8, 8, seed=30) * torch.logspace(-3, 2, 64).view(1, 64, 1, 1, 1)
+    w = rnd(64, 64, 1, 3, 3, seed=31, scale=0.05)
+    want = ref_conv(x, w, (1, 1, 1), (0, 1, 1))
+    got = hip_conv(ptx, x, w, (1, 1, 1), (0, 1, 1), x3=True)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    # an fp32 tile may not run a split problem, and vice versa
+    L = ptx._lib
+    with pytest.raises(L.PtxError):
+        hip_conv(ptx, x, w, (1, 1, 1), (0, 1, 1), cfg=24, x3=True)
+    with pytest.raises(L.PtxError):
+        hip_conv(ptx, x, w, (1, 1, 1), (0, 1, 1), cfg=cfgs[0])
+    print("x3 worst relative error %.2e" % worst)
+
+
+def test_x3_dual_source_and_stem(ptx):
+    """Split operands through the two other conv entry shapes of the ResNet3D plan: the K-concatenated
+    conv3 + shortcut-B GEMM (ptx_conv3d_dual_fwd) and the kW-folded stem on 32-float rows."""
+    L, lib = ptx._lib, _lib(ptx)
+    null = C.c_void_p(0)
+    r8 = lambda v: (v + 7) // 8 * 8      # noqa: E731
+    for (N, T, H, W, C1, C2, Co, s_) in [(2, 4, 8, 8, 64, 64, 256, 1), (2, 2, 7, 7, 128, 256, 512, 2), (1, 1, 5, 6, 20, 36, 72, 2)]:
+        T2, H2, W2 = (T - 1) * s_ + 1, (H - 1) * s_ + 1 + (s_ - 1), (W - 1) * s_ + 1
+        o, x = rnd(N, C1, T, H, W, seed=60), rnd(N, C2, T2, H2, W2, seed=61)
+        w3, wd = rnd(Co, C1, 1, 1, 1, seed=62, scale=C1 ** -0.5), rnd(Co, C2, 1, 1, 1, seed=63, scale=C2 ** -0.5)
+        bn3, bnd = make_bn(Co, 64), make_bn(Co, 65)
+        want = F.relu(ref_conv(o, w3, (1, 1, 1), (0, 0, 0), bn=bn3) + ref_conv(x, wd, (s_, s_, s_), (0, 0, 0), bn=bnd))
+        Kc, Kc2, Co_pad = r8(C1), r8(C2), (Co + 127) // 128 * 128
+        ld = Kc + Kc2
+        wp = torch.zeros((Co_pad * ld,), device=DEV)
+        bp = torch.full((Co_pad,), float("nan"), device=DEV)
+        for (wt, bn, Ci_, kc, koff, acc) in ((w3, bn3, C1, Kc, 0, 0), (wd, bnd, C2, Kc2, Kc, 1)):
+            pd = L.PackDesc(Co, Ci_, 1, 1, 1, kc, Co_pad, 0, ld, koff, acc)
+            pd.f16 = 2
+            ts = [t.to(DEV) for t in bn[:4]]
+            wdv = wt.contiguous().to(DEV)
+            L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wdv), null, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                             C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack dual")
+            torch.cuda.synchronize()
+        od, xd = to_cl(o), to_cl(x)
+        ldy = _r4(Co)
+        for cfg, split in [(-1, 0)] + [(c, 1) for c in x3_configs(lib)[:6]] + [(x3_configs(lib)[3], 2)]:
+            yd = torch.full((N, T, H, W, ldy), float("nan"), device=DEV)
+            d = L.ConvDesc()
+            d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C1, od.shape[-1]
+            d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, Co, ldy
+            d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+            d.Kc, d.Co_pad, d.flags = Kc, Co_pad, L.PTX_EPI_RELU | L.PTX_F16X3_OPERANDS
+            d.x2_C, d.x2_ld, d.x2_T, d.x2_H, d.x2_W = C2, xd.shape[-1], T2, H2, W2
+            d.x2_sT = d.x2_sH = d.x2_sW = s_
+            ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
+            ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
+            L.check(lib.ptx_conv3d_dual_fwd(C.byref(d), _p(od), _p(xd), _p(wp), _p(bp), _p(yd), _p(ws), ws_bytes, cfg,
+                                            split, _st()), "dual conv x3")
+            torch.cuda.synchronize()
+            close(from_cl(yd, Co), want, tol=2e-5)
+    # stem: fold to 32-float rows, split filter, (7,7,1) conv
+    N, T, H, W = 2, 5, 30, 26
+    x, w = rnd(N, 3, T, H, W, seed=20), rnd(64, 3, 7, 7, 7, seed=21, scale=0.03)
+    bn = make_bn(64, 22)
+    want = ref_conv(x, w, (1, 2, 2), (3, 3, 3), bn=bn, relu=True)
+    Wo, Ho = (W + 6 - 7) // 2 + 1, (H + 6 - 7) // 2 + 1
+    xd = x.to(DEV)
+    x2 = torch.full((N, T, H, Wo, 32), float("nan"), device=DEV)
+    L.check(lib.ptx_fold_kw_ncdhw(_p(xd), _p(x2), N, 3, T, H, W, 7, 2, 3, Wo, 32, _st()), "fold")
+    pd = L.PackDesc(64, 3, 7, 7, 7, 32, 128, 1)
+    pd.f16 = 2
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(128, device=DEV)
+    ts = [t.to(DEV) for t in bn[:4]]
+    wd = w.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                     C.c_float(1e-5), _p(wp), _p(bp), _st()), "pack")
+    for cfg in [-1] + x3_configs(lib):
+        if cfg >= 0 and lib.ptx_conv3d_config_name(cfg).decode().split("/")[0].split("x")[1] not in ("64", "32"):
+            continue
+        yd = torch.full((N, T, Ho, Wo, 64), float("nan"), device=DEV)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, Wo, 21, 32
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = T, Ho, Wo, 64, 64
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 7, 7, 1, 1, 2, 1, 3, 3, 0
+        d.Kc, d.Co_pad, d.flags = 32, 128, L.PTX_EPI_RELU | L.PTX_F16X3_OPERANDS
+        L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(x2), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st()), "conv")
+        torch.cuda.synchronize()
+        close(from_cl(yd, 64), want, tol=2e-5)

@@ -577,3 +577,47 @@ def test_weight_edits_through_data_need_refresh_or_checksum(ptx):
         model.bn1.weight.mul_(2.0)
     assert torch.equal(model(x), back)
     assert not torch.equal(model.refresh()(x), back)
+
+
+X3_CASES = ["resnet3d50_small", "resnet3d50_odd", "resnet3d18_small", "nonlocalresnet3d50_small", "r2plus1d50_small",
+            "nonlocal_r2plus1d50_small", "resnet18_cfg1"]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_x3_split_precision_parity_small(ptx, case):
+    """Engine.precision = "x3" (fp32 operands split into half pairs, three fp16 MFMAs, fp32 accumulate) must meet
+    the SAME bar as the fp32 path against the real reference's goldens -- 1e-3, identical argmax -- and stay within
+    1e-4 of the fp32-MFMA engine itself (it is an fp32-accurate mode, not an fp16 one)."""
+    arch, kw = GOLDEN_CASES[case]
+    blob = load_golden(case)
+    model, sd = _build(ptx, arch, kw, **golden_recipe(blob))
+    xd = golden_input(blob).to(DEV)
+    base = model(xd).clone()
+    model.engine().precision = "x3"
+    out = model(xd)
+    torch.cuda.synchronize()
+    plan = list(model.engine()._plans.values())[-1]
+    names = [ptx._lib.lib().ptx_conv3d_config_name(s.cfg).decode() for s in plan.conv_steps]
+    assert plan.x3 and sum(n.endswith("/x3") for n in names) >= 0.9 * len(names), names
+    ref = torch.from_numpy(blob["logits"])
+    err = _check(out, ref, case + " x3 logits vs golden")
+    assert torch.equal(out.cpu().argmax(1), ref.argmax(1))
+    assert (out - base).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    model.engine().precision = "fp32"
+    again = model(xd)
+    assert torch.equal(again, base), "switching back must reproduce the fp32 path bit for bit"
+    print("%s x3 max|dlogits| = %.3e" % (case, err))
+
+
+def test_x3_config2_full_size_parity(ptx):
+    blob = load_golden("resnet3d50_cfg2")
+    model, sd = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), int(blob["w_seed"]))
+    model.engine().precision = "x3"
+    x = synth_clips(8, 16, 224, int(blob["x_seed"]))
+    out = model(x.to(DEV))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(blob["logits"])
+    err = _check(out, ref, "cfg2 x3 logits vs golden")
+    assert err <= 2e-4, err            # fp32-class: the fp32-MFMA path measures 1.5e-5 here
+    assert torch.equal(out.cpu().argmax(1), ref.argmax(1))
+    print("cfg2 x3 max|dlogits| = %.3e (max|logit| %.2f)" % (err, ref.abs().max().item()))
