@@ -357,7 +357,7 @@ template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, 
           bool X3 = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
-    static_assert(!X3 || (DMA && !F16 && !K22 && NSTAGE == 2), "split operands: LDS-DMA tiles, 2 buffers");
+    static_assert(!X3 || (DMA && !F16 && !K22), "split operands: LDS-DMA tiles");
     using MF = Mfma<MT>;
     using acc_t = typename MF::acc_t;
     constexpr int NT = 64 * WM * WN;         // threads per workgroup (4 or 8 waves)
@@ -439,27 +439,33 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             a_mask[i] = ok ? 0x00010101u : 0u;
             continue;
         }
-        const int mm = ok ? m : 0;
-        const int wo = mm % p.Wo;
-        int t = mm / p.Wo;
-        const int ho = t % p.Ho;
-        t /= p.Ho;
-        const int to = t % p.To;
-        const int n = t / p.To;
+        // row decode with multiply-shift divisions (a plain `/` is a ~35-instruction sequence: at 8 rows per
+        // thread the decode used to cost more VALU than a short-K conv's whole k-loop)
+        const unsigned mm = ok ? (unsigned)m : 0u;
+        const unsigned q1 = fastdiv(mm, p.dv_wo);
+        const int wo = (int)(mm - q1 * (unsigned)p.Wo);
+        const unsigned q2 = fastdiv(q1, p.dv_ho);
+        const int ho = (int)(q1 - q2 * (unsigned)p.Ho);
+        const int n = (int)fastdiv(q2, p.dv_to);
+        const int to = (int)q2 - n * p.To;
         const int tc = to * p.sT, hc = ho * p.sH, wc = wo * p.sW;      // centre-tap input coordinate
-        unsigned mask = 0;
-        for (int k = 0; k < p.kT; ++k) mask |= ((unsigned)(tc - p.pT + k) < (unsigned)p.Ti ? 1u : 0u) << k;
-        for (int k = 0; k < p.kH; ++k) mask |= ((unsigned)(hc - p.pH + k) < (unsigned)p.Hi ? 1u : 0u) << (8 + k);
-        for (int k = 0; k < p.kW; ++k) mask |= ((unsigned)(wc - p.pW + k) < (unsigned)p.Wi ? 1u : 0u) << (16 + k);
+        // taps k in [lo, hi] of an axis land inside the image: closed form instead of a loop over the filter extent
+        auto tap_range = [](int c, int pad, int k, int extent) -> unsigned {
+            const int lo = max(0, pad - c), hi = min(k - 1, extent - 1 + pad - c);
+            return hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+        };
+        const unsigned mask = tap_range(tc, p.pT, p.kT, p.Ti) | (tap_range(hc, p.pH, p.kH, p.Hi) << 8) |
+                              (tap_range(wc, p.pW, p.kW, p.Wi) << 16);
         unsigned cpos = (unsigned)(((n * p.Ti + tc) * p.Hi + hc) * p.Wi + wc);
+        unsigned par = 0;
         if constexpr (F16) {
             if (p.up2) {     // stored position of the centre tap; tap offsets then depend on the parity of (hc, wc)
                 cpos = (unsigned)(((n * p.Ti + tc) * p.Hp + (hc >> 1)) * p.Wp + (wc >> 1));
-                mask |= ((unsigned)(hc & 1) << 24) | ((unsigned)(wc & 1) << 25);
+                par = ((unsigned)(hc & 1) << 24) | ((unsigned)(wc & 1) << 25);
             }
         }
         a_off[i] = ok ? (cpos * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
-        a_mask[i] = ok ? mask : 0u;
+        a_mask[i] = ok ? (mask | par) : 0u;
     }
     unsigned a_off2[A_IT];      // second activation source (strided gather), dual-source convs only
 #pragma unroll
@@ -470,12 +476,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             const int idx = tid + NT * i;
             const int m = m0 + idx / F4R;
             if ((idx < A_F4) && (m < p.M)) {
-                const int wo = m % p.Wo;
-                int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                t /= p.Ho;
-                const int to = t % p.To;
-                const int n = t / p.To;
+                const unsigned q1 = fastdiv((unsigned)m, p.dv_wo);
+                const int wo = (int)((unsigned)m - q1 * (unsigned)p.Wo);
+                const unsigned q2 = fastdiv(q1, p.dv_ho);
+                const int ho = (int)(q1 - q2 * (unsigned)p.Ho);
+                const int n = (int)fastdiv(q2, p.dv_to);
+                const int to = (int)q2 - n * p.To;
                 const unsigned pos2 = (unsigned)(((n * p.T2 + to * p.s2T) * p.H2 + ho * p.s2H) * p.W2 + wo * p.s2W);
                 a_off2[i] = (pos2 * (unsigned)p.ldx2 + (unsigned)swz_col(idx)) * 4u;
             }
@@ -596,7 +602,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 }
                 if constexpr (DMA) {
                     // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
-                    if (wave_u * 64 + NT * i < A_F4)
+                    if ((A_F4 % NT == 0) || (wave_u * 64 + NT * i < A_F4))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             rs, (lds_ptr_t)(As + dbuf * BM * LDK + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
                 } else {
@@ -614,7 +620,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             unsigned off = b_off[i] + s_woff;
             if (KTAIL) off = (wc0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
             if constexpr (DMA) {
-                if (wave_u * 64 + NT * i < B_F4)
+                if ((B_F4 % NT == 0) || (wave_u * 64 + NT * i < B_F4))
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rsrc_w, (lds_ptr_t)(Bs + dbuf * BN * LDK + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
             } else {
@@ -760,10 +766,24 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int i = 0; i < TM; ++i) {
                 const f32x4 r0 = fa[slot][i][0], r1 = fa[slot][i][NF - 1];
                 const f32x8 v = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#ifdef PTX_X3_NOCONV_EXPERIMENT      // timing experiment only (garbage results): what the loop costs without the split VALU
+                ahi[i] = r0; alo[i] = r1; continue;
+#endif
                 const half8 h = __builtin_convertvector(v, half8);
-                const half8 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x8), half8);
                 ahi[i] = __builtin_bit_cast(f32x4, h);
-                alo[i] = __builtin_bit_cast(f32x4, l);
+                // v - float(hi) as ONE mixed-precision fma per value (v_fma_mix_f32 reads the half in place:
+                // -1.0 * hi + v), instead of v_cvt_f32_f16 + v_sub_f32
+                f32x8 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hp = ahi[i][e];          // two packed halfs
+                    float d0, d1;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(v[2 * e]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(v[2 * e + 1]));
+                    d[2 * e] = d0;
+                    d[2 * e + 1] = d1;
+                }
+                alo[i] = __builtin_bit_cast(f32x4, __builtin_convertvector(d, half8));
             }
             // term-major order: consecutive MFMAs write different accumulators
 #pragma unroll
@@ -1036,8 +1056,8 @@ template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE, 
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if constexpr (X3) {
         if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
-            return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, 2, false, true>(a, grid, st);
-        return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, 2, false, true>(a, grid, st);
+            return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, NSTAGE, false, true>(a, grid, st);
+        return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, NSTAGE, false, true>(a, grid, st);
     }
     if constexpr (F16) {
         if ((a.kA % BK) || (a.kB % BK))
@@ -1226,6 +1246,9 @@ struct ConvConfig {
 #define PTX_CFG_X3(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/x3", \
       launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, false, true>, false, false, true }
+#define PTX_CFG_X3R(BM, BN, BK, WM, WN, MT, NS) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma" #NS "/x3", \
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, NS, false, true>, false, false, true }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -1342,6 +1365,17 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_X3(64, 32, 64, 2, 2, 16),     // 99
     PTX_CFG_X3(256, 64, 32, 4, 1, 32),    // 100 stem, 64x64 per wave
     PTX_CFG_X3(128, 64, 64, 4, 2, 32),    // 101
+    // deeper LDS-DMA rings: with the matrix work per k-step 5x shorter, one k-step of prefetch no longer covers L2 / HBM latency
+    PTX_CFG_X3R(256, 64, 32, 8, 1, 32, 3),   // 102
+    PTX_CFG_X3R(256, 64, 32, 4, 1, 32, 3),   // 103
+    PTX_CFG_X3R(128, 64, 32, 4, 2, 32, 3),   // 104
+    PTX_CFG_X3R(128, 64, 32, 4, 2, 32, 4),   // 105
+    PTX_CFG_X3R(128, 128, 32, 4, 2, 32, 3),  // 106
+    PTX_CFG_X3R(64, 128, 32, 2, 2, 32, 3),   // 107
+    PTX_CFG_X3R(64, 64, 32, 2, 2, 32, 4),    // 108
+    PTX_CFG_X3R(128, 64, 32, 2, 2, 32, 4),   // 109
+    PTX_CFG_X3R(32, 64, 64, 2, 2, 16, 3),    // 110
+    PTX_CFG_X3R(128, 128, 32, 2, 2, 32, 3),  // 111
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1488,6 +1522,9 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
     a.m_tiles = cdiv(a.M, c.BM);
+    fastdiv_make((unsigned)a.Wo, a.dv_wo);      // every launch path (conv, dual, batched GEMM) decodes rows with these
+    fastdiv_make((unsigned)a.Ho, a.dv_ho);
+    fastdiv_make((unsigned)a.To, a.dv_to);
     {
         static int t_inner = -1;
         if (t_inner < 0) { const char* e = getenv("PTX_T_INNER"); t_inner = e ? atoi(e) : 0; }   // measured: no gain (stem is MFMA-bound), off by default
@@ -1548,6 +1585,27 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         return hip_check(hipGetLastError(), "splitk_reduce launch");
     }
     return PTX_OK;
+}
+}  // namespace ptx
+
+namespace ptx {
+// y[M][ldy] = relu?( x[M][ldx] . w[Nout][K]^T + b ) on the implicit-GEMM tiles: a Linear layer's weight [out][in] already IS
+// the K-major "packed filter" of a 1x1x1 conv with one tap.  ptx_linear_fwd routes here once M leaves the GEMV class
+// (the skinny kernel re-reads the weights per group of rows: BigGAN's 64-row class-conditional GEMMs ran at 0.1 TB/s).
+int linear_gemm(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int ldx, int ldy,
+                unsigned flags, hipStream_t st) {
+    ConvArgs a{};
+    a.x = x; a.w = w; a.bias = b; a.res = nullptr; a.y = y;
+    a.N = 1; a.Ti = 1; a.Hi = 1; a.Wi = M; a.ldx = ldx; a.kA = K;
+    a.To = 1; a.Ho = 1; a.Wo = M; a.Co = Nout; a.ldy = ldy; a.k_live = K;
+    a.kT = a.kH = a.kW = 1; a.sT = a.sH = a.sW = 1; a.pT = a.pH = a.pW = 0;
+    a.ldw = K; a.kB = K; a.w_rows = Nout; a.w_tap_stride = 0;
+    a.M = M; a.flags = flags & PTX_EPI_RELU;
+    a.groups = 1; a.cig = K; a.cog = Nout; a.pps = M;
+    a.x_bytes = (unsigned)((uint64_t)M * ldx * 4ull);
+    a.w_bytes = (unsigned)((uint64_t)Nout * K * 4ull);
+    const int config = M <= 32 ? 30 : 24;          // 32x64x32 / 64x64x32 LDS-DMA tiles
+    return launch_conv(a, config, 1, 1, nullptr, 0, st);
 }
 }  // namespace ptx
 
@@ -1617,9 +1675,6 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     a.Hp = a.up2 ? d->Hi / 2 : d->Hi;
     a.Wp = a.up2 ? d->Wi / 2 : d->Wi;
     a.pps = d->To * d->Ho * d->Wo;
-    fastdiv_make((unsigned)d->Wo, a.dv_wo);
-    fastdiv_make((unsigned)d->Ho, a.dv_ho);
-    fastdiv_make((unsigned)d->To, a.dv_to);
     if (d->flags & PTX_EPI_OUT_F16) {
         if (d->Co % 2 || d->ldy % 8 || ((uintptr_t)y & 15))
             return fail(PTX_ERR_INVALID, "conv3d: PTX_EPI_OUT_F16 needs an even Co and ldy (halfs) %% 8 == 0");

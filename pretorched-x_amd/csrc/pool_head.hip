@@ -698,6 +698,11 @@ extern "C" int ptx_linear_fwd(const float* x, const float* w, const float* b, fl
                               int32_t Nout, int32_t ldx, int32_t ldy, uint32_t flags, ptx_stream_t stream) {
     if (!x || !w || !y) return fail(PTX_ERR_INVALID, "linear: null pointer");
     if (M <= 0 || K <= 0 || Nout <= 0 || ldx < K || ldy < Nout) return fail(PTX_ERR_INVALID, "linear: bad extents");
+    // M >= 32 rows is a GEMM, not a GEMV: the MFMA tiles read the weights once (flags they do not implement stay here)
+    if (M >= 32 && K % 4 == 0 && Nout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && !(flags & ~(uint32_t)PTX_EPI_RELU) &&
+        ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) && (uint64_t)M * ldx * 4ull < 0x80000000ull &&
+        (uint64_t)Nout * K * 4ull < 0x80000000ull && (uint64_t)M * ldy * 4ull < 0x80000000ull)
+        return linear_gemm(x, w, b, y, M, K, Nout, ldx, ldy, flags, (hipStream_t)stream);
     if (K % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0) && (int64_t)M * ldx <= 0x7fffffffLL) {
         SkinnyArgs a{};
         a.x = x; a.w = w; a.b = b; a.y = y;

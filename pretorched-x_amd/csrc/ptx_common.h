@@ -45,6 +45,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + bid / kNumXCD;
 }
 
+// conv_igemm.hip: a Linear layer on the implicit-GEMM MFMA tiles (M >= 32 rows)
+int linear_gemm(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int ldx, int ldy,
+                unsigned flags, hipStream_t st);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -206,7 +206,7 @@ class _Ref:
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
-    def __init__(self, plan, convs, bn, fold_kw=False, scale=None, f16=False):
+    def __init__(self, plan, convs, bn, fold_kw=False, scale=None, f16=False, x3=None):
         dev = plan.dev
         self.plan = plan
         self.f16 = bool(f16)         # filter stored as halfs for an fp16-operand conv
@@ -234,7 +234,7 @@ class Packed:
             self.groups //= self.sub_groups
             self.Ci = SUPER
         self.fold_kw = bool(fold_kw)
-        self.x3 = bool(getattr(plan, "x3", False)) and not self.f16 and self.groups == 1
+        self.x3 = bool(getattr(plan, "x3", False) if x3 is None else x3) and not self.f16 and self.groups == 1
         keff = kW * self.Ci if fold_kw else self.Ci
         self.Kc = (keff + 7) // 8 * 8 if (self.f16 or self.x3) else _r4(keff)
         if self.f16 and (fold_kw or self.groups > 1 or self.Ci % 2):
@@ -389,13 +389,14 @@ class Plan:
         self._cur = model
 
     # ---------------------------------------------------------------- building blocks
-    def pack(self, convs, bn, fold_kw=False, scale=None, f16=False):
-        """scale: (module, attribute name) of a scalar Parameter multiplying the filter."""
+    def pack(self, convs, bn, fold_kw=False, scale=None, f16=False, x3=None):
+        """scale: (module, attribute name) of a scalar Parameter multiplying the filter.
+        x3: force (True) / forbid (False) split operands for this filter; None = the plan's precision."""
         if not isinstance(convs, (list, tuple)):
             convs = [convs]
-        key = (tuple(id(c) for c in convs), id(bn), fold_kw, None if scale is None else (id(scale[0]), scale[1]), bool(f16))
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw, None if scale is None else (id(scale[0]), scale[1]), bool(f16), x3)
         if key not in self._pack_cache:
-            p = Packed(self, convs, bn, fold_kw, scale, f16)
+            p = Packed(self, convs, bn, fold_kw, scale, f16, x3)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]

@@ -241,6 +241,7 @@ def build_biggan(self, model):
     self.steps.append(first_linear)
 
     half = getattr(model, "precision", "fp32") == "fp16"      # fp16 operands for every conv behind a cBN pass
+    self.half_plan = half
 
     def affine(x, sc, sh, ld_s, up, act=1, f16_out=None):
         f16_out = (half and act == 1) if f16_out is None else f16_out
@@ -343,13 +344,16 @@ def biggan_attention(self, x, att, name):
     N, HW = x.N, x.H * x.W
     c8, c2 = att.ch // 8, att.ch // 2
     one, zero = (1, 1, 1), (0, 0, 0)
-    tpg = self.conv(x, self.pack([att.theta, att.phi, att.g], None), one, zero, label=name + ".theta_phi_g")
+    # the attention block works on the fp32 raw map (softmax wants fp32 logits); in the fp16 generator plan its two
+    # pointwise convs run as split operands on the fp16 matrix cores (fp32-accurate, ~2.5x the fp32-MFMA rate)
+    x3 = True if getattr(self, "half_plan", False) else None
+    tpg = self.conv(x, self.pack([att.theta, att.phi, att.g], None, x3=x3), one, zero, label=name + ".theta_phi_g")
     phi = self.maxpool(tpg.slice(c8, c8), (1, 2, 2), (1, 2, 2), (0, 0, 0))
     g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
     S4 = HW // 4
     yatt = self.act(N, 1, x.H, x.W, c2)
     if self.attention(tpg.slice(0, c8), phi, g, yatt):
-        return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma")), one, zero, res=x, label=name + ".o")
+        return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma"), x3=x3), one, zero, res=x, label=name + ".o")
     ldf = _r4(S4)
     f = torch.empty((N, HW, ldf), device=self.dev, dtype=torch.float32)
     gT = torch.empty((N, c2, ldf), device=self.dev, dtype=torch.float32)

@@ -5,7 +5,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-x3 ${BENCH_ARGS}"
 echo "== kernel trace"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 echo "trace exit $?"

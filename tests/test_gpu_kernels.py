@@ -772,7 +772,7 @@ def test_grouped_conv(ptx):
     d.groups = 3
     assert lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), None, _p(yd), None, 0, -1, 1, _st()) == 1
     # narrow groups packed as block-diagonal 32-wide super-groups -> MFMA tiles inside one super-group
-    mfma = [i for i, n in enumerate(names) if not n.endswith(("/direct", "/f16")) and n.split("x")[1] in ("16", "32")]
+    mfma = [i for i, n in enumerate(names) if not n.endswith(("/direct", "/f16", "/x3")) and n.split("x")[1] in ("16", "32")]
     assert len(mfma) >= 4
     for (N, T, H, W, Cc, G, s_) in [(2, 4, 9, 10, 128, 32, (1, 1, 1)), (1, 5, 11, 8, 256, 32, (2, 2, 2)), (2, 3, 6, 6, 64, 4, (1, 1, 1))]:
         gw = Cc // G
