@@ -340,6 +340,9 @@ int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float*
  * Limits: d, dv multiples of 4, d <= 512 (ptx_nonlocal_supported); larger d: ptx_bgemm_nt + ptx_softmax_rows. */
 #define PTX_NL_SOFTMAX 0
 #define PTX_NL_SCALE 1
+#define PTX_NL_F16 2   /* OR into mode (softmax, d <= 64): both matmuls on v_mfma_f32_16x16x16_f16 -- theta / phi / g / P are rounded
+                          to halfs in registers, accumulators / softmax statistics / y stay fp32.  The BigGAN generator's
+                          self-attention under its fp16 plan (BASELINE config 5); the video nets keep the fp32 kernel. */
 typedef struct ptx_nonlocal_desc {
     int32_t batch, Nq, Nk, d, dv;
     int32_t ld_theta, ld_phi, ld_g, ld_y;        /* row strides (floats)   */

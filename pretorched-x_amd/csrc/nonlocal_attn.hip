@@ -54,7 +54,19 @@ __device__ __forceinline__ void tile_barrier(int& a, int& b) {
     asm volatile("; ds_reads of this tile depend on these" : "+v"(a), "+v"(b)::"memory");
 }
 
-template <int D, int DV, bool SOFTMAX>
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16h(half4_t a, half4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ half4_t to_half4(float a, float b, float c, float d) {
+    return half4_t{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+}
+
+// F16 (PTX_NL_F16, the BigGAN generator's fp16 plan): the same data movement and register layouts, but both matmuls
+// run on v_mfma_f32_16x16x16_f16 -- the 4 consecutive d (resp. the 4 keys 4*gq .. 4*gq+3) a lane already holds as
+// floats ARE one K = 16 operand once rounded to halfs, so 4 fp32 MFMAs (128 clk) become one f16 MFMA (16 clk).
+// Accumulators, softmax statistics and the output stay fp32.
+template <int D, int DV, bool SOFTMAX, bool F16 = false>
 __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     constexpr int TK = 16;                   // keys per tile
     constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
@@ -91,6 +103,11 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         const unsigned off = ((unsigned)q * (unsigned)p.ld_t + (unsigned)col) * 4u;
         qf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                               rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
+    }
+    half4_t qh[QJ];
+    if constexpr (F16) {
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) qh[j] = to_half4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]);
     }
 
     // ---- per-lane DMA source offsets (tile independent) ----
@@ -153,6 +170,12 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
 #pragma unroll
         for (int j = 0; j < QJ; ++j) {
             const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + swz(n, 4 * j + gq) * 4);
+            if constexpr (F16) {
+                const half4_t kh = to_half4(kf[0], kf[1], kf[2], kf[3]);
+                if (j & 1) s1 = mfma16h(kh, qh[j], s1);
+                else       s0 = mfma16h(kh, qh[j], s0);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (j & 1) s1 = mfma16(kf[e], qf[j][e], s1);
@@ -192,6 +215,21 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         }
 
         // ---- O += P . g_tile ----
+        if constexpr (F16) {
+            // A = P[q = n][keys 4*gq + 0..3] (this lane's pr[]), B_e = g[keys 4*gq + 0..3][channel cb*64 + 4n + e]: the e-th
+            // component of the four 16-byte reads below -- one MFMA per output-channel quarter
+            const half4_t ph = to_half4(pr[0], pr[1], pr[2], pr[3]);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 vf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vf[r] = *reinterpret_cast<const f32x4*>(Vb + r * DV + cb * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    O[cb][e] = mfma16h(ph, to_half4(vf[0][e], vf[1][e], vf[2][e], vf[3][e]), O[cb][e]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -226,7 +264,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     }
 }
 
-template <int D, int DV, bool SOFTMAX>
+template <int D, int DV, bool SOFTMAX, bool F16 = false>
 static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 16 * (D + DV) * sizeof(float);
     const dim3 grid((unsigned)(a.q_tiles * a.batch), (unsigned)cdiv(a.dv, DV));
@@ -234,11 +272,11 @@ static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, F16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, F16>), grid, dim3(256), lds, st, a);
     return hip_check(hipGetLastError(), "nonlocal attention launch");
 }
 
@@ -267,7 +305,7 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
         d->ld_g % 4 || d->ld_y % 4 || d->bs_theta % 4 || d->bs_phi % 4 || d->bs_g % 4 || d->bs_y % 4)
         return fail(PTX_ERR_INVALID, "nonlocal: row / batch strides must be multiples of 4 floats and cover the extents");
     if (((uintptr_t)theta | (uintptr_t)phi | (uintptr_t)g | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "nonlocal: misaligned pointer");
-    if (d->mode != PTX_NL_SOFTMAX && d->mode != PTX_NL_SCALE) return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
+    if (d->mode & ~(PTX_NL_SCALE | PTX_NL_F16)) return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
     const uint64_t tb = (uint64_t)d->Nq * d->ld_theta * 4ull, pb = (uint64_t)d->Nk * d->ld_phi * 4ull, gb = (uint64_t)d->Nk * d->ld_g * 4ull;
     if (tb >= 0x80000000ull || pb >= 0x80000000ull || gb >= 0x80000000ull)
         return fail(PTX_ERR_UNSUPPORTED, "nonlocal: one batch item of theta / phi / g must be < 2 GiB");
@@ -277,9 +315,14 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     a.ld_t = d->ld_theta; a.ld_p = d->ld_phi; a.ld_g = d->ld_g; a.ld_y = d->ld_y;
     a.bs_t = d->bs_theta; a.bs_p = d->bs_phi; a.bs_g = d->bs_g; a.bs_y = d->bs_y;
     a.q_tiles = cdiv(d->Nq, 64);
-    a.scale_only = d->mode == PTX_NL_SCALE;
+    a.scale_only = (d->mode & PTX_NL_SCALE) != 0;
     a.t_bytes = (unsigned)tb; a.p_bytes = (unsigned)pb; a.g_bytes = (unsigned)gb;
     hipStream_t st = (hipStream_t)stream;
+    if (d->mode & PTX_NL_F16) {          // fp16-operand MFMAs: the generator's self-attention shape family only
+        if (a.scale_only || d->d > 64)
+            return fail(PTX_ERR_UNSUPPORTED, "nonlocal: PTX_NL_F16 covers softmax attention with d <= 64 (d=%d)", d->d);
+        return d->dv <= 64 ? launch_nl_mode<64, 64, true, true>(a, st) : launch_nl_mode<64, 256, true, true>(a, st);
+    }
     // smallest compiled (D, DV) covering the problem; dv > DV is split over blockIdx.y (S recomputed per chunk)
     if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl<32, 128>(a, st);
     if (d->d <= 64) return d->dv <= 64 ? launch_nl<64, 64>(a, st) : launch_nl<64, 256>(a, st);

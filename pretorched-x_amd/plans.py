@@ -352,7 +352,7 @@ def biggan_attention(self, x, att, name):
     g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
     S4 = HW // 4
     yatt = self.act(N, 1, x.H, x.W, c2)
-    if self.attention(tpg.slice(0, c8), phi, g, yatt):
+    if self.attention(tpg.slice(0, c8), phi, g, yatt, f16=bool(getattr(self, "half_plan", False))):
         return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma"), x3=x3), one, zero, res=x, label=name + ".o")
     ldf = _r4(S4)
     f = torch.empty((N, HW, ldf), device=self.dev, dtype=torch.float32)
