@@ -61,6 +61,7 @@ struct ConvArgs {
     unsigned x2_bytes;
     int groups, cig, cog;  // grouped conv: input / output channels per group
     int f16;               // A / B operands are halfs; K extents count 32-bit words
+    unsigned dv_hw[2];     // KWR tiles: fast division by the halo'd run length Wo + kW - 1
     int x3;                // fp32 A split into half (hi, lo) pairs on the fly, B packed as (hi8 | lo8) blocks: 3 f16 MFMAs
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;   // extents of one batch item (buffer-resource bounds)
     // fused generator stage (ptx_conv3d_fused_fwd, fp16-operand tiles): a per-sample affine after bias (+ skip) -- the
@@ -353,9 +354,15 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
 // stored as 8 hi halfs then 8 lo halfs -- the same 32 bytes), so B fragments are two 16-byte reads, no VALU.
 // Operand values must lie inside the half range (|v| < 65504); values below 2^-14 lose relative precision (their
 // lo part goes subnormal) but not absolute precision.
+// KWR ("kw reuse", KWR = 3): for stride-1 filters of width 3 whose M tile is a whole number of output rows, the A tile
+// staged per (kt, kh, channel chunk) is the HALO'D input run -- Wo + 2 positions per output row -- and the three kw taps
+// read their fragments from it at row offsets +0 / +1 / +2, each against its own B (filter) tile of the same stage.  A
+// moves through L2 -> LDS once instead of three times: with the matrix work per k-step 5x (x3) to 16x (f16) shorter than
+// on the fp32 cores, that traffic (8-11 TB/s sustained by the LDS-DMA path) is what bounds these convs.
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false>
+          bool X3 = false, int KWR = 0>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
+    static_assert(KWR == 0 || (KWR == 3 && DMA && NSTAGE == 2 && !K22), "kw-reuse tiles: 3-wide filters, 2-stage LDS-DMA");
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
     static_assert(!X3 || (DMA && !F16 && !K22), "split operands: LDS-DMA tiles");
     using MF = Mfma<MT>;
@@ -378,7 +385,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     constexpr int KSUB = BK / (KPL * KG);    // sub-steps per k-step
     static_assert(KSUB * KPL * KG == BK, "BK must be a multiple of KPL*KG");
     constexpr int F4R = BK / 4;              // float4 per tile row
-    constexpr int A_F4 = BM * F4R, B_F4 = BN * F4R;
+    constexpr int KW_T = KWR ? KWR : 1;      // kw taps served by one staged A tile
+    // LDS rows of the A image: BM/Wo runs of Wo + 2 positions (Wo >= 8), rounded so the image is whole 1-KiB DMA pieces
+    constexpr int AR = KWR ? (BM + BM / 4 + 15) / 16 * 16 : BM;
+    constexpr int ASTG = AR * (DMA ? BK : BK + 4), BSTG = KW_T * BN * (DMA ? BK : BK + 4);   // floats per stage
+    constexpr int A_F4 = AR * F4R, B_F4 = BN * F4R;
     constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
     // swizzle: physical 16-B slot = logical slot ^ ((row >> SWS) & (F4R - 1)); with 256-B rows (F4R 16)
     // SWS = 0, with 128-B rows (F4R 8) SWS = 1, with 64-B rows (F4R 4) SWS = 2 -- any 16 distinct
@@ -390,8 +401,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     };
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                        // [NSTAGE][BM][LDK]
-    float* Bs = smem + NSTAGE * BM * LDK;    // [NSTAGE][BN][LDK]
+    float* As = smem;                        // [NSTAGE][AR][LDK]
+    float* Bs = smem + NSTAGE * ASTG;        // [NSTAGE][KW_T][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -432,6 +443,37 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const int idx = tid + NT * i;
         const int row = idx / F4R;
         const int col = swz_col(idx);
+        if constexpr (KWR) {
+            // LDS row -> (output row-run r, position j of its halo'd run): input column j - pW of that run's image row
+            const int HW = p.Wo + KWR - 1;
+            const unsigned r = fastdiv((unsigned)row, p.dv_hw);
+            const int j = row - (int)r * HW;
+            const int m = m0 + (int)r * p.Wo;                       // first output position of the run
+            const int wcol = j - p.pW;
+            const bool ok = (idx < A_F4) && ((int)r * p.Wo < BM) && (m < p.M) && ((unsigned)wcol < (unsigned)p.Wi);
+            const unsigned mm = (m < p.M) ? (unsigned)m : 0u;
+            const unsigned q1 = fastdiv(mm, p.dv_wo);
+            const unsigned q2 = fastdiv(q1, p.dv_ho);
+            const int ho = (int)(q1 - q2 * (unsigned)p.Ho);
+            const int n = (int)fastdiv(q2, p.dv_to);
+            const int to = (int)q2 - n * p.To;
+            const int tc = to * p.sT, hc = ho * p.sH;
+            auto tap_range = [](int c, int pad, int k, int extent) -> unsigned {
+                const int lo = max(0, pad - c), hi = min(k - 1, extent - 1 + pad - c);
+                return hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+            };
+            unsigned mask = tap_range(tc, p.pT, p.kT, p.Ti) | (tap_range(hc, p.pH, p.kH, p.Hi) << 8) | (0xFFu << 16);
+            unsigned cpos = (unsigned)(((n * p.Ti + tc) * p.Hi + hc) * p.Wi + wcol);
+            if constexpr (F16) {
+                if (p.up2) {        // upsampling loader: wcol / hc are upsampled coordinates, the tensor stores half of them
+                    cpos = (unsigned)(((n * p.Ti + tc) * p.Hp + (hc >> 1)) * p.Wp + (wcol >> 1));
+                    mask |= (unsigned)(hc & 1) << 24;
+                }
+            }
+            a_off[i] = ok ? (cpos * (unsigned)p.ldx + (unsigned)col) * 4u : kOOB;
+            a_mask[i] = ok ? mask : 0u;
+            continue;
+        }
         const int m = m0 + row;
         const bool ok = (idx < A_F4) && (m < p.M);
         if (p.unit_pointwise) {      // 1x1x1, stride 1, no padding: input position == output position
@@ -524,7 +566,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // channel-chunk-minor; split-K slices that space evenly.  (kt, kh, kw, ch) is the next k-step to
     // LOAD and is advanced with a few scalar compares -- no divisions, no data-dependent branches.
     const int nkt = max(kt_hi - kt_lo + 1, 0), nkh = max(kh_hi - kh_lo + 1, 0);
-    const int total_steps = nkt * nkh * p.kW * p.kchunks;
+    const int kw_ext = KWR ? 1 : p.kW;            // KWR: one staged A tile serves all kw taps
+    const int total_steps = nkt * nkh * kw_ext * p.kchunks;
     const int per_split = (total_steps + p.split_k - 1) / p.split_k;
     const int s_begin = min(zs * per_split, total_steps);
     const int my_steps = min(s_begin + per_split, total_steps) - s_begin;
@@ -532,8 +575,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     {
         ch = s_begin % p.kchunks;
         int t = s_begin / p.kchunks;
-        kw = t % p.kW;
-        t /= p.kW;
+        kw = t % kw_ext;
+        t /= kw_ext;
         const int d = max(nkh, 1);
         kh = kh_lo + t % d;
         kt = kt_lo + t / d;
@@ -543,7 +586,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const bool c1 = ch == p.kchunks;
         ch = c1 ? 0 : ch;
         kw += c1 ? 1 : 0;
-        const bool c2 = kw == p.kW;
+        const bool c2 = kw == kw_ext;
         kw = c2 ? 0 : kw;
         kh += c2 ? 1 : 0;
         const bool c3 = kh > kh_hi;
@@ -575,8 +618,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const int wc0 = use2 ? p.wcol2 + c0 : c0;
         // uniform: tap selector for the mask test, signed byte offset of the tap from the centre
         const unsigned sel = valid ? ((1u << kt) | (1u << (8 + kh)) | (1u << (16 + kw))) : 0xFFFFFFFFu;
+        const int kw_rel = KWR ? 0 : kw - p.pW;       // KWR rows carry their own input column
         const unsigned s_off =
-            (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.ldx + c0) * 4);
+            (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + kw_rel) * p.ldx + c0) * 4);
         // nearest-2x upsampled input: the tap's stored offset is floor((par + k - p) / 2) rows / columns from the
         // centre's, i.e. one of two uniform values per axis, selected by the row's parity bits
         unsigned up_h0 = 0, up_h1 = 0, up_w0 = 0, up_w1 = 0;
@@ -587,8 +631,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 const int row_b = p.Wp * p.ldx * 4, col_b = p.ldx * 4;
                 up_h0 = (unsigned)(((kh - p.pH) >> 1) * row_b + c0 * 4);
                 up_h1 = (unsigned)(((kh - p.pH + 1) >> 1) * row_b + c0 * 4);
-                up_w0 = (unsigned)(((kw - p.pW) >> 1) * col_b);
-                up_w1 = (unsigned)(((kw - p.pW + 1) >> 1) * col_b);
+                up_w0 = KWR ? 0u : (unsigned)(((kw - p.pW) >> 1) * col_b);
+                up_w1 = KWR ? 0u : (unsigned)(((kw - p.pW + 1) >> 1) * col_b);
             }
         }
         auto issue_a = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&base)[A_IT], unsigned soff, int klim) {
@@ -604,7 +648,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
                     if ((A_F4 % NT == 0) || (wave_u * 64 + NT * i < A_F4))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rs, (lds_ptr_t)(As + dbuf * BM * LDK + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
+                            rs, (lds_ptr_t)(As + dbuf * ASTG + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
                 } else {
                     ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, 0));
                 }
@@ -614,24 +658,27 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             issue_a(rsrc_x2, a_off2, (unsigned)(c0 * 4), p.kA2);
         else
             issue_a(rsrc_x, a_off, s_off, p.kA);
-        const unsigned s_woff = valid ? (unsigned)(((size_t)tap * p.w_tap_stride + wc0) * 4) : kOOB;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            unsigned off = b_off[i] + s_woff;
-            if (KTAIL) off = (wc0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
-            if constexpr (DMA) {
-                if ((B_F4 % NT == 0) || (wave_u * 64 + NT * i < B_F4))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rsrc_w, (lds_ptr_t)(Bs + dbuf * BN * LDK + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
-            } else {
-                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+        for (int kw2 = 0; kw2 < KW_T; ++kw2) {
+            const unsigned s_woff = valid ? (unsigned)(((size_t)(tap + kw2) * p.w_tap_stride + wc0) * 4) : kOOB;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                unsigned off = b_off[i] + s_woff;
+                if (KTAIL) off = (wc0 + swz_col(tid + NT * i)) < p.kB ? off : kOOB;
+                if constexpr (DMA) {
+                    if ((B_F4 % NT == 0) || (wave_u * 64 + NT * i < B_F4))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsrc_w, (lds_ptr_t)(Bs + dbuf * BSTG + kw2 * BN * LDK + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
+                } else {
+                    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+                }
             }
         }
     };
 
     auto store_tiles = [&](int buf) {
-        float* Ab = As + buf * BM * LDK;
-        float* Bb = Bs + buf * BN * LDK;
+        float* Ab = As + buf * ASTG;
+        float* Bb = Bs + buf * BSTG;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int idx = tid + NT * i;
@@ -652,7 +699,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
 
-    const int frag_off_a = (wm * WTM + (lane % MT)) * LDK + (DMA ? 0 : (lane / MT) * 4);
+    // KWR: output row m_local of the tile lives at LDS row m_local + 2 * (m_local / Wo) (+ kw for tap kw)
+    int a_lrow[KWR ? TM : 1];
+    if constexpr (KWR) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * WTM + i * MT + (lane % MT);
+            a_lrow[i] = ml + (KWR - 1) * (int)fastdiv((unsigned)ml, p.dv_wo);
+        }
+    }
+    const int frag_off_a = KWR ? 0 : (wm * WTM + (lane % MT)) * LDK + (DMA ? 0 : (lane / MT) * 4);
     const int frag_off_b = (wn * WTN + (lane % MT)) * LDK + (DMA ? 0 : (lane / MT) * 4);
     const int frag_sw = ((lane % MT) >> SWS) & (F4R - 1);       // DMA: row swizzle of this lane's rows
 
@@ -686,7 +742,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 
     // fragment registers, rotated across sub-steps.  The slot sequence must close on itself at the
     // step boundary with compile-time indices: 2 slots for an even sub-step count, KSUB for odd.
-    static_assert(KSUB >= 2, "at least two sub-steps per k-step");
+    static_assert(KW_T * KSUB >= 2, "at least two sub-steps per k-step");
     // K22 (kW-folded stem: only 21 of the 24 k of a chunk carry data): the last sub-step covers
     // k = 16..21 with two 8-byte reads per row -- lane group g gets (16+2g, 17+2g) and (20+2g, 21+2g)
     // -- and 3 MFMAs pairing (16,18) (17,19) (20,22); the pair (21,23) is all padding and is dropped:
@@ -694,20 +750,34 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     static_assert(!K22 || ((BK == 24 || (DMA && BK == 32)) && MT == 32), "K22 is the 32x32x2 stem path (BK 24, or 32 under DMA)");
     // live sub-steps of a k-step: the LDS-DMA K22 tile stages 32-float rows of which 22 carry data -- sub-steps 0, 1
     // (k 0..15), the 3-MFMA sub-step 2 (k 16..21), nothing for k 24..31
-    constexpr int KLIVE = (K22 && DMA) ? 3 : KSUB;
+    constexpr int KLIVE = (K22 && DMA) ? 3 : KW_T * KSUB;      // KWR: the sub-steps of the three kw taps follow each other
     constexpr int NSLOT = (KLIVE % 2) ? KLIVE : 2;
     constexpr int NF = X3 ? 2 : 1;           // 16-byte reads per operand row per sub-step
     f32x4 fa[NSLOT][TM][NF], fb[NSLOT][TN][NF];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto read_frags = [&](int buf, int ks, int slot, int offa, int offb) {
+    auto read_frags = [&](int buf, int s_, int slot, int offa, int offb) {
+        const int kw_i = KWR ? s_ / KSUB : 0;
+        const int ks = KWR ? s_ % KSUB : s_;
+        // A row base (floats from As) and its 16-byte-slot swizzle key for wave-tile row block i
+        auto a_row = [&](int i, int& sw) -> int {
+            if constexpr (KWR) {
+                const int lr = a_lrow[i] + kw_i;
+                sw = (lr >> SWS) & (F4R - 1);
+                return buf * ASTG + offa + lr * LDK;
+            } else {
+                sw = frag_sw;
+                return buf * ASTG + offa + i * MT * LDK;
+            }
+        };
+        const float* Bk = Bs + buf * BSTG + kw_i * BN * LDK + offb;
         if (K22 && ks == KLIVE - 1) {
             // floats (16 + 2g, 17 + 2g) and (20 + 2g, 21 + 2g) of the row; under DMA they sit in the swizzled
             // 16-byte slots 4 and 5 (offa / offb then carry no lane-group term)
             const int g = lane / MT;
             const int lo_off = DMA ? ((4 ^ frag_sw) * 4 + 2 * g) : (16 + 2 * g - 4 * g);
             const int hi_off = DMA ? ((5 ^ frag_sw) * 4 + 2 * g) : (20 + 2 * g - 4 * g);
-            const float* Ab = As + buf * BM * LDK + offa;
-            const float* Bb = Bs + buf * BN * LDK + offb;
+            const float* Ab = As + buf * ASTG + offa;
+            const float* Bb = Bk;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const f32x2 lo = *reinterpret_cast<const f32x2*>(Ab + i * MT * LDK + lo_off);
@@ -727,12 +797,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             // (A: floats 8b..8b+3 | 8b+4..8b+7;  B: 8 hi halfs | 8 lo halfs)
             const int b2 = (ks * KG + lane / MT) * 2;
             const int k0 = ((b2 ^ frag_sw) * 4), k1 = (((b2 + 1) ^ frag_sw) * 4);
-            const float* Ab = As + buf * BM * LDK + offa;
-            const float* Bb = Bs + buf * BN * LDK + offb;
+            const float* Bb = Bk;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + k0);
-                fa[slot][i][NF - 1] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK + k1);
+                int sw;
+                const float* Ar = As + a_row(i, sw);
+                fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ar + ((b2 ^ sw) * 4));
+                fa[slot][i][NF - 1] = *reinterpret_cast<const f32x4*>(Ar + (((b2 + 1) ^ sw) * 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -742,10 +813,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             return;
         }
         const int koff = DMA ? (((ks * KG + lane / MT) ^ frag_sw) * 4) : ks * 4 * KG;
-        const float* Ab = As + buf * BM * LDK + offa + koff;
-        const float* Bb = Bs + buf * BN * LDK + offb + koff;
+        const float* Bb = Bk + koff;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ab + i * MT * LDK);
+        for (int i = 0; i < TM; ++i) {
+            int sw;
+            const float* Ar = As + a_row(i, sw);
+            fa[slot][i][0] = *reinterpret_cast<const f32x4*>(Ar + (DMA ? (((ks * KG + lane / MT) ^ sw) * 4) : ks * 4 * KG));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bb + j * MT * LDK);
     };
@@ -1032,13 +1106,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false>
+          bool X3 = false, int KWR = 0>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     // fp16 tiles: the fused epilogue parks one MT-row block per wave ([MT][BN / WN + 4] floats) in the tile buffers
-    constexpr size_t lds_tiles = (size_t)NSTAGE * (BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    constexpr size_t lds_tiles = (size_t)NSTAGE * ((KWR ? (BM + BM / 4 + 15) / 16 * 16 : BM) + (KWR ? KWR : 1) * BN) * (DMA ? BK : BK + 4) * sizeof(float);
     constexpr size_t lds_epi = F16 ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0;
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3, KWR>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -1052,6 +1126,13 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // KTAIL instantiation only when the K extent of either operand is not a multiple of BK
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool F16, bool X3, int KWR>
+static int launch_cfg_kwr(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if ((a.kA % BK) || (a.kB % BK))
+        return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, 2, F16, X3, KWR>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, 2, F16, X3, KWR>(a, grid, st);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool DMA, int NSTAGE, bool F16 = false, bool X3 = false>
 static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if constexpr (X3) {
@@ -1227,28 +1308,35 @@ struct ConvConfig {
     bool direct;      // VALU kernel: no split-K, own grid
     bool f16;         // fp16 operands (PTX_F16_OPERANDS)
     bool x3;          // split fp32 operands on the fp16 matrix cores (PTX_F16X3_OPERANDS)
+    int kwr;          // kw-reuse tile (3-wide stride-1 filters, BM a whole number of output rows)
 };
 
 #define PTX_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT, launch_cfg<BM, BN, BK, WM, WN, MT, false, 2>, false, false, false, 0 }
 #define PTX_CFG_DMA(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma", launch_cfg<BM, BN, BK, WM, WN, MT, true, 2>, false, false, false, 0 }
 #define PTX_CFG_DMA3(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3", launch_cfg<BM, BN, BK, WM, WN, MT, true, 3>, false, false, false, 0 }
 #define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false, false, 0 }
 
 #define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
-    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false, false }
+    { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false, false, 0 }
 #define PTX_CFG_F16(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/f16", \
-      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, true>, false, true, false }
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, true>, false, true, false, 0 }
 #define PTX_CFG_X3(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/x3", \
-      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, false, true>, false, false, true }
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, 2, false, true>, false, false, true, 0 }
+#define PTX_CFG_KWR_X3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/kwr/x3", \
+      launch_cfg_kwr<BM, BN, BK, WM, WN, MT, false, true, 3>, false, false, true, 3 }
+#define PTX_CFG_KWR_F16(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/kwr/f16", \
+      launch_cfg_kwr<BM, BN, BK, WM, WN, MT, true, false, 3>, false, true, false, 3 }
 #define PTX_CFG_X3R(BM, BN, BK, WM, WN, MT, NS) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma" #NS "/x3", \
-      launch_cfg<BM, BN, BK, WM, WN, MT, true, NS, false, true>, false, false, true }
+      launch_cfg<BM, BN, BK, WM, WN, MT, true, NS, false, true>, false, false, true, 0 }
 
 static const ConvConfig kConfigs[] = {
     PTX_CFG(128, 128, 32, 2, 2, 32),  // 0  large M, Co >= 128
@@ -1376,6 +1464,22 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_X3R(128, 64, 32, 2, 2, 32, 4),   // 109
     PTX_CFG_X3R(32, 64, 64, 2, 2, 16, 3),    // 110
     PTX_CFG_X3R(128, 128, 32, 2, 2, 32, 3),  // 111
+    // kw-reuse tiles: 3-wide stride-1 filters, BM = whole output rows (224 = 4 x 56 = 8 x 28 = 16 x 14; 128 / 256 for 2^k widths)
+    PTX_CFG_KWR_X3(224, 64, 32, 7, 1, 32),    // 112
+    PTX_CFG_KWR_X3(224, 64, 16, 7, 1, 32),    // 113
+    PTX_CFG_KWR_X3(224, 128, 16, 7, 1, 32),   // 114
+    PTX_CFG_KWR_X3(128, 64, 32, 4, 2, 32),    // 115
+    PTX_CFG_KWR_X3(112, 64, 32, 1, 4, 16),    // 116
+    PTX_CFG_KWR_X3(256, 64, 32, 8, 1, 32),    // 117
+    PTX_CFG_KWR_X3(256, 64, 16, 8, 1, 32),    // 118
+    PTX_CFG_KWR_F16(256, 64, 32, 8, 1, 32),   // 119
+    PTX_CFG_KWR_F16(256, 64, 16, 8, 1, 32),   // 120
+    PTX_CFG_KWR_F16(256, 64, 32, 4, 1, 32),   // 121
+    PTX_CFG_KWR_F16(128, 128, 32, 4, 2, 32),  // 122
+    PTX_CFG_KWR_F16(256, 128, 16, 4, 2, 32),  // 123
+    PTX_CFG_KWR_F16(128, 64, 32, 4, 2, 32),   // 124
+    PTX_CFG_KWR_F16(256, 16, 32, 8, 1, 16),   // 125 the 3-channel image conv
+    PTX_CFG_KWR_F16(128, 128, 16, 4, 2, 32),  // 126
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1519,6 +1623,13 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16-operand problems run on the /f16 tile configurations only (and vice versa)");
     if ((a.x3 != 0) != c.x3)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: split-operand problems run on the /x3 tile configurations only (and vice versa)");
+    if (c.kwr) {
+        if (a.kW != c.kwr || a.sW != 1 || a.dual || batch > 1 || a.groups > 1 || a.Wo < 8 || c.BM % a.Wo ||
+            a.Wo != a.Wi + 2 * a.pW - a.kW + 1)
+            return fail(PTX_ERR_UNSUPPORTED, "conv3d: a kw-reuse tile needs a dense %d-wide stride-1 filter and a %d-row tile made of "
+                        "whole output rows (Wo = %d >= 8)", c.kwr, c.BM, a.Wo);
+        fastdiv_make((unsigned)(a.Wo + c.kwr - 1), a.dv_hw);
+    }
     if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
     a.m_tiles = cdiv(a.M, c.BM);

@@ -160,7 +160,14 @@ def fp32_configs(lib):
 
 
 def x3_configs(lib):
-    return [i for i in range(lib.ptx_conv3d_num_configs()) if lib.ptx_conv3d_config_name(i).decode().endswith("/x3")]
+    """Split-operand tiles that run any geometry (the kw-reuse ones need whole-row tiles: kwr_configs)."""
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    return [i for i, n in enumerate(names) if n.endswith("/x3") and "/kwr/" not in n]
+
+
+def kwr_configs(lib, kind):
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    return [i for i, n in enumerate(names) if n.endswith("/kwr/" + kind)]
 
 
 def test_conv_every_config_and_split(ptx):
@@ -822,7 +829,7 @@ def test_conv_f16_operands(ptx):
     output): against an fp32 ATen conv of the SAME half-rounded inputs, so only the summation order differs."""
     L, lib = ptx._lib, _lib(ptx)
     names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
-    f16cfgs = [i for i, n in enumerate(names) if n.endswith("/f16")]
+    f16cfgs = [i for i, n in enumerate(names) if n.endswith("/f16") and "/kwr/" not in n]
     assert len(f16cfgs) >= 6
     for (N, H, W, Ci, Co, k, pad, relu, with_res) in [(2, 12, 10, 64, 96, 3, 1, True, True), (3, 9, 9, 40, 24, 1, 0, False, False),
                                                       (1, 20, 20, 128, 3, 3, 1, False, False), (2, 6, 6, 256, 160, 1, 0, True, True)]:
@@ -1004,7 +1011,7 @@ def test_conv_fused_generator_stage(ptx):
     ptx_conv3d_fused_fwd's epilogue / loader, each on several fp16 tiles (and split-K through the reduce kernel)."""
     lib = _lib(ptx)
     names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
-    f16 = [i for i, n in enumerate(names) if n.endswith("/f16")]
+    f16 = [i for i, n in enumerate(names) if n.endswith("/f16") and "/kwr/" not in n]
     wide = [(c, 1) for c in f16 if int(names[c].split("x")[1]) >= 32]
     every = [(-1, 0)] + wide + [(wide[0][0], 3)]
     some = [(-1, 0), wide[1], wide[-1], (wide[2][0], 2)]
@@ -1140,3 +1147,49 @@ def test_x3_dual_source_and_stem(ptx):
         L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(x2), _p(wp), _p(bp), None, _p(yd), None, 0, cfg, 1, _st()), "conv")
         torch.cuda.synchronize()
         close(from_cl(yd, 64), want, tol=2e-5)
+
+
+def test_conv_kwr_tiles(ptx):
+    """kw-reuse tiles: the A tile of a 3-wide stride-1 filter is staged once per (kt, kh, channel chunk) as the halo'd
+    input run and serves the three kw taps.  Same results as every other tile of their operand flavour, on geometries
+    whose M tile is a whole number of output rows; anything else is refused (PTX_ERR_UNSUPPORTED), never mis-computed."""
+    L, lib = ptx._lib, _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    kx3, kf16 = kwr_configs(lib, "x3"), kwr_configs(lib, "f16")
+    assert len(kx3) >= 4 and len(kf16) >= 4
+    ran = 0
+    # split operands: 3x3x3 and (1,3,3), W = 16 / 32 / 8, strides in T / H, ragged channels, M tails, residual
+    for (N, T, H, W, Ci, Co, k, s_, p_) in [(2, 3, 6, 16, 64, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+                                           (1, 4, 7, 32, 40, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                           (3, 2, 9, 8, 64, 130, (3, 3, 3), (1, 2, 1), (1, 1, 1)),
+                                           (2, 5, 5, 16, 128, 64, (3, 3, 3), (2, 1, 1), (1, 1, 1)),
+                                           (1, 1, 7, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1))]:
+        x, w = rnd(N, Ci, T, H, W, seed=70), rnd(Co, Ci, *k, seed=71, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 72)
+        To, Ho = (T + 2 * p_[0] - k[0]) // s_[0] + 1, (H + 2 * p_[1] - k[1]) // s_[1] + 1
+        res = rnd(N, Co, To, Ho, W, seed=73)
+        want = ref_conv(x, w, s_, p_, bn=bn, relu=True, res=res)
+        for cfg in kx3:
+            bm = int(names[cfg].split("x")[0])
+            for split in (1, 2):
+                if bm % W:
+                    with pytest.raises(L.PtxError):
+                        hip_conv(ptx, x, w, s_, p_, bn=bn, relu=True, res=res, cfg=cfg, split=1, x3=True)
+                    break
+                got = hip_conv(ptx, x, w, s_, p_, bn=bn, relu=True, res=res, cfg=cfg, split=split, x3=True)
+                err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+                assert err <= 2e-5, (names[cfg], (N, T, H, W, Ci, Co, k, s_), split, err)
+                ran += 1
+    assert ran >= 20
+    # a filter that is not 3 wide / not stride 1 in W is refused
+    x, w = rnd(1, 64, 1, 8, 16, seed=74), rnd(64, 64, 1, 1, 1, seed=75, scale=0.1)
+    with pytest.raises(L.PtxError):
+        hip_conv(ptx, x, w, (1, 1, 1), (0, 0, 0), cfg=kx3[0], x3=True)
+    # fp16 operands through the fused generator stage: plain 3x3, the upsampling loader, the 3-channel tanh image conv
+    wide = [(c, 1) for c in kf16 if int(names[c].split("x")[1]) >= 32]
+    narrow = [(c, 1) for c in kf16 if int(names[c].split("x")[1]) < 32]
+    assert wide and narrow
+    _fused_stage_case(ptx, 2, 8, 16, 64, 64, 3, False, True, True, False, True, False, None, wide + [(wide[0][0], 2)])
+    _fused_stage_case(ptx, 2, 8, 8, 32, 32, 3, True, True, True, False, True, False, None, wide)          # up2: 16-wide output
+    _fused_stage_case(ptx, 1, 16, 16, 48, 40, 3, True, True, True, False, True, False, None, wide)        # up2: 32-wide output
+    _fused_stage_case(ptx, 2, 16, 32, 64, 3, 3, False, False, False, True, False, False, None, narrow + wide[:1])
