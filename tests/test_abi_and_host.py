@@ -385,3 +385,87 @@ def test_bench_workload_table(ptx):
             assert tuple(cpu_fn(sd, x).shape) == (1, 1000)
     with pytest.raises(SystemExit):
         bench.other_workload("cfg9", 0)
+
+
+def test_standin_models_match_literature_shapes(ptx):
+    """the snapshot holds no I3D / BigGAN source, so their oracles are builder-written
+    stand-ins (parity unpinned).  Pin what CAN be pinned -- the published shape of the networks -- so the stand-ins
+    (and the plans compiled from them) cannot drift silently:
+      I3D (Carreira & Zisserman 2017, RGB stream, Kinetics-400): ~12.3 M parameters, ~108 G multiply-adds per
+        64 x 224 x 224 clip, 57 Unit3D convs (stem, 2 + 9 x 6 Inception convs, logits);
+      BigGAN-deep-256 (Brock et al. 2019, App. B): ch = 128, 12 bottleneck GBlocks with channel multipliers
+        in [16,16,8,8,4,2] -> out [16,8,8,4,2,1], upsampling on every second block 4 -> 256 px, self-attention at 64 x 64."""
+    m = ptx.i3d(400)
+    n = sum(p.numel() for p in m.parameters())
+    plan = m.engine().dry_plan(m, (1, 3, 64, 224, 224))
+    gmac = sum(s.macs for s in plan.conv_steps) / 1e9
+    assert len(plan.conv_steps) == 57
+    assert abs(n / 12.3e6 - 1) < 0.05, n
+    assert abs(gmac / 108.0 - 1) < 0.05, gmac
+    g = ptx.biggan_deep(256)
+    blocks = [b for st in g.blocks for b in st]
+    gb = [b for b in blocks if b.kind == "gblock"]
+    ch = 128
+    assert [(b.in_channels // ch, b.out_channels // ch) for b in gb[1::2]] == [(16, 16), (16, 8), (8, 8), (8, 4), (4, 2), (2, 1)]
+    assert [bool(b.upsample) for b in gb] == [False, True] * 6
+    assert all(b.in_channels == b.out_channels for b in gb[0::2])
+    res, att_res = g.bottom_width, None
+    for b in blocks:
+        if b.kind == "gblock":
+            res *= 2 if b.upsample else 1
+        else:
+            att_res = res
+    assert (g.bottom_width, res, att_res) == (4, 256, 64)
+    ng = sum(p.numel() for p in g.parameters())
+    assert 45e6 < ng < 60e6, ng            # published: ~50 M generator parameters
+    gplan = g.engine().dry_plan(g, (2, 128))
+    assert gplan.feat.C == 3 and (gplan.feat.H, gplan.feat.W) == (256, 256)
+
+
+def test_x3_precision_plan_wiring_without_gpu(ptx):
+    """Engine.precision = "x3": every dense conv of the plan is packed as split halfs (Kc % 8 == 0, the folded stem
+    on 32-float rows), carries PTX_F16X3_OPERANDS and defaults to an '/x3' tile; grouped convs keep fp32 tiles;
+    switching the precision drops the compiled plans; the tuned table is keyed per operand flavour."""
+    from pretorched_x_amd import engine
+    L, lib = ptx._lib, ptx._lib.lib()
+    m = ptx.resnet3d50(num_classes=339, pretrained=None)
+    eng = m.engine()
+    base = eng.dry_plan(m, (2, 3, 16, 224, 224))
+    assert not base.x3 and not any(s.d.flags & L.PTX_F16X3_OPERANDS for s in base.conv_steps)
+    with pytest.raises(ptx.PtxError):
+        eng.precision = "fp8"
+    eng.precision = "x3"
+    plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
+    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps)
+    for s in plan.conv_steps:
+        assert s.d.flags & L.PTX_F16X3_OPERANDS and s.d.Kc % 8 == 0, s.label
+        assert lib.ptx_conv3d_config_name(s.cfg).decode().endswith("/x3"), s.label
+    stem = plan.conv_steps[0]
+    assert (stem.d.Kc, stem.d.ldx, stem.d.Ci) == (32, 32, 21)
+    assert sum(s.macs for s in plan.conv_steps) == sum(s.macs for s in base.conv_steps)
+    # grouped convs (ResNeXt3D) are not split: they stay on the fp32 / direct tiles
+    rx = ptx.resnext3d50(num_classes=10)
+    rx.engine().precision = "x3"
+    px = rx.engine().dry_plan(rx, (1, 3, 8, 64, 64))
+    grouped = [s for s in px.conv_steps if s.d.groups > 1]
+    assert grouped and not any(s.d.flags & L.PTX_F16X3_OPERANDS for s in grouped)
+    assert all(s.d.flags & L.PTX_F16X3_OPERANDS for s in px.conv_steps if s.d.groups <= 1)
+    # tuned entries never cross operand flavours
+    key = "x3-test-key"
+    engine.tuned_merge({key: ("128x128x32/4x2/m32/dma/x3", 1)})
+    assert engine.tuned_lookup(key, "x3") is not None and engine.tuned_lookup(key, "") is None
+    assert engine.tuned_lookup(key, "f16") is None
+    # the C ABI refuses inconsistent descriptors
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx, d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, 1, 8, 8, 20, 20, 1, 8, 8, 8, 8
+    d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+    d.Kc, d.Co_pad, d.flags = 20, 128, L.PTX_F16X3_OPERANDS        # Kc % 8 != 0
+    assert lib.ptx_conv3d_config_supported(C.byref(d), 0) == 0
+    d.Kc = 24
+    assert lib.ptx_conv3d_config_supported(C.byref(d), 0) == 1
+    sk = C.c_int(0)
+    assert lib.ptx_conv3d_config_name(lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))).decode().endswith("/x3")
+    pd = L.PackDesc(8, 20, 1, 1, 1, 20, 128, 0)
+    pd.f16 = 2
+    assert lib.ptx_pack_conv_weight(C.byref(pd), C.c_void_p(16), None, None, None, None, None, C.c_float(0), C.c_void_p(16),
+                                    C.c_void_p(16), None) != 0

@@ -337,3 +337,17 @@ def test_oracle_nlblock_golden(ptx):
     with pytest.raises(Exception):               # sub_sample needs >= 2 positions along every axis
         m = ptx.NonLocalBlock3D(16, mode="gaussian", sub_sample=True)
         m.engine().dry_plan(m, (1, 16, 1, 4, 4))
+
+
+@needs_ref
+def test_reference_densenet3d_cannot_be_constructed():
+    """SURVEY.md 8(f) N1 tail: the reference's DenseNet3D (`pretorched/models/densenet3D.py:131`) registers children
+    named 'norm.1', 'relu.1', 'conv.1' ... through add_module; torch >= 1.x / 2.x rejects module names containing a
+    dot, so the class cannot be constructed in this environment -- there is no reference behaviour to pin (and no
+    registry entry upstream, `pretorched/__init__.py`).  This test documents WHY the row is not built; it would fail
+    (and flag the row as buildable) if a future torch accepted those names again."""
+    import importlib
+    ref_shim.import_reference()
+    dn = importlib.import_module("pretorched.models.densenet3D")
+    with pytest.raises(KeyError, match="module name can"):
+        dn.DenseNet(num_init_features=8, growth_rate=4, block_config=(1, 1, 1, 1), sample_size=32, sample_duration=8)
