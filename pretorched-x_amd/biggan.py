@@ -3,7 +3,7 @@ Image Synthesis", ICLR 2019, appendix B "BigGAN-deep") behind the HIP engine -- 
 
 The mounted reference snapshot has NO BigGAN source.  This module
 follows the published architecture with the parameter names of the authors' PyTorch release
-(`BigGANdeep.Generator`: shared, linear, blocks.{i}.{j}.{conv1..4, bn1..4.{gain,bias,stored_mean,
+(`BigGANdeep.Generator`: shared, linear, blocks.{stage}.{j}.{conv1..4, bn1..4.{gain,bias,stored_mean,
 stored_var}}, attention {theta,phi,g,o,gamma}, output_layer.{0,2}).  **Parity is unpinned by the
 reference**: the checker is the builder-written CPU module in oracle/biggan_standin.py.
 
@@ -80,6 +80,19 @@ class BigGANDeepGenerator(EngineOwner, nn.Module):
         self.precision = precision
         if resolution not in _ARCH:
             raise ValueError("resolution must be one of %s" % sorted(_ARCH))
+        ins_, outs_, attn_ = _ARCH[resolution]
+        if depth != 2:
+            raise ValueError("BigGAN-deep GBlocks come in pairs (depth = 2): the second block of a pair upsamples; got depth=%r" % (depth,))
+        if dim_z % 4 or shared_dim % 4 or dim_z <= 0 or shared_dim <= 0:
+            raise ValueError("dim_z and shared_dim must be positive multiples of 4 (16-byte rows of the conditioning vector); "
+                             "got dim_z=%r shared_dim=%r" % (dim_z, shared_dim))
+        if ch <= 0 or (min(outs_) * ch) % 8:
+            raise ValueError("ch * %d (the narrowest stage) must be a multiple of 8 channels; got ch=%r" % (min(outs_), ch))
+        if attn_ is not None:
+            att_ch = [co * ch for i, co in enumerate(outs_) if bottom_width * 2 ** (i + 1) == attn_]
+            if any(c % 32 for c in att_ch):
+                raise ValueError("the self-attention stage needs a channel count that is a multiple of 32 (theta / phi use "
+                                 "ch/8 channels in 4-channel groups); got %s from ch=%r" % (att_ch, ch))
         self.resolution, self.ch, self.dim_z, self.shared_dim = resolution, ch, dim_z, shared_dim
         self.n_classes, self.depth, self.bottom_width, self.bn_eps = n_classes, depth, bottom_width, bn_eps
         self.arch = Arch("gblock", (), "B", dims=2)
@@ -111,7 +124,25 @@ class BigGANDeepGenerator(EngineOwner, nn.Module):
         # spectral-norm power-iteration buffers of the original release are not parameters here
         sd = {k: v for k, v in state_dict.items() if not (k.rsplit(".", 1)[-1].startswith(("u", "sv"))
                                                           and k.rsplit(".", 1)[-1][1:].lstrip("v").isdigit())}
-        return super().load_state_dict(sd, strict=strict, **kw)
+        return super().load_state_dict(self._from_release_layout(sd), strict=strict, **kw)
+
+    def _from_release_layout(self, sd):
+        """The authors' BigGANdeep.Generator nests one ModuleList per GBlock -- keys `blocks.{stage*depth + d}.0.*`, the
+        attention block riding as `blocks.{j}.1.*` on the last GBlock of its stage -- where this class nests one list
+        per STAGE (`blocks.{stage}.{d}.*`, attention at `blocks.{stage}.{depth}.*`).  A state_dict in the release
+        layout is recognised by its block indices running past the number of stages and is re-keyed."""
+        import re
+        idx = [int(m.group(1)) for m in (re.match(r"blocks\.(\d+)\.", k) for k in sd) if m]
+        if not idx or max(idx) < len(self.blocks):
+            return sd
+        out = {}
+        for k, v in sd.items():
+            m = re.match(r"blocks\.(\d+)\.(\d+)\.(.*)", k)
+            if m:
+                stage, d = divmod(int(m.group(1)), self.depth)
+                k = "blocks.%d.%d.%s" % (stage, d if int(m.group(2)) == 0 else self.depth, m.group(3))
+            out[k] = v
+        return out
 
     def forward(self, z, y):
         return self._engine.generate(self, z, y)

@@ -469,3 +469,27 @@ def test_x3_precision_plan_wiring_without_gpu(ptx):
     pd.f16 = 2
     assert lib.ptx_pack_conv_weight(C.byref(pd), C.c_void_p(16), None, None, None, None, None, C.c_float(0), C.c_void_p(16),
                                     C.c_void_p(16), None) != 0
+
+
+def test_biggan_release_layout_and_config_validation(ptx):
+    """A state_dict keyed like the authors' BigGANdeep.Generator (one ModuleList per GBlock, attention riding on the
+    last GBlock of its stage) loads into the per-stage layout of this package; unusable widths are refused at
+    construction with a clear message instead of failing inside the planner."""
+    import re
+    g = ptx.biggan_deep(128, ch=32)
+    sd = {k: v.clone() for k, v in g.state_dict().items()}
+    rel = {}
+    for k, v in sd.items():
+        m = re.match(r"blocks\.(\d+)\.(\d+)\.(.*)", k)
+        if m:
+            st, d = int(m.group(1)), int(m.group(2))
+            k = "blocks.%d.%d.%s" % (st * g.depth + min(d, g.depth - 1), 0 if d < g.depth else 1, m.group(3))
+        rel[k] = v + 1
+    assert max(int(re.match(r"blocks\.(\d+)", k).group(1)) for k in rel if k.startswith("blocks.")) == 2 * len(g.blocks) - 1
+    res = g.load_state_dict(rel)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert all(torch.equal(g.state_dict()[k], sd[k] + 1) for k in sd)
+    g.load_state_dict(sd)                                   # the package's own layout still loads
+    for bad in (dict(ch=12, resolution=128), dict(shared_dim=130), dict(depth=3), dict(dim_z=6)):
+        with pytest.raises(ValueError):
+            ptx.biggan_deep(bad.pop("resolution", 256), **bad)
