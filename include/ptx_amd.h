@@ -62,6 +62,13 @@ typedef void* ptx_stream_t; /* hipStream_t */
                                 (measured: same |dlogits| vs the CPU reference as fp32 MFMA) at 3 / 16 of its matrix-core
                                 time.  Needs Kc % 8 == 0, groups == 1 and operand magnitudes inside the half range (< 65504).
                                 Runs on the ".../x3" tile configurations.                                          */
+#define PTX_SPLITK_FUSED 0x10000u /* split_k > 1 without the second (reduce) launch: the workspace then starts with 64 KiB of
+                                tile arrival counters -- which the CALLER zeroes once (ptx_conv3d_workspace_bytes includes
+                                them when the descriptor carries this flag) and every launch leaves at zero -- followed by
+                                the partial slabs; the last split block to finish a tile sums the partials in split order
+                                (bit-identical to the separate reduce kernel), applies the epilogue and writes y.  Grids
+                                with more than 16384 tiles and the fused generator-stage epilogue fall back to the reduce
+                                kernel (same workspace layout).                                                     */
 /* Fused generator stage (BigGAN-deep GBlock: cBN -> ReLU -> [nearest x2] -> conv, BASELINE config 5), on the
  * fp16-operand tiles through ptx_conv3d_fused_fwd.  The class-conditional BN that FOLLOWS a conv is applied in that
  * conv's epilogue as a per-sample affine (tables from ptx_cbn_fold), the upsampling that precedes a conv is done by

@@ -20,6 +20,7 @@ PTX_EPI_ACCUM = 16
 PTX_EPI_RES_UP = 64
 PTX_F16_OPERANDS = 128
 PTX_F16X3_OPERANDS = 0x8000
+PTX_SPLITK_FUSED = 0x10000
 PTX_ACT_OUT_F16 = 0x100
 PTX_EPI_OUT_F16, PTX_EPI_AFFINE, PTX_EPI_DUAL_RAW, PTX_RES_F16, PTX_PRO_UP2, PTX_EPI_TANH = 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000
 
@@ -38,7 +39,9 @@ class ConvDesc(C.Structure):
                  "x2_C", "x2_ld", "x2_T", "x2_H", "x2_W", "x2_sT", "x2_sH", "x2_sW", "groups")]
 
     def key(self):
-        return tuple(getattr(self, f) for f, _ in self._fields_)
+        """Identity of a conv PROBLEM for the tuned-tile table: every field, minus flag bits that do not change which
+        tile is fastest by construction of the table (PTX_SPLITK_FUSED arrived after the table was keyed)."""
+        return tuple((getattr(self, f) & ~0x10000) if f == "flags" else getattr(self, f) for f, _ in self._fields_)
 
 
 class ConvFusedExt(C.Structure):

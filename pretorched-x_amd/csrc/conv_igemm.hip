@@ -41,6 +41,7 @@ struct ConvArgs {
     const float* res;
     float* y;
     float* partial;
+    unsigned* counters;    // PTX_SPLITK_FUSED: one arrival counter per output tile (zero between launches)
     int N, Ti, Hi, Wi, ldx, kA;
     int To, Ho, Wo, Co, ldy;
     int ncol;             // output columns written per row = round_up(Co, 4) <= ldy (ldy is the row stride:
@@ -1054,6 +1055,42 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             }
         }
     }
+    // ---- split-K, fused reduction (PTX_SPLITK_FUSED): the LAST split block to finish a tile sums the partial tiles of
+    // all splits -- in split order, so the result is bit-identical to the separate reduce kernel and independent of
+    // which block happens to be last -- applies the epilogue and writes y.  No second launch.  Release / acquire:
+    // device-scope fences around one atomic arrival counter per tile; the last block leaves the counter at zero.
+    if (to_partial && p.counters) {
+        __threadfence();
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+            const unsigned prev = atomicAdd(p.counters + tile, 1u);
+            const unsigned last = prev == (unsigned)p.split_k - 1u ? 1u : 0u;
+            if (last) atomicExch(p.counters + tile, 0u);
+            flag[0] = last;
+        }
+        __syncthreads();
+        if (!flag[0]) return;
+        __threadfence();
+        const size_t slab = (size_t)p.M * p.ncol;
+        // a plain loop over the tile's elements, 4 columns per thread (tiny code: this tail is instantiated per tile shape)
+#pragma unroll 1
+        for (int e = tid * 4; e < BM * BN; e += NT * 4) {
+            const int m = m0 + e / BN, co = n0 + e % BN;
+            if (co < p.ncol && m < p.M) {
+                const float* src = p.partial + (size_t)m * p.ncol + co;
+                f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll 1
+                for (int z = 1; z < p.split_k; ++z) v += *reinterpret_cast<const f32x4*>(src + z * slab);
+                f32x4 o;
+                o.x = conv_epilogue(p, v.x, m, co);
+                o.y = conv_epilogue(p, v.y, m, co + 1);
+                o.z = conv_epilogue(p, v.z, m, co + 2);
+                o.w = conv_epilogue(p, v.w, m, co + 3);
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + co) = o;
+            }
+        }
+    }
 }
 
 // y = epilogue(sum over splits of partial)
@@ -1610,9 +1647,12 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     return cfg;
 }
 
+constexpr size_t kCounterBytes = 65536;       // PTX_SPLITK_FUSED: 16384 tile counters ahead of the partial slabs
+
 extern "C" size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* d, int split_k) {
     if (!d || split_k <= 1) return 0;
-    return (size_t)split_k * d->N * d->To * d->Ho * d->Wo * ((d->Co + 3) / 4 * 4) * sizeof(float);
+    return ((d->flags & PTX_SPLITK_FUSED) ? kCounterBytes : 0) +
+           (size_t)split_k * d->N * d->To * d->Ho * d->Wo * ((d->Co + 3) / 4 * 4) * sizeof(float);
 }
 
 namespace ptx {
@@ -1676,20 +1716,26 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         if (split_k > 1) a.y_bytes = (unsigned)std::min<uint64_t>((uint64_t)a.M * a.ncol * 4ull, 0x7fffffffull);   // fp32 partial slab
     }
     a.partial = nullptr;
+    a.counters = nullptr;
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
                         a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && !a.up2) ? 1 : 0;
+    bool fused_reduce = false;
     if (split_k > 1) {
-        const size_t need = (size_t)split_k * a.M * a.ncol * sizeof(float);
+        const size_t head = (a.flags & PTX_SPLITK_FUSED) ? kCounterBytes : 0;
+        const size_t need = head + (size_t)split_k * a.M * a.ncol * sizeof(float);
         if (!workspace || workspace_bytes < need)
             return fail(PTX_ERR_WORKSPACE, "conv3d: split_k=%d needs %zu workspace bytes, got %zu", split_k, need,
                         workspace_bytes);
-        a.partial = static_cast<float*>(workspace);
+        a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + head);
+        // the fused generator-stage epilogue (halfs out, dual output ...) keeps the separate reduce kernel
+        fused_reduce = head != 0 && (size_t)a.m_tiles * a.n_tiles * 4 <= kCounterBytes && !(a.flags & kFusedEpiFlags);
+        if (fused_reduce) a.counters = static_cast<unsigned*>(workspace);
     }
     if ((int64_t)a.m_tiles * a.n_tiles > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "conv3d: grid too large");
     dim3 grid((unsigned)(a.m_tiles * a.n_tiles), (unsigned)batch, (unsigned)split_k);
     int s = c.launch(a, grid, st);
     if (s != PTX_OK) return s;
-    if (split_k > 1) {
+    if (split_k > 1 && !fused_reduce) {
         const size_t total4 = (size_t)a.M * a.ncol / 4;
         unsigned blocks = (unsigned)std::min<size_t>((total4 + 255) / 256, (size_t)kNumCU * 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);

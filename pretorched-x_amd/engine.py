@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
-                   PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_F16X3_OPERANDS, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
+                   PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_F16X3_OPERANDS, PTX_SPLITK_FUSED, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None                    # conv problem key -> (tile configuration NAME, split-K)
@@ -369,7 +369,7 @@ class Plan:
         with _device_ctx(dev):
             self._build(model)
             if self.ws_bytes:
-                self.ws = torch.empty(self.ws_bytes // 4, device=dev, dtype=torch.float32)
+                self.ws = torch.zeros(self.ws_bytes // 4, device=dev, dtype=torch.float32)
                 self.ws_ptr = _ptr(self.ws)
         self._cur = None
 
@@ -441,7 +441,12 @@ class Plan:
                 label, (y.N, y.T, y.H, y.W, y.C), (x.N, To, Ho, Wo, pk.Co)))
         if y.ld != _r4(pk.Co) and pk.Co % 4 and not out_f16:
             raise PtxError("%s: a channel-slice output needs Co %% 4 == 0" % label)
-        flags = PTX_EPI_RELU if relu else 0
+        # PTX_SPLITK_FUSED=1: split-K launches reduce in-kernel (last-arriving block; the plan's workspace is allocated
+        # ZEROED, its first 64 KiB are tile counters every launch leaves at zero).  Off by default: measured SLOWER than
+        # the separate reduce launch on MI355X (layer4 3x3x3, split 6: 33 -> 54 us) -- the device-scope release / acquire
+        # across the 8 XCD L2s and one block summing what 100+ blocks of the reduce kernel sum in parallel cost more than
+        # the launch they save; the tuner answered by abandoning split-K (config 2: 1355 -> 1309 clips/s).
+        flags = (PTX_EPI_RELU if relu else 0) | (PTX_SPLITK_FUSED if os.environ.get("PTX_SPLITK_FUSED", "0") == "1" else 0)
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, xT, xH, xW, x.C, x.ld
         half = bool(getattr(x, "f16", False))

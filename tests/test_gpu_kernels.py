@@ -42,7 +42,7 @@ def from_cl(y, c):
 
 
 def hip_conv(ptx, x, w, stride, padding, bias=None, bn=None, relu=False, res=None, res_pad=None, res_stride=1,
-             cfg=-1, split=0, pro_relu=False, x3=False):
+             cfg=-1, split=0, pro_relu=False, x3=False, fused_split=None):
     """x NCDHW cpu, w [Co,Ci,kT,kH,kW] cpu.  Returns NCDHW cpu output of ptx_conv3d_fwd.
     x3: split operands (PTX_F16X3_OPERANDS) -- the filter packed as (hi8 | lo8) half blocks."""
     L, lib = ptx._lib, _lib(ptx)
@@ -86,9 +86,15 @@ def hip_conv(ptx, x, w, stride, padding, bias=None, bn=None, relu=False, res=Non
         d.res_C, d.res_T, d.res_H, d.res_W = res_pad.shape[1], res_pad.shape[2], res_pad.shape[3], res_pad.shape[4]
         d.res_sT = d.res_sH = d.res_sW = res_stride
         flags |= L.PTX_EPI_RES_PADA
+    if fused_split is not None:          # PTX_SPLITK_FUSED: `fused_split` is the caller's zeroed workspace (reused across calls)
+        flags |= L.PTX_SPLITK_FUSED
     d.flags = flags
     ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
-    ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
+    if fused_split is not None:
+        assert fused_split.numel() * 4 >= ws_bytes
+        ws = fused_split
+    else:
+        ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
     L.check(lib.ptx_conv3d_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), _p(rd) if rd is not None else null, _p(yd),
                                _p(ws), ws_bytes, cfg, split, _st()), "conv")
     torch.cuda.synchronize()
@@ -1193,3 +1199,31 @@ def test_conv_kwr_tiles(ptx):
     _fused_stage_case(ptx, 2, 8, 8, 32, 32, 3, True, True, True, False, True, False, None, wide)          # up2: 16-wide output
     _fused_stage_case(ptx, 1, 16, 16, 48, 40, 3, True, True, True, False, True, False, None, wide)        # up2: 32-wide output
     _fused_stage_case(ptx, 2, 16, 32, 64, 3, 3, False, False, False, True, False, False, None, narrow + wide[:1])
+
+
+def test_splitk_fused_reduction(ptx):
+    """PTX_SPLITK_FUSED: the last split block of a tile reduces in-kernel.  Bit-identical to the two-launch path (partials
+    are summed in split order either way), the counters return to zero (one workspace serves launch after launch, across
+    tile shapes), and every epilogue (BN bias, residual, shortcut-A, ReLU) goes through it."""
+    lib = _lib(ptx)
+    names = [lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())]
+    N, T, H, W, Ci, Co = 2, 3, 9, 10, 64, 160
+    x, w = rnd(N, Ci, T, H, W, seed=4), rnd(Co, Ci, 3, 3, 3, seed=5, scale=0.03)
+    bn, res = make_bn(Co, 6), rnd(N, Co, T, H, W, seed=7)
+    ws = torch.zeros(8 * N * T * H * W * Co + 65536 // 4 + 64, device=DEV)
+    fp32 = [c for c in fp32_configs(lib) if not names[c].endswith("/direct")]
+    for cfg in fp32[::3] + x3_configs(lib)[::4]:
+        is_x3 = names[cfg].endswith("/x3")
+        for split in (2, 5, 8):
+            base = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res, cfg=cfg, split=split, x3=is_x3)
+            for rep_ in range(2):
+                got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, res=res, cfg=cfg, split=split, x3=is_x3,
+                               fused_split=ws)
+                assert torch.equal(got, base), (names[cfg], split, rep_)
+            assert int(ws[:16384].abs().sum().item()) == 0, "tile counters must return to zero"
+    # shortcut-A residual through the fused tail, strided conv
+    xs, w3 = rnd(2, 64, 4, 8, 8, seed=11), rnd(128, 64, 3, 3, 3, seed=16, scale=0.03)
+    rp2, bn2 = rnd(2, 48, 4, 8, 8, seed=17), make_bn(128, 13)
+    base = hip_conv(ptx, xs, w3, (2, 2, 2), (1, 1, 1), bn=bn2, relu=True, res_pad=rp2, res_stride=2, split=3)
+    got = hip_conv(ptx, xs, w3, (2, 2, 2), (1, 1, 1), bn=bn2, relu=True, res_pad=rp2, res_stride=2, split=3, fused_split=ws)
+    assert torch.equal(got, base)
