@@ -414,6 +414,9 @@ def main():
             "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
             "distributed_check": verify, "ranks_seen": ranks_seen,
         }
+    if rank == 0 and os.environ.get("PTX_TUNED_OUT"):      # tile choices of this run (both legs), for tuned_gfx950.json
+        from pretorched_x_amd.engine import save_tuned_table
+        save_tuned_table(os.environ["PTX_TUNED_OUT"])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,23 @@
+"""Merge tuned-tile tables dumped by bench.py (PTX_TUNED_OUT) into pretorched-x_amd/tuned_gfx950.json.
+
+    python scripts/merge_tuned.py gpurun_out/tuned_*.json
+Later files win; entries whose tile name the current build does not have are dropped."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pretorched_x_amd import engine, _lib        # noqa: E402
+
+lib = _lib.lib()
+names = {lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())}
+path = os.path.join(ROOT, "pretorched-x_amd", "tuned_gfx950.json")
+table = json.load(open(path))
+n0 = len(table)
+for f in sys.argv[1:]:
+    table.update(json.load(open(f)))
+table = {k: v for k, v in table.items() if v[0] in names}
+engine._tuned = {k: (str(v[0]), int(v[1])) for k, v in table.items()}
+engine.save_tuned_table(path)
+print("%d -> %d entries" % (n0, len(table)))
