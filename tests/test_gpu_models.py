@@ -2,9 +2,8 @@
 (a) golden outputs of the real reference (tests/golden/*.npz, generated in the builder container)
 and (b) the CPU oracle restatement run in the same process on the same seeded weights/inputs.
 
-Bar (BASELINE.json north_star): |logits_gpu - logits_cpu| <= 1e-3 in fp32 and identical argmax.
-The tolerance is scaled by max(1, max|logit| / 30) for the few synthetic cases whose logits leave
-the calibrated 10-30 range (SURVEY.md 8d asks for the relative error next to the absolute one).
+Bar (BASELINE.json north_star): |logits_gpu - logits_cpu| <= 1e-3 in fp32 and identical argmax -- applied
+unscaled (round 1 widened it by max|logit| / 30; measured errors are 1e-5 class, so the plain bar holds).
 """
 import numpy as np
 import pytest
@@ -28,11 +27,11 @@ def _build(ptx, arch, kw, seed, **recipe):
 
 
 def _check(got, want, what, tol=TOL):
+    """The stated bar, unscaled: max |got - want| <= 1e-3 (BASELINE.json north_star)."""
     got = got.detach().cpu()
-    scale = max(1.0, want.abs().max().item() / 30.0)
     err = (got - want).abs().max().item()
     assert got.shape == want.shape, what
-    assert err <= tol * scale, "%s: max abs err %.3e > %.1e (max|ref| %.2f)" % (what, err, tol * scale, want.abs().max().item())
+    assert err <= tol, "%s: max abs err %.3e > %.1e (max|ref| %.2f)" % (what, err, tol, want.abs().max().item())
     return err
 
 
@@ -479,10 +478,11 @@ def test_nonlocal_block_modes(ptx):
         blk = blk.to(DEV).eval()
         y = blk(x.to(DEV))
         torch.cuda.synchronize()
-        _check(y, torch.from_numpy(blob[tag]), "nlblock %s vs golden" % tag, 1e-4)
+        ref = torch.from_numpy(blob[tag])      # a feature map, not logits: 1e-4 of its scale (still inside the 1e-3 bar)
+        _check(y, ref, "nlblock %s vs golden" % tag, min(TOL, 1e-4 * max(1.0, ref.abs().max().item())))
         with torch.no_grad():
             want = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
-        _check(y, want, "nlblock %s vs oracle" % tag, 1e-4)
+        _check(y, want, "nlblock %s vs oracle" % tag, min(TOL, 1e-4 * max(1.0, want.abs().max().item())))
     with pytest.raises(Exception):
         ptx.NonLocalBlock3D(16, mode="gaussian", sub_sample=True).to(DEV)(torch.zeros(1, 16, 1, 4, 4, device=DEV))
 
