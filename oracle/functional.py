@@ -16,6 +16,7 @@ Reference lines followed:
   * NL-ResNet3D placement rule ...... nonlocalnet.py:456-485
   * TRN relation MLP ................ trn.py:20-56, multi-scale :59-113
   * 2-D ResNet (torchvision shape) .. torchvision_models.py:443-492 + oracle/tv_standin.py
+  * MultiViewConv / MVResNet ........ multiview.py:13-59, :82-140
 """
 import itertools
 import math
@@ -79,6 +80,10 @@ ARCHS = {
     "preact_resnet3d10": ArchCfg("preact_basic", [1, 1, 1, 1], "B", head="fc"),
     "preact_resnet3d18": ArchCfg("preact_basic", [2, 2, 2, 2], "B", head="fc"),
     "preact_resnet3d50": ArchCfg("preact_bottleneck", [3, 4, 6, 3], "B", head="fc"),
+    "mvresnet10": ArchCfg("basic", [1, 1, 1, 1], "B", conv="mv", head="fc"),
+    "mvresnet18": ArchCfg("basic", [2, 2, 2, 2], "B", conv="mv", head="fc"),
+    "mvresnet34": ArchCfg("basic", [3, 4, 6, 3], "B", conv="mv", head="fc"),
+    "mvresnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", conv="mv", head="fc"),
     "resnet18": ArchCfg("basic", [2, 2, 2, 2], "B", dims=2),
     "resnet34": ArchCfg("basic", [3, 4, 6, 3], "B", dims=2),
     "resnet50": ArchCfg("bottleneck", [3, 4, 6, 3], "B", dims=2),
@@ -122,7 +127,21 @@ def _st_conv(sd, x, p, stride, padding):
     return _conv(sd, x, p + ".temporal_conv", (st, 1, 1), (pt, 0, 0))
 
 
+def _mv_conv(sd, x, p, stride, padding):
+    """MultiViewConv.forward, multiview.py:51-59: the 2-D bank viewed as (1,k,k) / (k,1,k) / (k,k,1) kernels, each with
+    the padding of its two live axes, stacked on a new last axis and combined by Linear(3, 1)."""
+    w = sd[p + ".weight"]
+    b = sd.get(p + ".bias")
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    pt, ph, pw = _t3(padding)
+    views = [((1, k, k), (0, ph, pw)), ((k, 1, k), (pt, 0, pw)), ((k, k, 1), (pt, ph, 0))]
+    y = torch.stack([F.conv3d(x, w.view(co, ci, *ks), b, _t3(stride), pad, (1, 1, 1), 1) for ks, pad in views], -1)
+    return F.linear(y, sd[p + ".linear.weight"], sd[p + ".linear.bias"])[..., 0]
+
+
 def _any_conv(cfg, sd, x, p, stride, padding):
+    if cfg.conv == "mv":
+        return _mv_conv(sd, x, p, stride, padding)
     if cfg.conv == "2p1d":
         return _st_conv(sd, x, p, stride, padding)
     return _conv(sd, x, p, stride, padding, cfg.dims)

@@ -71,6 +71,14 @@ def import_preact():
     return importlib.import_module("pretorched.models.pre_act_resnet3D")
 
 
+def import_multiview():
+    """multiview.py:10 uses an absolute `import resnet3D`."""
+    ref = import_reference()
+    import importlib
+    sys.modules.setdefault("resnet3D", ref.models.resnet3D)
+    return importlib.import_module("pretorched.models.multiview")
+
+
 def import_wideresnet3d():
     """wideresnet3D.py:9 does `from torchvision_models import ...` (absolute)."""
     ref = import_reference()

@@ -24,7 +24,7 @@ from . import transforms  # noqa: F401
 from .biggan import BigGANDeepGenerator, biggan_deep  # noqa: F401
 from .i3d import InceptionI3d, i3d  # noqa: F401
 from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
-from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation,
+from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation, MultiViewConv,
                   NonLocalBlock3D, Relation, VideoResNet, factored_mid_channels)
 
 __version__ = "0.1.0"
@@ -249,6 +249,24 @@ preact_resnet3d152 = _preact_factory("preact_resnet3d152")
 preact_resnet3d200 = _preact_factory("preact_resnet3d200")
 
 
+def _mvresnet_factory(name):
+    def factory(num_classes=339, shortcut_type="B"):
+        return _build(name, num_classes, shortcut_type)
+    factory.__name__ = name
+    factory.__doc__ = ("Constructs a %s model (reference pretorched/models/multiview.py:95-140: MVResNet(block, layers, "
+                       "**kwargs) -- ResNet3D with every convolution a MultiViewConv; module-level upstream)." % name)
+    return factory
+
+
+mvresnet10 = _mvresnet_factory("mvresnet10")
+mvresnet18 = _mvresnet_factory("mvresnet18")
+mvresnet34 = _mvresnet_factory("mvresnet34")
+mvresnet50 = _mvresnet_factory("mvresnet50")
+mvresnet101 = _mvresnet_factory("mvresnet101")
+mvresnet152 = _mvresnet_factory("mvresnet152")
+mvresnet200 = _mvresnet_factory("mvresnet200")
+
+
 def wideresnet3d50(num_classes=400, pretrained="kinetics-400", shortcut_type="B", k=2):
     """reference wideresnet3D.py:202-210 (module-level upstream; no checkpoint URL is published for it)."""
     key = "wideresnet3d50" if k == 2 else "wideresnet3d50/k%d" % k
@@ -310,4 +328,5 @@ model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
                "resnet101", "resnet152", "trn", "i3d", "resnext3d10", "resnext3d18", "resnext3d34", "resnext3d50",
                "resnext3d101", "resnext3d152", "resnext3d200", "wideresnet3d50", "preact_resnet3d10", "preact_resnet3d18", "preact_resnet3d34",
-               "preact_resnet3d50", "preact_resnet3d101", "preact_resnet3d152", "preact_resnet3d200"]
+               "preact_resnet3d50", "preact_resnet3d101", "preact_resnet3d152", "preact_resnet3d200",
+               "mvresnet10", "mvresnet18", "mvresnet34", "mvresnet50", "mvresnet101", "mvresnet152", "mvresnet200"]

@@ -252,7 +252,9 @@ class Packed:
     def refresh(self):
         get = self.plan.get
         convs, bn = [get(c) for c in self.convs], (get(self.bn) if self.bn is not None else None)
-        if len(convs) == 1:
+        if len(convs) == 1 and hasattr(convs[0], "effective_weight_bias"):
+            w, cb = convs[0].effective_weight_bias()      # MultiViewConv: three views of one 2-D bank as a dense filter
+        elif len(convs) == 1:
             w = convs[0].weight.detach()
             cb = convs[0].bias.detach() if convs[0].bias is not None else None
         else:

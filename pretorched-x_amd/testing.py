@@ -95,6 +95,10 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
             out[key] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
             if prefix.endswith(".conv4") or prefix.endswith(".o"):      # closes a BigGAN residual / attention branch
                 out[key] = out[key] * closing_conv_damp
+        elif leaf == "weight" and shape == (1, 3) and prefix.endswith(".linear") and (prefix[:-7] + ".weight") in keys:
+            # MultiViewConv's view-mixing Linear(3, 1) (multiview.py:50): positive weights with sum of squares ~ 1, so the
+            # three-view sum keeps the signal scale of a plain conv (default Linear init would shrink it 0.58x per layer)
+            out[key] = torch.rand(shape, generator=g) * 0.6 + 0.3
         elif leaf == "weight" and len(shape) == 2:          # linear
             bound = 1.0 / shape[1] ** 0.5
             out[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound

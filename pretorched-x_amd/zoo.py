@@ -86,6 +86,15 @@ ARCHS = {
     "preact_resnet3d101": Arch("preact_bottleneck", (3, 4, 23, 3), "B", head="fc"),
     "preact_resnet3d152": Arch("preact_bottleneck", (3, 8, 36, 3), "B", head="fc"),
     "preact_resnet3d200": Arch("preact_bottleneck", (3, 24, 36, 3), "B", head="fc"),
+    # multi-view ResNets (multiview.py:82-140; module-level upstream, `import resnet3D` absolute, keep `fc`):
+    # every conv -- stem, 3x3x3, 1x1x1, shortcut B -- is a MultiViewConv
+    "mvresnet10": Arch("basic", (1, 1, 1, 1), "B", conv="mv", head="fc"),
+    "mvresnet18": Arch("basic", (2, 2, 2, 2), "B", conv="mv", head="fc"),
+    "mvresnet34": Arch("basic", (3, 4, 6, 3), "B", conv="mv", head="fc"),
+    "mvresnet50": Arch("bottleneck", (3, 4, 6, 3), "B", conv="mv", head="fc"),
+    "mvresnet101": Arch("bottleneck", (3, 4, 23, 3), "B", conv="mv", head="fc"),
+    "mvresnet152": Arch("bottleneck", (3, 8, 36, 3), "B", conv="mv", head="fc"),
+    "mvresnet200": Arch("bottleneck", (3, 24, 36, 3), "B", conv="mv", head="fc"),
     "resnet18": Arch("basic", (2, 2, 2, 2), "B", dims=2),
     "resnet34": Arch("basic", (3, 4, 6, 3), "B", dims=2),
     "resnet50": Arch("bottleneck", (3, 4, 6, 3), "B", dims=2),
@@ -111,9 +120,63 @@ def factored_mid_channels(cin, cout, k):
     return int(math.floor((kt * kh * kw * cin * cout) / (kh * kw * cin + kt * cout)))
 
 
+class MultiViewConv(nn.Module):
+    """reference multiview.py:13-59: ONE 2-D filter bank [Co, Ci, k, k] applied as three 3-D convolutions -- viewed as
+    (1,k,k), (k,1,k) and (k,k,1) kernels, each with the matching two-axis padding -- whose outputs are combined by a
+    learned Linear(3, 1).  Parameter names / order as upstream (an nn.Conv2d subclass there): `weight`, [`bias`],
+    `linear.weight`, `linear.bias`.
+
+    On the HIP engine the three views are ONE dense conv: W3[:, :, t, h, w] = a0 W[h, w] [t == pT] + a1 W[t, w] [h == pH]
+    + a2 W[t, h] [w == pW] (a = linear.weight), bias = linear.bias + conv.bias * sum(a) (`effective_weight_bias`, folded at
+    pack time like a BatchNorm) -- valid because each view's unpadded axis lines up with tap index == padding, and the
+    reference's torch.stack requires 2 * padding == k - 1 anyway (equal output extents)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False):
+        super().__init__()
+        if not isinstance(kernel_size, int):
+            raise ValueError("MultiViewConv takes one kernel extent, as upstream")
+        k = kernel_size
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, 1
+        self.kernel_size, self.stride, self.padding = (k, k, k), _triple(stride), _triple(padding)
+        if any(2 * p != k - 1 for p in self.padding):
+            raise ValueError("MultiViewConv needs 'same' padding (2 * padding == kernel_size - 1): the three views "
+                             "must produce equal extents (multiview.py:52-57)")
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.linear = nn.Linear(3, 1)
+
+    def views(self):
+        k = self.kernel_size[0]
+        pt, ph, pw = self.padding
+        return [((1, k, k), (0, ph, pw)), ((k, 1, k), (pt, 0, pw)), ((k, k, 1), (pt, ph, 0))]
+
+    def forward(self, x):        # the torch.nn path (train / CPU, eager.py): the reference's own op sequence
+        import torch.nn.functional as F
+        co, ci = self.out_channels, self.in_channels
+        y = torch.stack([F.conv3d(x, self.weight.view(co, ci, *ks), self.bias, self.stride, pad) for ks, pad in self.views()], -1)
+        return self.linear(y)[..., 0]
+
+    def effective_weight_bias(self):
+        w, a = self.weight.detach(), self.linear.weight.detach()[0]
+        k = self.kernel_size[0]
+        pt, ph, pw = self.padding
+        w3 = torch.zeros(self.out_channels, self.in_channels, k, k, k, device=w.device, dtype=w.dtype)
+        w3[:, :, pt, :, :] += a[0] * w
+        w3[:, :, :, ph, :] += a[1] * w
+        w3[:, :, :, :, pw] += a[2] * w
+        b = self.linear.bias.detach().expand(self.out_channels).clone()
+        if self.bias is not None:
+            b = b + self.bias.detach() * a.sum()
+        return w3, b
+
+
 def _conv(arch, cin, cout, k, stride=1, padding=0, bias=False):
     if arch.dims == 2:
         return nn.Conv2d(cin, cout, k, stride, padding, bias=bias)
+    if arch.conv == "mv":
+        if not isinstance(k, int):
+            k = k[0]
+        return MultiViewConv(cin, cout, k, stride, padding, bias=bias)
     if arch.conv == "2p1d":
         (kt, kh, kw), (st, sh, sw), (pt, ph, pw) = _triple(k), _triple(stride), _triple(padding)
         mid = factored_mid_channels(cin, cout, k)
@@ -281,7 +344,7 @@ class VideoResNet(EngineOwner, nn.Module):
     # -- initialisation with the reference's distributions (resnet3D.py:195-201, r2plus1d.py:103) --
     def _init_like_reference(self):
         for m in self.modules():
-            if isinstance(m, (nn.Conv3d, nn.Conv2d)):
+            if isinstance(m, (nn.Conv3d, nn.Conv2d, MultiViewConv)):          # multiview.py:86-92 for the latter
                 nn.init.kaiming_normal_(m.weight, mode="fan_out")
             elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm2d)):
                 nn.init.ones_(m.weight)

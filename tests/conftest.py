@@ -69,6 +69,9 @@ GOLDEN_CASES = {
     "wideresnet3d50_small": ("wideresnet3d50", dict(num_classes=400, pretrained=None)),
     "preact_resnet3d50_small": ("preact_resnet3d50", dict(num_classes=339)),
     "preact_resnet3d18_odd": ("preact_resnet3d18", dict(num_classes=17, shortcut_type="A")),
+    "mvresnet18_small": ("mvresnet18", dict(num_classes=339)),
+    "mvresnet50_small": ("mvresnet50", dict(num_classes=174)),
+    "mvresnet10_odd": ("mvresnet10", dict(num_classes=17)),
     "resnet3d50_cfg2": ("resnet3d50", dict(num_classes=339, pretrained=None)),
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),

@@ -52,6 +52,10 @@ CASES = {
     "wideresnet3d50_small": ("wideresnet3d50", (2, 3, 8, 64, 64), dict(num_classes=400, pretrained=None)),
     "preact_resnet3d50_small": ("preact_resnet3d50", (2, 3, 8, 64, 64), dict(num_classes=339)),
     "preact_resnet3d18_odd": ("preact_resnet3d18", (3, 3, 5, 50, 70), dict(num_classes=17, shortcut_type="A")),
+    # multi-view ResNets (multiview.py: module-level upstream, imported through the F6 shim)
+    "mvresnet18_small": ("mvresnet18", (2, 3, 8, 64, 64), dict(num_classes=339)),
+    "mvresnet50_small": ("mvresnet50", (2, 3, 8, 64, 64), dict(num_classes=174)),
+    "mvresnet10_odd": ("mvresnet10", (3, 3, 5, 50, 70), dict(num_classes=17)),
     # BASELINE.json config 3 at full size (8 x 3 x 32 x 112 x 112): the composite and its two parents
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", (8, 3, 32, 112, 112), dict(num_classes=400)),
@@ -70,6 +74,10 @@ RECIPES = {
     "resnext3d10_odd": dict(last_bn_damp=2.0),
     "resnext3d50_full": dict(last_bn_damp=2.0),
     "nonlocalresnet3d50_cfg3": dict(last_bn_damp=0.65, nl_bn_damp=0.05),
+    # MultiViewConv: a 1x1x1 conv's three views are identical, so it gains sum(a) ~ 1.8 per layer: damp per block
+    "mvresnet50_small": dict(last_bn_damp=0.19),
+    "mvresnet18_small": dict(last_bn_damp=0.55),
+    "mvresnet10_odd": dict(last_bn_damp=1.1),
 }
 
 
@@ -165,7 +173,7 @@ def main():
 
     # (2+1)D reference models must be *built and run* before any resnet3d* factory patches
     # ResNet3D.forward at class level -- so handle them first.
-    order = sorted(CASES, key=lambda n: 0 if ("r2plus1d" in n or "preact" in n) else 1)
+    order = sorted(CASES, key=lambda n: 0 if ("r2plus1d" in n or "preact" in n or "mvresnet" in n) else 1)
     for case in order:
         if only and case not in only:
             continue
@@ -178,6 +186,8 @@ def main():
             model = getattr(ref_shim.import_preact(), arch)(**kw)
         elif arch.startswith("wideresnet"):
             model = getattr(ref_shim.import_wideresnet3d(), arch)(**kw)
+        elif arch.startswith("mvresnet"):
+            model = getattr(ref_shim.import_multiview(), arch)(**kw)
         else:
             model = ref.__dict__[arch](**kw)
         model.eval()
@@ -193,7 +203,7 @@ def main():
             g = torch.Generator().manual_seed(X_SEED)
             x = torch.randn(*shape, generator=g)
         with torch.no_grad():
-            if hasattr(model, "features") and not arch.startswith(("r2plus1d", "resnext", "wideresnet", "preact")):
+            if hasattr(model, "features") and not arch.startswith(("r2plus1d", "resnext", "wideresnet", "preact", "mvresnet")):
                 feat = model.features(x)
                 logits = model.logits(feat)
             else:   # R2Plus1D keeps ResNet3D.forward / fc (r2plus1d.py:99-110)

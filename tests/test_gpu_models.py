@@ -580,7 +580,7 @@ def test_weight_edits_through_data_need_refresh_or_checksum(ptx):
 
 
 X3_CASES = ["resnet3d50_small", "resnet3d50_odd", "resnet3d18_small", "nonlocalresnet3d50_small", "r2plus1d50_small",
-            "nonlocal_r2plus1d50_small", "resnet18_cfg1"]
+            "nonlocal_r2plus1d50_small", "resnet18_cfg1", "mvresnet50_small"]
 
 
 @pytest.mark.parametrize("case", X3_CASES)

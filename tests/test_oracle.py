@@ -351,3 +351,36 @@ def test_reference_densenet3d_cannot_be_constructed():
     dn = importlib.import_module("pretorched.models.densenet3D")
     with pytest.raises(KeyError, match="module name can"):
         dn.DenseNet(num_init_features=8, growth_rate=4, block_config=(1, 1, 1, 1), sample_size=32, sample_duration=8)
+
+
+@needs_ref
+def test_oracle_multiview_bit_equal_to_reference(ptx):
+    """multiview.py (MVResNet: ResNet3D with every conv a MultiViewConv; module-level upstream, imported through the F6
+    shim): state_dict ABI equal, oracle bit-equal to the reference forward, the product's torch.nn path (CPU model)
+    bit-equal too, and the dense 3-D filter the HIP engine packs (`effective_weight_bias`) equivalent to the module."""
+    mv = ref_shim.import_multiview()
+    for name, shape in (("mvresnet18", (2, 3, 8, 64, 64)), ("mvresnet50", (1, 3, 5, 48, 64))):
+        ref = getattr(mv, name)(num_classes=17).eval()
+        mine = getattr(ptx, name)(num_classes=17)
+        assert [(k, tuple(v.shape)) for k, v in ref.state_dict().items()] == \
+               [(k, tuple(v.shape)) for k, v in mine.state_dict().items()]
+        sd = synth_state_dict(ref.state_dict(), 1234, last_bn_damp=0.4)
+        ref.load_state_dict(sd)
+        mine.load_state_dict(sd)
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(99))
+        with torch.no_grad():
+            # ResNet3D.forward as written (resnet3D.py:203-218): the class attribute may have been replaced by
+            # modify_resnets earlier in this process (SURVEY.md F7), so the op sequence is spelled out
+            h = ref.maxpool(ref.relu(ref.bn1(ref.conv1(x))))
+            h = ref.avgpool(ref.layer4(ref.layer3(ref.layer2(ref.layer1(h)))))
+            want = ref.fc(h.view(h.size(0), -1))
+            assert torch.equal(OF.forward(OF.ARCHS[name], sd, x), want), name
+            assert torch.equal(mine(x), want), name
+        conv = mine.layer2[0].conv2 if hasattr(mine.layer2[0], "conv3") else mine.layer2[0].conv1     # a strided 3x3x3
+        xin = torch.randn(1, conv.in_channels, 5, 9, 10, generator=torch.Generator().manual_seed(5))
+        w3, b3 = conv.effective_weight_bias()
+        with torch.no_grad():
+            dense = torch.nn.functional.conv3d(xin, w3, b3, conv.stride, conv.padding)
+            assert (dense - conv(xin)).abs().max().item() <= 1e-5 * max(1.0, dense.abs().max().item())
+    with pytest.raises(ValueError):
+        ptx.MultiViewConv(4, 4, 3, padding=0)          # views of unequal extents: the reference's stack would fail
