@@ -158,16 +158,18 @@ def shortcut_a(x, planes, stride):
 # non-local block
 # --------------------------------------------------------------------------------------------
 def nonlocal_block(sd, x, p, mode="embedded_gaussian", sub_sample=False, bn_layer=True):
-    """_NonLocalBlockND for dimension=3 (nonlocalnet.py:139-243)."""
+    """_NonLocalBlockND (nonlocalnet.py:139-243); the dimension (1 / 2 / 3, :246-270) is read off the input."""
     b, c = x.shape[:2]
     gk = p + ".g.0" if sub_sample else p + ".g"
     ci = sd[gk + ".weight"].shape[0]
+    conv_nd = {3: F.conv1d, 4: F.conv2d, 5: F.conv3d}[x.dim()]
+    pool_nd = {3: F.max_pool1d, 4: F.max_pool2d, 5: F.max_pool3d}[x.dim()]
 
     def pw(key, inp):
-        return F.conv3d(inp, sd[key + ".weight"], sd.get(key + ".bias"))
+        return conv_nd(inp, sd[key + ".weight"], sd.get(key + ".bias"))
 
     def pool(t):
-        return F.max_pool3d(t, 2) if sub_sample else t
+        return pool_nd(t, 2) if sub_sample else t
 
     g_x = pool(pw(gk, x)).reshape(b, ci, -1).permute(0, 2, 1)
     if mode == "gaussian":
@@ -195,6 +197,23 @@ def nonlocal_block(sd, x, p, mode="embedded_gaussian", sub_sample=False, bn_laye
     else:
         w_y = pw(p + ".W", y)
     return w_y + x
+
+
+def mnist_nonlocal_forward(sd, x):
+    """MNISTNonLocalNet.forward (nonlocalnet.py:273-309): `convs` = [conv3x3(bias), BN, ReLU, MaxPool2d(2)] x 3 with a
+    NonLocalBlock2D at indices 4 and 9; `fc` = Linear, ReLU, Dropout (identity in eval), Linear."""
+    with torch.no_grad():
+        for i in (0, 5, 10):
+            p = "convs.%d" % i
+            x = F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], 1, 1)
+            q = "convs.%d" % (i + 1)
+            x = F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.1, BN_EPS)
+            x = F.max_pool2d(F.relu(x), 2)
+            if i < 10:
+                x = nonlocal_block(sd, x, "convs.%d" % (i + 4))
+        x = x.view(x.size(0), -1)
+        x = F.relu(F.linear(x, sd["fc.0.weight"], sd["fc.0.bias"]))
+        return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"])
 
 
 # --------------------------------------------------------------------------------------------

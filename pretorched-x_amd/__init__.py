@@ -24,8 +24,8 @@ from . import transforms  # noqa: F401
 from .biggan import BigGANDeepGenerator, biggan_deep  # noqa: F401
 from .i3d import InceptionI3d, i3d  # noqa: F401
 from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
-from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MultiScaleHierarchicalRelation, MultiScaleRelation, MultiViewConv,
-                  NonLocalBlock3D, Relation, VideoResNet, factored_mid_channels)
+from .zoo import (ARCHS, TRN, Arch, HierarchicalRelation, MNISTNonLocalNet, MultiScaleHierarchicalRelation, MultiScaleRelation, MultiViewConv,
+                  NonLocalBlock1D, NonLocalBlock2D, NonLocalBlock3D, Relation, VideoResNet, factored_mid_channels)
 
 __version__ = "0.1.0"
 

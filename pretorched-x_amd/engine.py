@@ -149,6 +149,8 @@ def _geom(conv):
     k, s, p = conv.kernel_size, conv.stride, conv.padding
     if isinstance(conv, nn.Conv2d):
         return (1,) + tuple(k), (1,) + tuple(s), (0,) + tuple(p)
+    if isinstance(conv, nn.Conv1d):
+        return (1, 1) + tuple(k), (1, 1) + tuple(s), (0, 0) + tuple(p)
     return tuple(k), tuple(s), tuple(p)
 
 
@@ -667,9 +669,12 @@ class Plan:
             tpg = self.conv(x, self.pack([nl.theta, first(nl.phi), g_conv], None), one, zero, label=label + ".theta_phi_g")
             th_act, ph_act, g_act = tpg.slice(0, ci), tpg.slice(ci, ci), tpg.slice(2 * ci, ci)
         if sub:
-            pool = ((2, 2, 2), (2, 2, 2), (0, 0, 0))          # nn.MaxPool3d(kernel_size=2): stride 2, floor
-            if min(x.T, x.H, x.W) < 2:
-                raise PtxError("%s: sub_sample needs at least 2 positions along T, H and W" % label)
+            # nn.MaxPool{1,2,3}d(kernel_size=2): stride 2, floor -- over the block's own axes (a 2-D block runs as T = 1)
+            dim = int(getattr(nl, "dimension", 3))
+            win = (1,) * (3 - dim) + (2,) * dim
+            pool = (win, win, (0, 0, 0))
+            if any(e < w for e, w in zip((x.T, x.H, x.W), win)):
+                raise PtxError("%s: sub_sample needs at least 2 positions along every pooled axis" % label)
             ph_act = self.maxpool(ph_act, *pool)
             g_act = self.maxpool(g_act, *pool)
         N, Sq, Sk, K = x.N, x.S, ph_act.S, th_act.C

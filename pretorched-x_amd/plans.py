@@ -173,6 +173,36 @@ def build_i3d(self, model):
     self.head = head
 
 # --------------------------------------------------------------------------------------------
+# MNISTNonLocalNet (nonlocalnet.py:273-309)
+def build_mnist_nl(self, model):
+    N, Cin, H, W = self.shape
+    x = self.to_channels_last(RawInput(N, Cin, 1, H, W))
+    for i in (0, 5, 10):                          # conv3x3 (bias) + BN + ReLU as one launch, MaxPool2d(2), NL block
+        x = self.conv_bn(x, model.convs[i], model.convs[i + 1], relu=True, label="convs.%d" % i)
+        x = self.maxpool(x, (1, 2, 2), (1, 2, 2), (0, 0, 0))
+        if i < 10:
+            x = self.nonlocal_block(x, model.convs[i + 4], "convs.%d" % (i + 4))
+    self.feat = x
+    self.pooled = None
+    if x.C * x.H * x.W != model.fc[0].in_features:
+        self.head = None
+        self.head_error = ("MNISTNonLocalNet: fc expects %d features (a 28x28 input), the conv stack produced %dx%dx%d" % (
+            model.fc[0].in_features, x.C, x.H, x.W))
+        return
+    flat = torch.empty((N, x.C, x.H, x.W), device=self.dev, dtype=torch.float32)      # NCHW: `.view(batch, -1)` order
+    self.keepalive.append(flat)
+    lib = self.lib
+
+    def head(engine, model, x=x, flat=flat):
+        from ._lib import PTX_EPI_RELU
+        from .engine import linear
+        check(lib.ptx_ndhwc_to_ncdhw(_ptr(x.t), _ptr(flat), x.N, x.C, x.S, x.ld, _stream()), "ptx_ndhwc_to_ncdhw")
+        h = linear(flat.view(x.N, -1), model.fc[0], PTX_EPI_RELU)          # Dropout is the identity in eval mode
+        return linear(h, model.fc[3])
+    self.head = head
+
+
+# --------------------------------------------------------------------------------------------
 # BigGAN-deep generator
 def build_biggan(self, model):
     N = self.shape[0]

@@ -203,38 +203,44 @@ def _nonlocal(channels):
     return nl
 
 
-class NonLocalBlock3D(EngineOwner, nn.Module):
+class _NonLocalBlockND(EngineOwner, nn.Module):
     """Standalone non-local block with the reference's constructor and parameter names
-    (nonlocalnet.py:51-131, :264-270): z = W(y) + x over [B,C,T,H,W].  HIP path: modes embedded_gaussian,
-    dot_product, gaussian and concatenation, with or without `sub_sample` / `bn_layer`."""
+    (nonlocalnet.py:51-131; NonLocalBlock1D / 2D / 3D :246-270): z = W(y) + x over [B,C,L] / [B,C,H,W] / [B,C,T,H,W].
+    HIP path: modes embedded_gaussian, dot_product, gaussian and concatenation, with or without `sub_sample` /
+    `bn_layer`.  The block is pointwise convs + attention over positions, so the 1-D and 2-D variants run as the
+    T = 1 (and H = 1) case of the same plan; only the `sub_sample` pooling window depends on the dimension."""
     plan_kind = "nlblock"
+    dimension = 3
 
     def __init__(self, in_channels, inter_channels=None, mode="embedded_gaussian", sub_sample=False, bn_layer=True):
         super().__init__()
         assert mode in ["embedded_gaussian", "gaussian", "dot_product", "concatenation"]
-        self.mode, self.dimension, self.sub_sample, self.bn_layer = mode, 3, sub_sample, bn_layer
+        assert self.dimension in (1, 2, 3)
+        Conv, Pool, Norm = {3: (nn.Conv3d, nn.MaxPool3d, nn.BatchNorm3d), 2: (nn.Conv2d, nn.MaxPool2d, nn.BatchNorm2d),
+                            1: (nn.Conv1d, nn.MaxPool1d, nn.BatchNorm1d)}[self.dimension]
+        self.mode, self.sub_sample, self.bn_layer = mode, sub_sample, bn_layer
         self.in_channels = in_channels
         self.inter_channels = inter_channels if inter_channels is not None else max(in_channels // 2, 1)
         ci = self.inter_channels
         self.arch = Arch("nlblock", (), "B")
-        self.g = nn.Conv3d(in_channels, ci, 1)
+        self.g = Conv(in_channels, ci, 1)
         if bn_layer:
-            self.W = nn.Sequential(nn.Conv3d(ci, in_channels, 1), nn.BatchNorm3d(in_channels))
+            self.W = nn.Sequential(Conv(ci, in_channels, 1), Norm(in_channels))
             nn.init.constant_(self.W[1].weight, 0)
             nn.init.constant_(self.W[1].bias, 0)
         else:
-            self.W = nn.Conv3d(ci, in_channels, 1)
+            self.W = Conv(ci, in_channels, 1)
             nn.init.constant_(self.W.weight, 0)
             nn.init.constant_(self.W.bias, 0)
         self.theta = self.phi = self.concat_project = None
         if mode in ("embedded_gaussian", "dot_product", "concatenation"):
-            self.theta = nn.Conv3d(in_channels, ci, 1)
-            self.phi = nn.Conv3d(in_channels, ci, 1)
+            self.theta = Conv(in_channels, ci, 1)
+            self.phi = Conv(in_channels, ci, 1)
             if mode == "concatenation":
                 self.concat_project = nn.Sequential(nn.Conv2d(ci * 2, 1, 1, 1, 0, bias=False), nn.ReLU())
         if sub_sample:
-            self.g = nn.Sequential(self.g, nn.MaxPool3d(kernel_size=2))
-            self.phi = nn.MaxPool3d(kernel_size=2) if self.phi is None else nn.Sequential(self.phi, nn.MaxPool3d(kernel_size=2))
+            self.g = nn.Sequential(self.g, Pool(kernel_size=2))
+            self.phi = Pool(kernel_size=2) if self.phi is None else nn.Sequential(self.phi, Pool(kernel_size=2))
         self.eval()
         self._init_engine()
 
@@ -242,7 +248,53 @@ class NonLocalBlock3D(EngineOwner, nn.Module):
         if eager.wanted(self, x):          # train() / autograd / CPU tensors: the torch.nn path (eager.py)
             eager._count()
             return eager.nonlocal_block(self, x)
+        if isinstance(x, torch.Tensor) and x.dim() == self.dimension + 2 and self.dimension < 3:
+            b, c = x.shape[:2]
+            lead = (1,) * (3 - self.dimension)
+            return self._engine.features(self, x.reshape(b, c, *lead, *x.shape[2:])).reshape(x.shape)
         return self._engine.features(self, x)
+
+
+class NonLocalBlock3D(_NonLocalBlockND):
+    dimension = 3
+
+
+class NonLocalBlock2D(_NonLocalBlockND):
+    """nonlocalnet.py:255-261."""
+    dimension = 2
+
+
+class NonLocalBlock1D(_NonLocalBlockND):
+    """nonlocalnet.py:246-252."""
+    dimension = 1
+
+
+class MNISTNonLocalNet(EngineOwner, nn.Module):
+    """reference nonlocalnet.py:273-309: three conv3x3 (bias) -> BN -> ReLU -> MaxPool2d(2) stages over a 1x28x28 image
+    with a NonLocalBlock2D before the second and third conv, then Linear(128*3*3, 256) -> ReLU -> Dropout -> Linear(256, 10).
+    Same module tree / state_dict keys (`convs.{0..14}.*`, `fc.{0,3}.*`)."""
+    plan_kind = "mnist_nl"
+
+    def __init__(self):
+        super().__init__()
+        self.arch = Arch("mnist_nl", (), "B", dims=2)
+        self.convs = nn.Sequential(
+            nn.Conv2d(1, 32, 3, 1, 1), nn.BatchNorm2d(32), nn.ReLU(), nn.MaxPool2d(2),
+            NonLocalBlock2D(32), nn.Conv2d(32, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2),
+            NonLocalBlock2D(64), nn.Conv2d(64, 128, 3, 1, 1), nn.BatchNorm2d(128), nn.ReLU(), nn.MaxPool2d(2))
+        self.fc = nn.Sequential(nn.Linear(128 * 3 * 3, 256), nn.ReLU(), nn.Dropout(0.5), nn.Linear(256, 10))
+        self.eval()
+        self._init_engine()
+
+    @property
+    def head_module(self):
+        return self.fc
+
+    def forward(self, x):
+        if eager.wanted(self, x):          # train() / autograd / CPU: the module tree itself (nonlocalnet.py:304-308)
+            eager._count()
+            return self.fc(self.convs(x).view(x.size(0), -1))
+        return self._engine.forward(self, x)
 
 
 def _block(arch, cin, planes, stride, with_down, with_nl):

@@ -234,6 +234,8 @@ def main():
         make_trn(ref, trn, keys_out)
     if not only or "nlblock" in only:
         make_nlblock(ref, keys_out)
+    if not only or "mnist_nl" in only:
+        make_mnist_nl(ref, keys_out)
     if not only or any(c.startswith("slowfast") for c in only):
         make_slowfast(ref, keys_out, only)
     json.dump(keys_out, open(keys_path, "w"))
@@ -242,6 +244,20 @@ def main():
 NL_CASES = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
             ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
             ("concatenation", False, True), ("concatenation", True, False)]
+
+
+def make_mnist_nl(ref, keys_out):
+    """MNISTNonLocalNet (nonlocalnet.py:273-309) on a batch of 28x28 single-channel images."""
+    net = ref.models.nonlocalnet.MNISTNonLocalNet().eval()
+    sd = synth_state_dict(net.state_dict(), W_SEED, nl_bn_damp=1.0)
+    net.load_state_dict(sd)
+    x = torch.randn(6, 1, 28, 28, generator=torch.Generator().manual_seed(X_SEED))
+    keys_out["mnist_nl"] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    with torch.no_grad():
+        y = net(x)
+    np.savez_compressed(os.path.join(OUT, "mnist_nl.npz"), logits=y.numpy(), shape=np.array(x.shape), w_seed=W_SEED,
+                        x_seed=X_SEED, recipe=np.array(json.dumps(dict(nl_bn_damp=1.0))))
+    print("mnist_nl logits", tuple(y.shape), "max|.|=%.3f" % y.abs().max().item(), y.argmax(1).tolist())
 
 
 def make_nlblock(ref, keys_out):
@@ -259,6 +275,20 @@ def make_nlblock(ref, keys_out):
             blob[tag] = blk(x).numpy()
     np.savez_compressed(os.path.join(OUT, "nlblock.npz"), **blob)
     print("nlblock modes", [k for k in blob if k not in ("shape", "w_seed", "x_seed")])
+    # NonLocalBlock2D / NonLocalBlock1D (nonlocalnet.py:246-261): the same block over [B,C,H,W] / [B,C,L]
+    for dim, cls, shape in ((2, "NonLocalBlock2D", (2, 16, 10, 12)), (1, "NonLocalBlock1D", (3, 16, 30))):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(X_SEED))
+        blob = dict(shape=np.array(x.shape), w_seed=W_SEED, x_seed=X_SEED)
+        for mode, sub, bn in NL_CASES:
+            blk = getattr(nl, cls)(16, mode=mode, sub_sample=sub, bn_layer=bn).eval()
+            sd = synth_state_dict(blk.state_dict(), W_SEED)
+            blk.load_state_dict(sd)
+            tag = "%s_%d_%d" % (mode, sub, bn)
+            keys_out["nlblock%dd_%s" % (dim, tag)] = [[k, list(v.shape)] for k, v in blk.state_dict().items()]
+            with torch.no_grad():
+                blob[tag] = blk(x).numpy()
+        np.savez_compressed(os.path.join(OUT, "nlblock%dd.npz" % dim), **blob)
+        print("nlblock%dd modes" % dim, len(NL_CASES))
 
 
 def make_trn(ref, trn, keys_out):

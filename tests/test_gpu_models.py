@@ -487,6 +487,51 @@ def test_nonlocal_block_modes(ptx):
         ptx.NonLocalBlock3D(16, mode="gaussian", sub_sample=True).to(DEV)(torch.zeros(1, 16, 1, 4, 4, device=DEV))
 
 
+def test_mnist_nonlocal_net(ptx):
+    """MNISTNonLocalNet (nonlocalnet.py:273-309) on the GPU against the real reference's logits (golden) and the oracle:
+    single-channel 3x3 convs with bias + BN + ReLU, MaxPool2d(2), two 2-D non-local blocks (fused attention), the
+    NCHW-ordered flatten and the two-layer classifier."""
+    blob = load_golden("mnist_nl")
+    x = golden_input(blob)
+    net = ptx.MNISTNonLocalNet()
+    sd = synth_state_dict(net.state_dict(), **golden_recipe(blob))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    y = net(x.to(DEV))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(blob["logits"])
+    _check(y, ref, "mnist_nl vs golden", 1e-4)
+    assert torch.equal(y.cpu().argmax(1), ref.argmax(1))
+    _check(y, OF.mnist_nonlocal_forward(sd, x), "mnist_nl vs oracle", 1e-4)
+    with pytest.raises(ptx.PtxError):
+        net(torch.zeros(2, 1, 32, 32, device=DEV))
+
+
+@pytest.mark.parametrize("dim", [1, 2])
+def test_nonlocal_block_1d_2d(ptx, dim):
+    """NonLocalBlock1D / NonLocalBlock2D (nonlocalnet.py:246-261) on the GPU -- the T = 1 (H = 1) case of the 3-D plan
+    with a dimension-aware sub_sample window -- against the real reference's outputs (golden) and the oracle."""
+    blob = load_golden("nlblock%dd" % dim)
+    x = golden_input(blob)
+    cls = {1: ptx.NonLocalBlock1D, 2: ptx.NonLocalBlock2D}[dim]
+    for mode, sub, bn in [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
+                          ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
+                          ("concatenation", False, True), ("concatenation", True, False)]:
+        tag = "%s_%d_%d" % (mode, sub, bn)
+        blk = cls(16, mode=mode, sub_sample=sub, bn_layer=bn)
+        sd = synth_state_dict(blk.state_dict(), int(blob["w_seed"]))
+        blk.load_state_dict(sd)
+        blk = blk.to(DEV).eval()
+        y = blk(x.to(DEV))
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == tuple(x.shape)
+        ref = torch.from_numpy(blob[tag])
+        _check(y, ref, "nlblock%dd %s vs golden" % (dim, tag), min(TOL, 1e-4 * max(1.0, ref.abs().max().item())))
+        with torch.no_grad():
+            want = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
+        _check(y, want, "nlblock%dd %s vs oracle" % (dim, tag), min(TOL, 1e-4 * max(1.0, want.abs().max().item())))
+
+
 def test_i3d_forward_frames(ptx):
     """uint8 frames through the SAME-padded kW-folded I3D stem (the fold consumes the front pad of SAME)."""
     from oracle import i3d_standin as I3

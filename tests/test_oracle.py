@@ -339,6 +339,53 @@ def test_oracle_nlblock_golden(ptx):
         m.engine().dry_plan(m, (1, 16, 1, 4, 4))
 
 
+@pytest.mark.parametrize("dim", [1, 2])
+def test_oracle_nlblock_1d_2d_golden(ptx, dim):
+    """NonLocalBlock1D / NonLocalBlock2D (nonlocalnet.py:246-261): parameter names / shapes (Conv1d / Conv2d kernels,
+    BatchNorm1d / 2d) equal to the reference's, oracle and the product's torch.nn path equal to the reference outputs,
+    and the plan compiles them as the T = 1 (H = 1) case with a dimension-aware sub_sample window."""
+    blob = load_golden("nlblock%dd" % dim)
+    x = golden_input(blob)
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    cls = {1: ptx.NonLocalBlock1D, 2: ptx.NonLocalBlock2D}[dim]
+    for mode, sub, bn in NL_CASES:
+        tag = "%s_%d_%d" % (mode, sub, bn)
+        blk = cls(16, mode=mode, sub_sample=sub, bn_layer=bn)
+        assert [[k, list(v.shape)] for k, v in blk.state_dict().items()] == keys["nlblock%dd_%s" % (dim, tag)], tag
+        sd = synth_state_dict(blk.state_dict(), int(blob["w_seed"]))
+        blk.load_state_dict(sd)
+        with torch.no_grad():
+            y = OF.nonlocal_block({"b." + k: v for k, v in sd.items()}, x, "b", mode, sub, bn)
+            assert torch.equal(blk(x), y), tag                   # CPU model: the torch.nn path
+        assert np.abs(y.numpy() - blob[tag]).max() <= GOLDEN_TOL, tag
+        lead = (1,) * (3 - dim)
+        plan = blk.engine().dry_plan(blk, (x.shape[0], 16) + lead + tuple(x.shape[2:]))
+        assert len(plan.conv_steps) >= 2
+
+
+def test_oracle_mnist_nonlocal_net_golden(ptx):
+    """MNISTNonLocalNet (nonlocalnet.py:273-309): module tree / state_dict ABI equal to the reference's, oracle and the
+    product's torch.nn path equal to the reference logits, plan = 7 conv launches + 2 fused attentions + 3 pools."""
+    blob = load_golden("mnist_nl")
+    x = golden_input(blob)
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))["mnist_nl"]
+    net = ptx.MNISTNonLocalNet()
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == keys
+    sd = synth_state_dict(net.state_dict(), **golden_recipe(blob))
+    net.load_state_dict(sd)
+    want = torch.from_numpy(blob["logits"])
+    y = OF.mnist_nonlocal_forward(sd, x)
+    assert (y - want).abs().max().item() <= GOLDEN_TOL and torch.equal(y.argmax(1), want.argmax(1))
+    with torch.no_grad():
+        assert torch.equal(net(x), y)                            # CPU model: the torch.nn path
+    plan = net.engine().dry_plan(net, tuple(x.shape))
+    assert [s.label for s in plan.conv_steps] == ["convs.0", "convs.4.theta_phi_g", "convs.4.W", "convs.5",
+                                                  "convs.9.theta_phi_g", "convs.9.W", "convs.10"]
+    assert getattr(plan, "attn_steps", 0) == 2 and plan.head is not None
+    bad = net.engine().dry_plan(net, (2, 1, 32, 32))             # fc is sized for 28x28 inputs, as upstream
+    assert bad.head is None and "28x28" in bad.head_error
+
+
 @needs_ref
 def test_reference_densenet3d_cannot_be_constructed():
     """SURVEY.md 8(f) N1 tail: the reference's DenseNet3D (`pretorched/models/densenet3D.py:131`) registers children
