@@ -368,9 +368,14 @@ def main():
                         f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
                             lab, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
                             stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, stp.split, ms, 2e-9 * macs / ms))
+                    for lab, kind, nb, macs, ms, _ in rows3:
+                        if kind != "conv":
+                            f.write("%-34s %-5s bytes=%-12d macs=%-14d %8.4f ms %8.1f TF\n" % (lab, kind, nb, macs, ms, 2e-9 * macs / ms))
             conv3 = [r for r in rows3 if r[1] == "conv"]
             byk = {}
-            for lab, kind, nb, macs, ms, cfg in conv3:
+            # the direct split-operand stem (ptx_conv_stem_x3_fwd) is a conv too, with its own kernel
+            for lab, kind, nb, macs, ms, cfg in conv3 + [(r[0], "conv", 0, r[3], r[4], "conv_stem_x3") for r in rows3
+                                                          if r[1] == "mfma" and r[0].startswith("conv1")]:
                 k = byk.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
                 k["ms"] += ms
                 k["flop"] += 2.0 * macs
@@ -383,7 +388,7 @@ def main():
                                   "fp32 accumulate; activations / epilogues / outputs fp32",
                      "value": round(rate3, 2), "unit": "%s/s" % unit, "ms_per_step": round(1e3 * el3 / args.steps, 4),
                      "speedup_vs_fp32_mfma": round(rate3 / (clips_per_s / world), 3),
-                     "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<%s>" % dn,
+                     "roofline": {"bound": "mfma", "kernel": ("conv_igemm_kernel<%s>" % dn) if dn != "conv_stem_x3" else "conv_stem_x3_kernel",
                                   "achieved": round(dv["flop"] / dv["ms"] / 1e9, 2), "peak": round(peak3, 1),
                                   "unit": "TFLOP/s (algorithmic fp32-equivalent; peak = 2500 dense f16 / 3 MFMAs per product)",
                                   "frac": round(dv["flop"] / dv["ms"] / 1e9 / peak3, 4), "launches_per_step": dv["launches"],

@@ -151,6 +151,21 @@ int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* desc, const float* x, const float
                         const float* w_packed, const float* bias, float* y, void* workspace,
                         size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
 
+/* Small-Cin STEM convolution with split operands (PTX_F16X3_OPERANDS), read straight from a channels-last input whose
+ * positions are 16 bytes (Ci <= 4, ldx == 4) -- `conv1` of the ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D
+ * stems, the (1,7,7) spatial stem of R2Plus1D (r2plus1d.py:73-88).  A workgroup stages the input patch of one temporal
+ * tap ((R-1)*sH + kH rows of (Wo-1)*sW + 8 positions) once and serves all kH x kW taps from it: ~6x less L2 -> LDS
+ * traffic than the kW-folded implicit GEMM and no fold pass.  desc: Ci <= 4, ldx = 4, Kc = 32, kW <= 8, stride_w <= 2,
+ * symmetric padding, flags within PTX_F16X3_OPERANDS | PTX_EPI_RELU.  x: the output of ptx_ncdhw_to_split4 (16-byte
+ * positions holding (hi4 | lo4) halfs of 4 channels).  w_packed: ptx_pack_conv_weight with fold_kw = 1, Ci = 4
+ * (channel 3 zero), Kc = 32, f16 = 2.  ptx_conv_stem_x3_supported: 1 if the descriptor can run here.                  */
+/* x [N][C][S] fp32, C <= 4  ->  y [N][S] positions of 16 bytes: halfs (hi c0..c3 | lo c0..c3), hi = half(v),
+ * lo = half(v - hi); missing channels are zero.  The NCDHW -> channels-last edge of a split-operand stem.            */
+int ptx_ncdhw_to_split4(const float* x, void* y, int32_t N, int32_t C, int64_t S, ptx_stream_t stream);
+int ptx_conv_stem_x3_supported(const ptx_conv3d_desc* desc);
+int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_packed, const float* bias, float* y,
+                         ptx_stream_t stream);
+
 /* Operands of the fused generator-stage epilogue (see PTX_EPI_AFFINE / PTX_EPI_DUAL_RAW). */
 typedef struct ptx_conv_fused_ext {
     const float* scale;   /* [N][ld_affine] per-sample, per-output-channel scale (ptx_cbn_fold)  */

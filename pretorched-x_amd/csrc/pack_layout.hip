@@ -353,10 +353,64 @@ static int check_layout_args(const void* x, const void* y, int N, int C, int64_t
     return PTX_OK;
 }
 
+// C <= 4 channels -> 16-byte positions (the split-operand stem's input): every thread gathers its position's channels
+// from C coalesced planes and writes one float4 -- the 32 x 32 tile transpose above spends 29 of its 32 channel rows
+// on padding for an RGB clip (1.6 TB/s; this one streams at the HBM rate)
+__global__ void __launch_bounds__(256) ncs_to_ns4_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                         long long S, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / S, sp = i - n * S;
+        const float* xn = x + (size_t)n * C * S + sp;
+        f32x4 v = {xn[0], 0.f, 0.f, 0.f};
+        if (C > 1) v.y = xn[S];
+        if (C > 2) v.z = xn[2 * S];
+        if (C > 3) v.w = xn[3 * S];
+        *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = v;
+    }
+}
+
+// The split-operand stem's input format: one 16-byte position = 4 channels as (hi4 | lo4) halfs, hi = half(v),
+// lo = half(v - hi) -- the split the x3 tiles do in registers, done once here, in the pass that leaves NCDHW anyway.
+typedef _Float16 half8_s __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) ncs_to_split4_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                            long long S, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / S, sp = i - n * S;
+        const float* xn = x + (size_t)n * C * S + sp;
+        float v[4] = {xn[0], 0.f, 0.f, 0.f};
+        if (C > 1) v[1] = xn[S];
+        if (C > 2) v[2] = xn[2 * S];
+        if (C > 3) v[3] = xn[3 * S];
+        half8_s o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const _Float16 h = (_Float16)v[c];
+            o[c] = h;
+            o[4 + c] = (_Float16)(v[c] - (float)h);
+        }
+        *reinterpret_cast<half8_s*>(y + (size_t)i * 4) = o;
+    }
+}
+
+extern "C" int ptx_ncdhw_to_split4(const float* x, void* y, int32_t N, int32_t C, int64_t S, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "ncdhw_to_split4: null pointer");
+    if (N <= 0 || C <= 0 || C > 4 || S <= 0 || (((uintptr_t)y) & 15)) return fail(PTX_ERR_INVALID, "ncdhw_to_split4: 1..4 channels, 16-byte aligned output");
+    const long long total = (long long)N * S;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, (long long)kNumCU * 32);
+    hipLaunchKernelGGL(ncs_to_split4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, static_cast<float*>(y), C, (long long)S, total);
+    return hip_check(hipGetLastError(), "ncdhw_to_split4 launch");
+}
+
 extern "C" int ptx_ncdhw_to_ndhwc(const float* x, float* y, int32_t N, int32_t C, int64_t S, int32_t ld,
                                   ptx_stream_t stream) {
     int s = check_layout_args(x, y, N, C, S, ld);
     if (s) return s;
+    if (C <= 4 && ld == 4 && (((uintptr_t)y) & 15) == 0) {
+        const long long total = (long long)N * S;
+        const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, (long long)kNumCU * 32);
+        hipLaunchKernelGGL(ncs_to_ns4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)S, total);
+        return hip_check(hipGetLastError(), "ncdhw_to_ndhwc launch");
+    }
     dim3 grid((unsigned)cdiv64(S, 32), (unsigned)cdiv(ld, 32), (unsigned)N);
     hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)S, ld);
     return hip_check(hipGetLastError(), "ncdhw_to_ndhwc launch");

@@ -208,8 +208,9 @@ class _Ref:
 class Packed:
     """BN-folded, K-major filter + bias living on one device; refreshable in place."""
 
-    def __init__(self, plan, convs, bn, fold_kw=False, scale=None, f16=False, x3=None):
+    def __init__(self, plan, convs, bn, fold_kw=False, scale=None, f16=False, x3=None, stem4=False):
         dev = plan.dev
+        self.stem4 = bool(stem4)     # direct split-operand stem (ptx_conv_stem_x3_fwd): Cin zero-padded to 4, kW folded
         self.plan = plan
         self.f16 = bool(f16)         # filter stored as halfs for an fp16-operand conv
         # split operands (Engine.precision == "x3"): every dense fp32 filter is packed as (hi8 | lo8) half blocks
@@ -226,6 +227,8 @@ class Packed:
             raise PtxError("grouped convolutions are packed one at a time, unfolded")
         self.Ci = c0.in_channels // self.groups      # K extent of one filter row (per group)
         self.real_ci = self.Ci
+        if self.stem4:
+            self.Ci = 4
         self.sub_groups = 0
         cog = c0.out_channels // self.groups
         SUPER = 32      # narrow groups (width 4/8/16, resnext3D.py:85-92) are packed as block-diagonal 32-wide
@@ -243,6 +246,8 @@ class Packed:
             raise PtxError("fp16 filters: dense, unfolded convs with an even channel count only")
         if fold_kw:
             self.Kc = max(self.Kc, 32 if self.x3 else _stem_ld()) if keff <= 24 else self.Kc
+        if self.stem4:
+            self.Kc = 32
         self.Co_pad = _r128(self.Co)
         self.k_eff = (kT, kH, 1) if fold_kw else (kT, kH, kW)
         self.d = PackDesc(self.Co, self.Ci, kT, kH, kW, self.Kc, self.Co_pad, int(fold_kw), 0, 0, 0,
@@ -262,6 +267,8 @@ class Packed:
         else:
             w = torch.cat([c.weight.detach() for c in convs], 0)
             cb = torch.cat([c.bias.detach() for c in convs], 0) if convs[0].bias is not None else None
+        if self.stem4 and w.shape[1] < 4:             # zero channel(s) up to the 16-byte position the stem kernel reads
+            w = torch.cat([w, w.new_zeros((w.shape[0], 4 - w.shape[1]) + tuple(w.shape[2:]))], 1)
         w = w.contiguous()
         if w.dtype != torch.float32 or not w.is_cuda:
             raise PtxError("weights must be fp32 CUDA tensors on the plan's device")
@@ -342,6 +349,14 @@ class ConvStep:
                                             p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
 
 
+class StemStep:
+    """One ptx_conv_stem_x3_fwd launch (split-operand stem read from 4-channel positions)."""
+    __slots__ = ("d", "x", "w", "b", "y", "label", "macs", "hbm_bytes")
+
+    def __call__(self, st):
+        check(_lib.lib().ptx_conv_stem_x3_fwd(C.byref(self.d), self.x, self.w, self.b, self.y, st), self.label)
+
+
 class Plan:
     def __init__(self, engine, model, shape, dev, norm=None):
         self.dev = dev
@@ -393,14 +408,15 @@ class Plan:
         self._cur = model
 
     # ---------------------------------------------------------------- building blocks
-    def pack(self, convs, bn, fold_kw=False, scale=None, f16=False, x3=None):
+    def pack(self, convs, bn, fold_kw=False, scale=None, f16=False, x3=None, stem4=False):
         """scale: (module, attribute name) of a scalar Parameter multiplying the filter.
         x3: force (True) / forbid (False) split operands for this filter; None = the plan's precision."""
         if not isinstance(convs, (list, tuple)):
             convs = [convs]
-        key = (tuple(id(c) for c in convs), id(bn), fold_kw, None if scale is None else (id(scale[0]), scale[1]), bool(f16), x3)
+        key = (tuple(id(c) for c in convs), id(bn), fold_kw, None if scale is None else (id(scale[0]), scale[1]), bool(f16), x3,
+               bool(stem4))
         if key not in self._pack_cache:
-            p = Packed(self, convs, bn, fold_kw, scale, f16, x3)
+            p = Packed(self, convs, bn, fold_kw, scale, f16, x3, stem4)
             self._pack_cache[key] = p
             self.packs.append(p)
         return self._pack_cache[key]
@@ -536,7 +552,9 @@ class Plan:
         if hasattr(conv, "spatial_conv"):      # r2plus1d.py:85-88
             ks, ss, ps = _geom(conv.spatial_conv)
             fold = _foldable(conv.spatial_conv, x)
-            mid = self.conv(x if not fold else self.fold_input(x, conv.spatial_conv),
+            mid = self.stem_direct(x, conv.spatial_conv, conv.bn, True, label + ".spatial") if fold else None
+            if mid is None:
+                mid = self.conv(x if not fold else self.fold_input(x, conv.spatial_conv),
                             self.pack(conv.spatial_conv, conv.bn, fold),
                             (ss[0], ss[1], 1) if fold else ss, (ps[0], ps[1], 0) if fold else ps,
                             relu=True, label=label + ".spatial")
@@ -546,6 +564,10 @@ class Plan:
         k, s, p = _geom(conv)
         same = bool(getattr(conv, "tf_same", False))       # I3D's Unit3D: explicit "SAME" padding
         fold = _foldable(conv, x)
+        if fold and res is None and y is None:
+            direct = self.stem_direct(x, conv, bn, relu, label)
+            if direct is not None:
+                return direct
         if fold:
             if same:    # the fold consumes the W axis with its own SAME front pad; T/H stay SAME in the conv
                 _, pf = _same_geometry((x.T, x.H, x.W), k, s)
@@ -555,6 +577,42 @@ class Plan:
             s, p = (s[0], s[1], 1), (p[0], p[1], 0)
         return self.conv(x, self.pack(conv, bn, fold), s, p, relu=relu, res=res, res_kind=res_kind,
                          res_stride=res_stride, label=label, y=y, same=same)
+
+    def stem_direct(self, raw, conv, bn, relu, label):
+        """Split-operand stems skip the kW fold: the input becomes [N,T,H,W,4] (16-byte positions) and
+        ptx_conv_stem_x3_fwd serves every (kh, kw) tap of a temporal tap from one staged input patch.  Returns None when
+        the kernel does not cover the geometry (the folded implicit-GEMM path then runs)."""
+        if not self.x3 or os.environ.get("PTX_STEM_DIRECT", "1") == "0" or raw.norm is not None or raw.t_step != 1:
+            return None
+        if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or getattr(conv, "tf_same", False) or raw.C > 4:
+            return None
+        (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
+        To, Ho, Wo = (raw.T + 2 * pT - kT) // sT + 1, (raw.H + 2 * pH - kH) // sH + 1, (raw.W + 2 * pW - kW) // sW + 1
+        d = ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = raw.N, raw.T, raw.H, raw.W, raw.C, 4
+        d.To, d.Ho, d.Wo, d.Co = To, Ho, Wo, conv.out_channels
+        d.ldy = _r4(conv.out_channels)
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
+        d.Kc, d.Co_pad = 32, _r128(conv.out_channels)
+        d.flags = PTX_F16X3_OPERANDS | (PTX_EPI_RELU if relu else 0)
+        if min(To, Ho, Wo) < 1 or not self.lib.ptx_conv_stem_x3_supported(C.byref(d)):
+            return None
+        # one 16-byte position per pixel, already split into (hi4 | lo4) halfs: the NCDHW edge does the split once
+        x4 = self.act(raw.N, raw.T, raw.H, raw.W, 4)
+        lib, x4p, Nn, Cc, Ss = self.lib, _ptr(x4.t), raw.N, raw.C, raw.T * raw.H * raw.W
+
+        def to_split4(st, self=self):
+            check(lib.ptx_ncdhw_to_split4(self.in_ptr, x4p, Nn, Cc, Ss, st), "ptx_ncdhw_to_split4")
+        self.steps.append(_tag(to_split4, "ncdhw_to_split4", 4 * Nn * Cc * Ss + 16 * Nn * Ss))
+        pk = self.pack(conv, bn, fold_kw=True, x3=True, stem4=True)
+        y = self.act(raw.N, To, Ho, Wo, conv.out_channels)
+        st = StemStep()
+        st.d, st.x, st.w, st.b, st.y, st.label = d, _ptr(x4.t), _ptr(pk.w), _ptr(pk.b), _ptr(y.t), label
+        st.macs = raw.N * To * Ho * Wo * conv.out_channels * raw.C * kT * kH * kW
+        st.hbm_bytes = 0
+        self.steps.append(st)
+        self.stem_steps = getattr(self, "stem_steps", 0) + 1
+        return y
 
     def fold_input(self, raw, conv, same_pad=None):
         """raw: RawInput (NCDHW user tensor or uint8 frames).  Emits the fold kernel."""

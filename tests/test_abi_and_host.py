@@ -422,7 +422,7 @@ def test_standin_models_match_literature_shapes(ptx):
     assert gplan.feat.C == 3 and (gplan.feat.H, gplan.feat.W) == (256, 256)
 
 
-def test_x3_precision_plan_wiring_without_gpu(ptx):
+def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     """Engine.precision = "x3": every dense conv of the plan is packed as split halfs (Kc % 8 == 0, the folded stem
     on 32-float rows), carries PTX_F16X3_OPERANDS and defaults to an '/x3' tile; grouped convs keep fp32 tiles;
     switching the precision drops the compiled plans; the tuned table is keyed per operand flavour."""
@@ -436,13 +436,20 @@ def test_x3_precision_plan_wiring_without_gpu(ptx):
         eng.precision = "fp8"
     eng.precision = "x3"
     plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
-    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps)
+    # the stem leaves the implicit-GEMM list: ptx_conv_stem_x3_fwd reads 4-channel positions, no kW fold
+    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps) - 1 and plan.stem_steps == 1
+    stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
+    assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"
+    assert not any(getattr(s, "label", "") == "fold_kw" for s in plan.steps)
     for s in plan.conv_steps:
         assert s.d.flags & L.PTX_F16X3_OPERANDS and s.d.Kc % 8 == 0, s.label
         assert lib.ptx_conv3d_config_name(s.cfg).decode().endswith("/x3"), s.label
-    stem = plan.conv_steps[0]
-    assert (stem.d.Kc, stem.d.ldx, stem.d.Ci) == (32, 32, 21)
-    assert sum(s.macs for s in plan.conv_steps) == sum(s.macs for s in base.conv_steps)
+    assert sum(s.macs for s in plan.conv_steps) + stem.macs == sum(s.macs for s in base.conv_steps)
+    monkeypatch.setenv("PTX_STEM_DIRECT", "0")               # the folded implicit-GEMM stem on 32-float rows
+    folded = eng.dry_plan(m, (2, 3, 16, 224, 224))
+    assert len(folded.conv_steps) == len(base.conv_steps)
+    assert (folded.conv_steps[0].d.Kc, folded.conv_steps[0].d.ldx, folded.conv_steps[0].d.Ci) == (32, 32, 21)
+    monkeypatch.delenv("PTX_STEM_DIRECT")
     # grouped convs (ResNeXt3D) are not split: they stay on the fp32 / direct tiles
     rx = ptx.resnext3d50(num_classes=10)
     rx.engine().precision = "x3"

@@ -1227,3 +1227,63 @@ def test_splitk_fused_reduction(ptx):
     base = hip_conv(ptx, xs, w3, (2, 2, 2), (1, 1, 1), bn=bn2, relu=True, res_pad=rp2, res_stride=2, split=3)
     got = hip_conv(ptx, xs, w3, (2, 2, 2), (1, 1, 1), bn=bn2, relu=True, res_pad=rp2, res_stride=2, split=3, fused_split=ws)
     assert torch.equal(got, base)
+
+
+def test_conv_stem_x3_direct(ptx):
+    """ptx_conv_stem_x3_fwd: small-Cin stems with split operands, read from 4-channel (16-byte) positions -- against
+    Conv3d / Conv2d + BN + ReLU in torch fp32.  ResNet3D stem (7^3, stride (1,2,2)), the 2-D ResNet stem, the (1,7,7)
+    spatial stem of R2Plus1D with its 110 output channels (two N tiles, ragged), a strided-in-time I3D-like stem, and the
+    MNIST net's single-channel 3x3."""
+    L, lib = ptx._lib, _lib(ptx)
+    cases = [  # N, Cin, T, H, W, Co, (kT,kH,kW), stride, pad
+        (2, 3, 5, 30, 26, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),
+        (3, 3, 1, 33, 40, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+        (2, 3, 4, 20, 18, 110, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+        (1, 3, 9, 18, 22, 64, (7, 7, 7), (2, 2, 2), (3, 3, 3)),
+        (4, 1, 1, 28, 28, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+        (1, 3, 3, 224, 224, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),          # full 112-wide rows: R = 4 rows per workgroup
+    ]
+    for (N, Ci, T, H, W, Co, k, s_, p_) in cases:
+        x = rnd(N, Ci, T, H, W, seed=80)
+        w = rnd(Co, Ci, *k, seed=81, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 82)
+        want = ref_conv(x, w, s_, p_, bn=bn, relu=True)
+        To, Ho, Wo = want.shape[2:]
+        xsrc = x.contiguous().to(DEV)
+        xd = torch.full((N, T, H, W, 4), float("nan"), device=DEV)        # 16-byte positions: (hi4 | lo4) halfs
+        L.check(lib.ptx_ncdhw_to_split4(_p(xsrc), _p(xd), N, Ci, T * H * W, _st()), "split4")
+        torch.cuda.synchronize()
+        halves = xd.view(torch.float16).view(N, T, H, W, 8).float().cpu()
+        back = (halves[..., :4] + halves[..., 4:])[..., :Ci].permute(0, 4, 1, 2, 3)
+        assert (back - x).abs().max().item() <= 2.0 ** -21 * max(1.0, x.abs().max().item())      # hi + lo == v to 22 bits
+        assert bool((halves[..., Ci:4] == 0).all()) and bool((halves[..., 4 + Ci:] == 0).all())
+        w4 = torch.zeros(Co, 4, *k)
+        w4[:, :Ci] = w
+        Co_pad = (Co + 127) // 128 * 128
+        pd = L.PackDesc(Co, 4, k[0], k[1], k[2], 32, Co_pad, 1)
+        pd.f16 = 2
+        wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(Co_pad, device=DEV)
+        ts = [t.to(DEV) for t in bn[:4]]
+        wd = w4.contiguous().to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                         C.c_float(bn[4]), _p(wp), _p(bp), _st()), "pack stem")
+        ldy = _r4(Co)
+        yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, 4
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, ldy
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = k[0], k[1], k[2], s_[0], s_[1], s_[2], p_[0], p_[1], p_[2]
+        d.Kc, d.Co_pad, d.flags = 32, Co_pad, L.PTX_EPI_RELU | L.PTX_F16X3_OPERANDS
+        assert lib.ptx_conv_stem_x3_supported(C.byref(d)), (N, Ci, T, H, W)
+        L.check(lib.ptx_conv_stem_x3_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), _p(yd), _st()), "stem x3")
+        torch.cuda.synchronize()
+        got = from_cl(yd, Co)
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        assert err <= 2e-5, ((N, Ci, T, H, W, Co, k, s_), err)
+        pad = yd[..., Co:ldy]
+        assert pad.numel() == 0 or bool((pad == 0).all())
+    # refused, not mis-computed: fp32 operands, a 64-channel input, a 16-wide filter
+    d.flags = L.PTX_EPI_RELU
+    assert not lib.ptx_conv_stem_x3_supported(C.byref(d))
+    assert lib.ptx_conv_stem_x3_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), _p(yd), _st()) == 2
