@@ -32,7 +32,7 @@ GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md HBM3E peak
-TRAFFIC_FILE = "r01_pmc_traffic.json"   # newest committed PMC traffic table (profiles/), replayed in roofline.traffic
+TRAFFIC_FILE = "r02_pmc_traffic.json"   # newest committed PMC traffic table (profiles/), replayed in roofline.traffic
 
 
 def other_workload(name, rank):

@@ -1,0 +1,24 @@
+"""profiles/rNN_pmc_traffic.json from a scripts/gpu_prof_pmc.sh summary: mean FETCH_SIZE / WRITE_SIZE (KiB per dispatch)
+per kernel, the table bench.py replays in `roofline.traffic` (with its provenance).
+
+    python scripts/pmc_traffic_json.py gpurun_out/prof_cfg2_fp32/summary.txt profiles/r02_pmc_traffic.json
+"""
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+out, sect = {}, None
+for line in open(src):
+    m = re.match(r"## counters: pmc_(\w+)/", line)
+    if m:
+        sect = m.group(1)
+        continue
+    if line.startswith("## "):
+        sect = None
+    if sect in ("FETCH_SIZE", "WRITE_SIZE") and not line.startswith("kernel") and line.strip():
+        m = re.match(r"(.{62})\s+(\d+)\s+([0-9.e+-]+)\s+([0-9.e+-]+)", line)
+        if m:
+            out.setdefault(m.group(1).strip(), {})[sect + "_KiB"] = float(m.group(3))
+json.dump(out, open(dst, "w"), indent=1)
+print(len(out), "kernels ->", dst)
