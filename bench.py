@@ -261,10 +261,12 @@ def main():
             want_dma = stage.startswith("dma")
             want_nstage = int(stage[3:]) if len(stage) > 3 else 2
             for k, v in tj.items():
-                m = re.match(r"conv_igemm<([^>]*)>", k)
-                if not m or v.get("WRITE_SIZE_KiB") is None:
+                m = re.match(r"conv_igemm<([^>(]*)", k)         # names are cut at 60 characters by summarize_prof.py
+                if not m or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
                     continue
                 targs = [a.strip() for a in m.group(1).split(",")]
+                if len(targs) < 10 or (len(targs) > 10 and targs[10].startswith("t")):     # fp32-operand tiles only
+                    continue
                 if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
                     traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
                     traffic_source = {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0,
