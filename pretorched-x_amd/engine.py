@@ -333,9 +333,24 @@ class PackedDual:
 class ConvStep:
     """One ptx_conv3d_fwd (or, with a second source, ptx_conv3d_dual_fwd) launch with everything but
     the stream frozen."""
-    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused")
+    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused", "from_table")
 
     def __call__(self, st):
+        try:
+            self._launch(st)
+        except PtxError:
+            # a tile taken from the tuned table that this build / this problem cannot run (a stale or hand-edited
+            # entry): fall back to the library's own default once, loudly, instead of failing the forward
+            if not getattr(self, "from_table", False):
+                raise
+            sk = C.c_int(1)
+            self.cfg = self.plan.lib.ptx_conv3d_pick_config(C.byref(self.d), C.byref(sk))
+            self.split, self.from_table = sk.value, False
+            import warnings
+            warnings.warn("pretorched-x_amd: tuned tile for %s rejected by the library; using the default tile" % self.label)
+            self._launch(st)
+
+    def _launch(self, st):
         p = self.plan
         if self.fused:        # fp16 generator stage: per-sample affine / halfs out / dual output / upsampling loader
             check(_lib.lib().ptx_conv3d_fused_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
@@ -533,6 +548,7 @@ class Plan:
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
         tuned = tuned_lookup(key, _flags_kind(flags))
+        st.from_table = tuned is not None
         if tuned is not None:
             st.cfg, st.split = tuned
         else:
@@ -1415,7 +1431,7 @@ class Engine:
                     for sk in splits:
                         if sk > 1 and lib.ptx_conv3d_workspace_bytes(C.byref(stp.d), sk) > plan.ws_bytes:
                             continue
-                        stp.cfg, stp.split = cfg, sk
+                        stp.cfg, stp.split, stp.from_table = cfg, sk, False     # a refusal must surface here, not fall back
                         try:
                             stp(_stream())      # warm-up + validity
                         except PtxError:
