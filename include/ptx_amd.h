@@ -61,6 +61,11 @@ typedef void* ptx_stream_t; /* hipStream_t */
                                 a_lo.b_lo term is <= 2^-22 of the product, so results match the fp32 path to ~1e-6 relative
                                 (measured: same |dlogits| vs the CPU reference as fp32 MFMA) at 3 / 16 of its matrix-core
                                 time.  Needs Kc % 8 == 0, groups == 1 and operand magnitudes inside the half range (< 65504).
+                                Precision contract per operand value v: relative error 2^-22 for |v| >= 2^-3 (both halves
+                                normal); below that the lo half is a subnormal half and the ABSOLUTE error is bounded by
+                                2^-25 (measured conv error vs fp64: 1e-6 relative at |x| ~ 1, 2e-6 at 1e-2, 3e-5 at 1e-3,
+                                2e-4 at 1e-4, where lo vanishes and the value is a plain half): right for BN-normalised
+                                activations and kaiming-scale weights, not for operands far below 1e-2.
                                 Runs on the ".../x3" tile configurations.                                          */
 #define PTX_SPLITK_FUSED 0x10000u /* split_k > 1 without the second (reduce) launch: the workspace then starts with 64 KiB of
                                 tile arrival counters -- which the CALLER zeroes once (ptx_conv3d_workspace_bytes includes
@@ -365,6 +370,9 @@ int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float*
 #define PTX_NL_F16 2   /* OR into mode (softmax, d <= 64): both matmuls on v_mfma_f32_16x16x16_f16 -- theta / phi / g / P are rounded
                           to halfs in registers, accumulators / softmax statistics / y stay fp32.  The BigGAN generator's
                           self-attention under its fp16 plan (BASELINE config 5); the video nets keep the fp32 kernel. */
+#define PTX_NL_X3 4    /* OR into mode: fp32-ACCURATE split operands on the same fp16 MFMAs (theta / phi / g / P as (hi, lo) half
+                          pairs, a.b = hi.lo + lo.hi + hi.hi, fp32 accumulate) -- the attention of a plan compiled with
+                          Engine.precision = "x3" (PTX_F16X3_OPERANDS convs).  Exclusive with PTX_NL_F16.               */
 typedef struct ptx_nonlocal_desc {
     int32_t batch, Nq, Nk, d, dv;
     int32_t ld_theta, ld_phi, ld_g, ld_y;        /* row strides (floats)   */

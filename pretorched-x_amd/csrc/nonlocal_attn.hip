@@ -66,8 +66,17 @@ __device__ __forceinline__ half4_t to_half4(float a, float b, float c, float d) 
 // run on v_mfma_f32_16x16x16_f16 -- the 4 consecutive d (resp. the 4 keys 4*gq .. 4*gq+3) a lane already holds as
 // floats ARE one K = 16 operand once rounded to halfs, so 4 fp32 MFMAs (128 clk) become one f16 MFMA (16 clk).
 // Accumulators, softmax statistics and the output stay fp32.
-template <int D, int DV, bool SOFTMAX, bool F16 = false>
+// X3 (PTX_NL_X3, Engine.precision = "x3"): fp32-ACCURATE on the same fp16 MFMAs -- every operand is split into
+// (hi, lo) halfs in registers and a.b = hi.lo + lo.hi + hi.hi (conv_igemm.hip, X3): three f16 MFMAs instead of four
+// fp32 ones, each 4x shorter.  F16 and X3 are exclusive (MODE 1 / 2).
+__device__ __forceinline__ void split4(float a, float b, float c, float d, half4_t& hi, half4_t& lo) {
+    hi = to_half4(a, b, c, d);
+    lo = to_half4(a - (float)hi[0], b - (float)hi[1], c - (float)hi[2], d - (float)hi[3]);
+}
+
+template <int D, int DV, bool SOFTMAX, int MODE = 0>
 __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
+    constexpr bool F16 = MODE == 1, X3 = MODE == 2;
     constexpr int TK = 16;                   // keys per tile
     constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
     constexpr int CB = DV / 64;              // 64-channel output super-blocks (one ds_read_b128 + 4 MFMAs per key group)
@@ -104,10 +113,14 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         qf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                               rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
     }
-    half4_t qh[QJ];
+    half4_t qh[QJ], ql[X3 ? QJ : 1];
     if constexpr (F16) {
 #pragma unroll
         for (int j = 0; j < QJ; ++j) qh[j] = to_half4(qf[j][0], qf[j][1], qf[j][2], qf[j][3]);
+    }
+    if constexpr (X3) {
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) split4(qf[j][0], qf[j][1], qf[j][2], qf[j][3], qh[j], ql[j]);
     }
 
     // ---- per-lane DMA source offsets (tile independent) ----
@@ -176,6 +189,13 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
                 else       s0 = mfma16h(kh, qh[j], s0);
                 continue;
             }
+            if constexpr (X3) {
+                half4_t kh, kl;
+                split4(kf[0], kf[1], kf[2], kf[3], kh, kl);
+                if (j & 1) { s1 = mfma16h(kh, ql[j], s1); s1 = mfma16h(kl, qh[j], s1); s1 = mfma16h(kh, qh[j], s1); }
+                else       { s0 = mfma16h(kh, ql[j], s0); s0 = mfma16h(kl, qh[j], s0); s0 = mfma16h(kh, qh[j], s0); }
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (j & 1) s1 = mfma16(kf[e], qf[j][e], s1);
@@ -211,7 +231,9 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = s[r] * inv_nk;   // keys >= Nk read as zero rows: no mask needed
+            // keys >= Nk read as zero rows: no mask needed.  Split operands: the 1 / Nk factor moves to the epilogue -- P = S / Nk
+            // would sit around 1e-2, where the lo half of a split goes subnormal and the product keeps ~17 bits instead of 22
+            for (int r = 0; r < 4; ++r) pr[r] = X3 ? s[r] : s[r] * inv_nk;
         }
 
         // ---- O += P . g_tile ----
@@ -227,6 +249,25 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     O[cb][e] = mfma16h(ph, to_half4(vf[0][e], vf[1][e], vf[2][e], vf[3][e]), O[cb][e]);
+            }
+            continue;
+        }
+        if constexpr (X3) {
+            half4_t ph, pl;
+            split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 vf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vf[r] = *reinterpret_cast<const f32x4*>(Vb + r * DV + cb * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half4_t vh, vl;
+                    split4(vf[0][e], vf[1][e], vf[2][e], vf[3][e], vh, vl);
+                    O[cb][e] = mfma16h(ph, vl, O[cb][e]);
+                    O[cb][e] = mfma16h(pl, vh, O[cb][e]);
+                    O[cb][e] = mfma16h(ph, vh, O[cb][e]);
+                }
             }
             continue;
         }
@@ -251,7 +292,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     float* yb = p.y + (size_t)b * p.bs_y;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float iv = SOFTMAX ? __shfl(inv, 4 * gq + r, 64) : 1.f;
+        const float iv = SOFTMAX ? __shfl(inv, 4 * gq + r, 64) : (X3 ? inv_nk : 1.f);
         const int qo = qt * 64 + wave * 16 + 4 * gq + r;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
@@ -264,7 +305,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     }
 }
 
-template <int D, int DV, bool SOFTMAX, bool F16 = false>
+template <int D, int DV, bool SOFTMAX, int MODE = 0>
 static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 16 * (D + DV) * sizeof(float);
     const dim3 grid((unsigned)(a.q_tiles * a.batch), (unsigned)cdiv(a.dv, DV));
@@ -272,17 +313,21 @@ static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, F16>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, MODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, F16>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, MODE>), grid, dim3(256), lds, st, a);
     return hip_check(hipGetLastError(), "nonlocal attention launch");
 }
 
 template <int D, int DV>
 static int launch_nl(const NlArgs& a, hipStream_t st) {
     return a.scale_only ? launch_nl_mode<D, DV, false>(a, st) : launch_nl_mode<D, DV, true>(a, st);
+}
+template <int D, int DV>
+static int launch_nl_x3(const NlArgs& a, hipStream_t st) {
+    return a.scale_only ? launch_nl_mode<D, DV, false, 2>(a, st) : launch_nl_mode<D, DV, true, 2>(a, st);
 }
 
 }  // namespace ptx
@@ -305,7 +350,8 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
         d->ld_g % 4 || d->ld_y % 4 || d->bs_theta % 4 || d->bs_phi % 4 || d->bs_g % 4 || d->bs_y % 4)
         return fail(PTX_ERR_INVALID, "nonlocal: row / batch strides must be multiples of 4 floats and cover the extents");
     if (((uintptr_t)theta | (uintptr_t)phi | (uintptr_t)g | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "nonlocal: misaligned pointer");
-    if (d->mode & ~(PTX_NL_SCALE | PTX_NL_F16)) return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
+    if ((d->mode & ~(PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_X3)) || ((d->mode & PTX_NL_F16) && (d->mode & PTX_NL_X3)))
+        return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
     const uint64_t tb = (uint64_t)d->Nq * d->ld_theta * 4ull, pb = (uint64_t)d->Nk * d->ld_phi * 4ull, gb = (uint64_t)d->Nk * d->ld_g * 4ull;
     if (tb >= 0x80000000ull || pb >= 0x80000000ull || gb >= 0x80000000ull)
         return fail(PTX_ERR_UNSUPPORTED, "nonlocal: one batch item of theta / phi / g must be < 2 GiB");
@@ -321,7 +367,13 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     if (d->mode & PTX_NL_F16) {          // fp16-operand MFMAs: the generator's self-attention shape family only
         if (a.scale_only || d->d > 64)
             return fail(PTX_ERR_UNSUPPORTED, "nonlocal: PTX_NL_F16 covers softmax attention with d <= 64 (d=%d)", d->d);
-        return d->dv <= 64 ? launch_nl_mode<64, 64, true, true>(a, st) : launch_nl_mode<64, 256, true, true>(a, st);
+        return d->dv <= 64 ? launch_nl_mode<64, 64, true, 1>(a, st) : launch_nl_mode<64, 256, true, 1>(a, st);
+    }
+    if (d->mode & PTX_NL_X3) {           // split operands: the same tile family as the fp32 kernel
+        if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl_x3<32, 128>(a, st);
+        if (d->d <= 64) return d->dv <= 64 ? launch_nl_x3<64, 64>(a, st) : launch_nl_x3<64, 256>(a, st);
+        if (d->d <= 256) return d->dv <= 128 ? launch_nl_x3<256, 128>(a, st) : launch_nl_x3<256, 256>(a, st);
+        return launch_nl_x3<512, 256>(a, st);
     }
     // smallest compiled (D, DV) covering the problem; dv > DV is split over blockIdx.y (S recomputed per chunk)
     if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl<32, 128>(a, st);

@@ -701,7 +701,7 @@ class Plan:
         th [N, Sq, d], ph [N, Sk, d], g [N, Sk, dv], y [N, Sq, dv]: channels-last activations (possibly channel
         slices).  Returns False -- nothing emitted -- when the fused kernel does not cover the shape (d > 512)
         or PTX_NL_FUSED=0 asks for the unfused bgemm / softmax / bgemm chain."""
-        from ._lib import NonlocalDesc, PTX_NL_F16, PTX_NL_SCALE, PTX_NL_SOFTMAX
+        from ._lib import NonlocalDesc, PTX_NL_F16, PTX_NL_SCALE, PTX_NL_SOFTMAX, PTX_NL_X3
         d = NonlocalDesc()
         d.batch, d.Nq, d.Nk, d.d, d.dv = th.N, th.S, ph.S, th.C, g.C
         d.ld_theta, d.ld_phi, d.ld_g, d.ld_y = th.ld, ph.ld, g.ld, y.ld
@@ -709,6 +709,8 @@ class Plan:
         d.mode = PTX_NL_SCALE if scale_only else PTX_NL_SOFTMAX
         if f16 and not scale_only and th.C <= 64:      # fp16-operand MFMAs (the generator's fp16 plan)
             d.mode |= PTX_NL_F16
+        elif self.x3 and os.environ.get("PTX_NL_X3", "1") != "0":      # split operands, like the plan's convs
+            d.mode |= PTX_NL_X3
         if os.environ.get("PTX_NL_FUSED", "1") == "0" or not self.lib.ptx_nonlocal_supported(C.byref(d)):
             return False
         lib, tp, pp, gp, yp = self.lib, _ptr(th.t), _ptr(ph.t), _ptr(g.t), _ptr(y.t)

@@ -888,6 +888,10 @@ def test_conv_f16_operands(ptx):
     (1, 64, 1568, 256, 256, "softmax", "many key tiles: online-softmax rescaling"),
     (2, 256, 64, 64, 256, "softmax/f16", "PTX_NL_F16: BigGAN-256 attention shape on 16x16x16 f16 MFMAs"),
     (2, 100, 50, 32, 40, "softmax/f16", "PTX_NL_F16: ragged tails"),
+    (2, 196, 196, 512, 512, "softmax/x3", "PTX_NL_X3: layer3 of config 3, split operands"),
+    (1, 300, 300, 256, 256, "softmax/x3", "PTX_NL_X3: layer2 width"),
+    (2, 90, 90, 40, 24, "scale/x3", "PTX_NL_X3: dot_product mode"),
+    (1, 64, 1568, 256, 256, "softmax/x3", "PTX_NL_X3: many key tiles"),
 ])
 def test_fused_nonlocal_attention(ptx, case):
     """ptx_nonlocal_fwd against the reference's op sequence (nonlocalnet.py:143-166 / :192-211): matmul ->
@@ -903,7 +907,7 @@ def test_fused_nonlocal_attention(ptx, case):
     theta, phi, gv = tpg_q[..., :d] * scale, tpg_k[..., d:2 * d].clone(), tpg_k[..., 2 * d:2 * d + dv].clone()
     tpg_q[..., :d] = theta
     f = torch.matmul(theta, phi.transpose(1, 2))
-    half = mode.endswith("/f16")
+    half, x3 = mode.endswith("/f16"), mode.endswith("/x3")
     mode = mode.split("/")[0]
     f = F.softmax(f, dim=-1) if mode == "softmax" else f / f.size(-1)
     want = torch.matmul(f, gv)
@@ -915,7 +919,7 @@ def test_fused_nonlocal_attention(ptx, case):
     desc.ld_theta = desc.ld_phi = desc.ld_g = ld
     desc.ld_y = ldy
     desc.bs_theta, desc.bs_phi, desc.bs_g, desc.bs_y = Nq * ld, Nk * ld, Nk * ld, Nq * ldy
-    desc.mode = (L.PTX_NL_SOFTMAX if mode == "softmax" else L.PTX_NL_SCALE) | (L.PTX_NL_F16 if half else 0)
+    desc.mode = (L.PTX_NL_SOFTMAX if mode == "softmax" else L.PTX_NL_SCALE) | (L.PTX_NL_F16 if half else 0) | (L.PTX_NL_X3 if x3 else 0)
     assert lib.ptx_nonlocal_supported(C.byref(desc))
     L.check(lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()), "nonlocal")
     torch.cuda.synchronize()
