@@ -377,7 +377,7 @@ def main():
             byk = {}
             # the direct split-operand stem (ptx_conv_stem_x3_fwd) is a conv too, with its own kernel
             for lab, kind, nb, macs, ms, cfg in conv3 + [(r[0], "conv", 0, r[3], r[4], "conv_stem_x3") for r in rows3
-                                                          if r[1] == "mfma" and r[0].startswith("conv1")]:
+                                                          if r[1] == "mfma" and not r[0].startswith("nonlocal")]:
                 k = byk.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
                 k["ms"] += ms
                 k["flop"] += 2.0 * macs

@@ -263,9 +263,16 @@ extern "C" int ptx_conv_stem_x3_supported(const ptx_conv3d_desc* d) {
     if (R < 1 || (int64_t)PR * PC > kStemPatchMax) return 0;
     if ((int64_t)d->N * d->Ti * d->Hi * d->Wi * 16 >= 0x80000000LL || (int64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4 >= 0x80000000LL)
         return 0;
-    // the conv arithmetic of the W axis must match the patch geometry (symmetric padding)
-    if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1 || d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1 ||
-        d->To != (d->Ti + 2 * d->pT - d->kT) / d->sT + 1)
+    // output extents: symmetric padding p, or TF-"SAME" (out = ceil(in / stride), p = the FRONT pad floor(total / 2); the
+    // back pad is implied -- taps beyond the image read zero either way), as ptx_conv3d_fwd accepts them
+    auto extent_ok = [](int in, int out, int k, int s, int p) {
+        if (out == (in + 2 * p - k) / s + 1) return true;
+        const int same = (in + s - 1) / s;
+        const int total = std::max((same - 1) * s + k - in, 0);
+        return out == same && p == total / 2;
+    };
+    if (!extent_ok(d->Wi, d->Wo, d->kW, d->sW, d->pW) || !extent_ok(d->Hi, d->Ho, d->kH, d->sH, d->pH) ||
+        !extent_ok(d->Ti, d->To, d->kT, d->sT, d->pT))
         return 0;
     return 1;
 }
@@ -276,7 +283,7 @@ extern "C" int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* d, const float* x, co
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "conv_stem_x3: pointers must be 16-byte aligned");
     if (!ptx_conv_stem_x3_supported(d))
         return fail(PTX_ERR_UNSUPPORTED, "conv_stem_x3: needs a split-operand (PTX_F16X3_OPERANDS) stem: Ci <= 4 stored as 4-channel "
-                    "positions (ldx == 4), kW <= 8 folded into Kc == 32, stride_w <= 2, symmetric padding, Wo <= %d and an input "
+                    "positions (ldx == 4), kW <= 8 folded into Kc == 32, stride_w <= 2, symmetric or SAME padding, Wo <= %d and an input "
                     "patch of at most %d positions", kStemRows, kStemPatchMax);
     if (d->ldy < d->Co || d->ldy % 4) return fail(PTX_ERR_INVALID, "conv_stem_x3: bad output stride");
     StemArgs a{};

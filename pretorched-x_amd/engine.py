@@ -600,10 +600,13 @@ class Plan:
         the kernel does not cover the geometry (the folded implicit-GEMM path then runs)."""
         if not self.x3 or os.environ.get("PTX_STEM_DIRECT", "1") == "0" or raw.norm is not None or raw.t_step != 1:
             return None
-        if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or getattr(conv, "tf_same", False) or raw.C > 4:
+        if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or raw.C > 4:
             return None
         (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
-        To, Ho, Wo = (raw.T + 2 * pT - kT) // sT + 1, (raw.H + 2 * pH - kH) // sH + 1, (raw.W + 2 * pW - kW) // sW + 1
+        if getattr(conv, "tf_same", False):     # I3D's Unit3D: out = ceil(in / stride), front pad = total // 2
+            (To, Ho, Wo), (pT, pH, pW) = _same_geometry((raw.T, raw.H, raw.W), (kT, kH, kW), (sT, sH, sW))
+        else:
+            To, Ho, Wo = (raw.T + 2 * pT - kT) // sT + 1, (raw.H + 2 * pH - kH) // sH + 1, (raw.W + 2 * pW - kW) // sW + 1
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = raw.N, raw.T, raw.H, raw.W, raw.C, 4
         d.To, d.Ho, d.Wo, d.Co = To, Ho, Wo, conv.out_channels

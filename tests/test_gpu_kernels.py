@@ -1246,12 +1246,20 @@ def test_conv_stem_x3_direct(ptx):
         (1, 3, 9, 18, 22, 64, (7, 7, 7), (2, 2, 2), (3, 3, 3)),
         (4, 1, 1, 28, 28, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
         (1, 3, 3, 224, 224, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),          # full 112-wide rows: R = 4 rows per workgroup
+        (2, 3, 6, 21, 24, 64, (7, 7, 7), (2, 2, 2), "same"),               # TF-SAME (I3D Unit3D): front pad 2, back pad 3 / 2
     ]
     for (N, Ci, T, H, W, Co, k, s_, p_) in cases:
         x = rnd(N, Ci, T, H, W, seed=80)
         w = rnd(Co, Ci, *k, seed=81, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
         bn = make_bn(Co, 82)
-        want = ref_conv(x, w, s_, p_, bn=bn, relu=True)
+        if p_ == "same":                 # F.pad(front = total // 2, back = rest) then an unpadded conv, as I3D ports do
+            outs = [-(-i // st) for i, st in zip((T, H, W), s_)]
+            tot = [max((o - 1) * st + kk - i, 0) for o, st, kk, i in zip(outs, s_, k, (T, H, W))]
+            p_ = tuple(t // 2 for t in tot)
+            xp = F.pad(x, (tot[2] // 2, tot[2] - tot[2] // 2, tot[1] // 2, tot[1] - tot[1] // 2, tot[0] // 2, tot[0] - tot[0] // 2))
+            want = ref_conv(xp, w, s_, (0, 0, 0), bn=bn, relu=True)
+        else:
+            want = ref_conv(x, w, s_, p_, bn=bn, relu=True)
         To, Ho, Wo = want.shape[2:]
         xsrc = x.contiguous().to(DEV)
         xd = torch.full((N, T, H, W, 4), float("nan"), device=DEV)        # 16-byte positions: (hi4 | lo4) halfs
