@@ -353,8 +353,11 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
 // kernel, the residual and the epilogue are untouched); a lane splits its 8-channel A fragment in registers (24 VALU
 // per 3 x TN MFMAs).  The filter is split once, at pack time (ptx_pack_desc.f16 == 2: each 8-channel block of a row is
 // stored as 8 hi halfs then 8 lo halfs -- the same 32 bytes), so B fragments are two 16-byte reads, no VALU.
-// Operand values must lie inside the half range (|v| < 65504); values below 2^-14 lose relative precision (their
-// lo part goes subnormal) but not absolute precision.
+// SCALED lo: lo is stored as half((v - hi) * 2^12).  Unscaled it is ~2^-11 |v| and falls into the subnormal halfs as soon
+// as |v| < 2^-3 (measured: 3e-5 relative conv error at |x| ~ 1e-3, 2e-4 at 1e-4); scaled it is a normal half whenever hi
+// is one.  The two cross terms then carry a factor 2^12 and accumulate in their own accumulator, folded back once after
+// the k-loop (acc += 2^-12 acc2; powers of two: exact).  22 bits per product for every operand in the normal half range
+// (6.1e-5 <= |v| < 65504), at the price of a second accumulator tile.
 // KWR ("kw reuse", KWR = 3): for stride-1 filters of width 3 whose M tile is a whole number of output rows, the A tile
 // staged per (kt, kh, channel chunk) is the HALO'D input run -- Wo + 2 positions per output row -- and the three kw taps
 // read their fragments from it at row offsets +0 / +1 / +2, each against its own B (filter) tile of the same stage.  A
@@ -693,12 +696,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     };
 
     acc_t acc[TM][TN];
+    acc_t acc2[X3 ? TM : 1][X3 ? TN : 1];        // split operands: the 2^12-scaled cross terms hi.lo' + lo'.hi
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < MF::NACC; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (X3) acc2[i][j][r] = 0.f;
+            }
 
     // KWR: output row m_local of the tile lives at LDS row m_local + 2 * (m_local / Wo) (+ kw for tap kw)
     int a_lrow[KWR ? TM : 1];
@@ -855,8 +862,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     float d0, d1;
                     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(v[2 * e]));
                     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(v[2 * e + 1]));
-                    d[2 * e] = d0;
-                    d[2 * e + 1] = d1;
+                    d[2 * e] = d0 * 4096.f;              // scaled lo: stays a normal half whenever hi is one
+                    d[2 * e + 1] = d1 * 4096.f;
                 }
                 alo[i] = __builtin_bit_cast(f32x4, __builtin_convertvector(d, half8));
             }
@@ -864,11 +871,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(ahi[i], fb[slot][j][NF - 1], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc2[i][j] = MF::mma16(ahi[i], fb[slot][j][NF - 1], acc2[i][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma16(alo[i], fb[slot][j][0], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc2[i][j] = MF::mma16(alo[i], fb[slot][j][0], acc2[i][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1007,6 +1014,14 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         }
     }
 
+    if constexpr (X3) {           // fold the scaled cross terms back: acc += 2^-12 acc2 (exact scaling)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = fmaf(acc2[i][j][r], 1.0f / 4096.0f, acc[i][j][r]);
+    }
     if constexpr (F16) {
         if (fused_epi) {          // generator stage: per-sample affine / halfs out / dual output / half skip / tanh
             fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane, smem, wave_u);

@@ -146,13 +146,13 @@ __global__ void __launch_bounds__(kStemNT) conv_stem_x3_kernel(const StemArgs p)
     const int b_rowoff = l32 * 32;                       // filter row of this lane inside a 32-row block
     const int b_sw = (l32 >> 1) & 7;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acc2[2][2];            // acc2: the 2^12-scaled cross terms (scaled lo halves, conv_igemm.hip X3)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
     if (n_kt > 0) {
         // prologue: the first patch (all pieces) and the first filter tile
@@ -206,11 +206,11 @@ __global__ void __launch_bounds__(kStemNT) conv_stem_x3_kernel(const StemArgs p)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mma16(ahi[i], blo[j], acc[i][j]);
+                        for (int j = 0; j < 2; ++j) acc2[i][j] = mma16(ahi[i], blo[j], acc2[i][j]);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mma16(alo[i], bhi[j], acc[i][j]);
+                        for (int j = 0; j < 2; ++j) acc2[i][j] = mma16(alo[i], bhi[j], acc2[i][j]);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kStemNT) conv_stem_x3_kernel(const StemArgs p)
                 const int trow = (r & 3) + 8 * (r >> 2) + 4 * g;
                 const int m = __shfl(m_out[i], trow, 64);
                 const int ok = __shfl((int)row_ok[i], trow, 64);
-                float v = acc[i][j][r] + bv;
+                float v = fmaf(acc2[i][j][r], 1.0f / 4096.0f, acc[i][j][r]) + bv;
                 v = relu ? fmaxf(v, 0.f) : v;
                 const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ok) ? off : kOOB, 0, 0);

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(ptx_pack_desc d, const
             // split operands (PTX_F16X3_OPERANDS): the 8-channel block of column k holds 8 hi halfs then 8 lo halfs
             const size_t row_h = (((size_t)tap * d.Co_pad + co) * ld + d.k_off) * 2;      // row start, in halfs
             const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)(v - (float)hi);
+            const _Float16 lo = (_Float16)((v - (float)hi) * 4096.f);       // scaled lo: a normal half whenever hi is one
             _Float16* o = reinterpret_cast<_Float16*>(out) + row_h + (size_t)(k >> 3) * 16 + (k & 7);
             o[0] = hi;
             o[8] = lo;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) ncs_to_split4_kernel(const float* __restr
         for (int c = 0; c < 4; ++c) {
             const _Float16 h = (_Float16)v[c];
             o[c] = h;
-            o[4 + c] = (_Float16)(v[c] - (float)h);
+            o[4 + c] = (_Float16)((v[c] - (float)h) * 4096.f);      // scaled lo (conv_igemm.hip, X3)
         }
         *reinterpret_cast<half8_s*>(y + (size_t)i * 4) = o;
     }

@@ -1266,7 +1266,7 @@ def test_conv_stem_x3_direct(ptx):
         L.check(lib.ptx_ncdhw_to_split4(_p(xsrc), _p(xd), N, Ci, T * H * W, _st()), "split4")
         torch.cuda.synchronize()
         halves = xd.view(torch.float16).view(N, T, H, W, 8).float().cpu()
-        back = (halves[..., :4] + halves[..., 4:])[..., :Ci].permute(0, 4, 1, 2, 3)
+        back = (halves[..., :4] + halves[..., 4:] / 4096.0)[..., :Ci].permute(0, 4, 1, 2, 3)        # lo is stored scaled by 2^12
         assert (back - x).abs().max().item() <= 2.0 ** -21 * max(1.0, x.abs().max().item())      # hi + lo == v to 22 bits
         assert bool((halves[..., Ci:4] == 0).all()) and bool((halves[..., 4 + Ci:] == 0).all())
         w4 = torch.zeros(Co, 4, *k)
