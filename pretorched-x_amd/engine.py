@@ -239,7 +239,10 @@ class Packed:
             self.groups //= self.sub_groups
             self.Ci = SUPER
         self.fold_kw = bool(fold_kw)
-        self.x3 = bool(getattr(plan, "x3", False) if x3 is None else x3) and not self.f16 and self.groups == 1
+        # narrow outputs (Co <= 32: SlowFast's fast pathway, lateral convs) keep the fp32 narrow / direct tiles -- there is no
+        # 16-wide split-operand tile, and a 64-wide one would spend 4-8x padded work on them
+        self.x3 = (bool(getattr(plan, "x3", False) if x3 is None else x3) and not self.f16 and self.groups == 1
+                   and (self.Co > 32 or stem4))
         keff = kW * self.Ci if fold_kw else self.Ci
         self.Kc = (keff + 7) // 8 * 8 if (self.f16 or self.x3) else _r4(keff)
         if self.f16 and (fold_kw or self.groups > 1 or self.Ci % 2):
