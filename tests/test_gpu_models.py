@@ -358,6 +358,17 @@ def test_forward_frames_fused_preprocessing(ptx):
     _check(a, want, "fp32 clip vs oracle")
     _check(b, want, "uint8 frames vs oracle")
     assert (a - b).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    # split-operand plans: uint8 frames keep the folded stem (normalisation fused into the fold, 32-float rows, x3 tiles),
+    # fp32 clips take the direct patch-resident stem -- both within the bar, and within 1e-4 of each other
+    model.engine().precision = "x3"
+    a3 = model(clip.to(DEV))
+    b3 = model.forward_frames(frames.to(DEV), opts)
+    _check(a3, want, "x3 fp32 clip vs oracle")
+    _check(b3, want, "x3 uint8 frames vs oracle")
+    assert (a3 - b3).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    plans = list(model.engine()._plans.values())
+    assert sorted(getattr(p, "stem_steps", 0) for p in plans) == [0, 1]
+    model.engine().precision = "fp32"
     with pytest.raises(Exception):
         model.forward_frames(frames.to(DEV))            # pretrained=None models carry no mean/std
     with pytest.raises(Exception):
