@@ -177,8 +177,8 @@ def main():
         # tile configurations are timed on rank 0 ONLY and broadcast: N tuners running at once on one node
         # perturb each other's HIP-event timings, and every rank must launch the same kernels
         if rank == 0:
-            if headline:
-                eng.autotune(model, x, iters=2, verbose=args.verbose)
+            if headline or (os.environ.get("PTX_FULL_TUNE") == "1" and fwd is None):
+                eng.autotune(model, x, iters=2, verbose=args.verbose)      # every candidate tile of every conv problem
             else:
                 run()                              # first call compiles the plan and times untuned tiles
             torch.cuda.synchronize()
@@ -348,7 +348,7 @@ def main():
         if world == 1 and not f16 and args.workload != "cfg5-fp32" and not args.no_x3:
             eng.precision = "x3"
             if not args.no_autotune:
-                if headline:
+                if headline or (os.environ.get("PTX_FULL_TUNE") == "1" and fwd is None):
                     eng.autotune(model, x, iters=2, verbose=args.verbose)
                 else:
                     run()
