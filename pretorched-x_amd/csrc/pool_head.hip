@@ -44,16 +44,19 @@ __global__ void __launch_bounds__(256) maxpool3d_kernel(ptx_pool3d_desc d, const
     }
 }
 
-// k = 3, s = 2, p = 1 along W (the reference's only pooling geometry, resnet3D.py:156): a thread
-// produces WSEG consecutive outputs of one (n, to, ho, 4-channel group) and slides along W, so the
-// input column shared by neighbouring windows is loaded once: (2*WSEG + 1) * kT * kH loads for WSEG
-// outputs (19 per output at WSEG = 8) instead of 27.
-template <int WSEG>
+// kW = 3 along W with stride 1 or 2 (resnet3D.py:156's MaxPool3d(3,2,1); the SAME-padded 3x3x3 / (1,3,3) pools of the
+// Inception modules): a thread produces WSEG consecutive outputs of one (n, to, ho, 4-channel group) and slides along W,
+// so an input column shared by neighbouring windows is reduced over (t, h) ONCE: ((WSEG-1)*SW + 3) * kT * kH loads for
+// WSEG outputs -- 19 per output at stride 2, 11 at stride 1 (WSEG = 8) -- instead of 27.  Any front pad < 3, explicit
+// (SAME) output extents and zero-valued padding (PTX_POOL_PAD_ZERO: a clipped window also sees a 0) are handled.
+template <int WSEG, int SW>
 __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
                                                               float* __restrict__ y, size_t total) {
+    constexpr int NCOL = (WSEG - 1) * SW + 3;
     const int f4r = (d.C + 3) / 4;
     const int ldy = d.ldy ? d.ldy : d.ld;
     const int segs = (d.Wo + WSEG - 1) / WSEG;
+    const bool pad_zero = (d.flags & PTX_POOL_PAD_ZERO) != 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % f4r);
         size_t r = i / f4r;
@@ -65,31 +68,147 @@ __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d,
         const int n = (int)(r / d.To);
         const int t_lo = max(0, to * d.sT - d.pT), t_hi = min(d.Ti, to * d.sT - d.pT + d.kT);
         const int h_lo = max(0, ho * d.sH - d.pH), h_hi = min(d.Hi, ho * d.sH - d.pH + d.kH);
+        const bool th_clipped = (t_hi - t_lo) != d.kT || (h_hi - h_lo) != d.kH;
         const float* base = x + ((size_t)n * d.Ti * d.Hi * d.Wi) * d.ld + q * 4;
-        auto colmax = [&](int w) -> f32x4 {
-            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (w < 0 || w >= d.Wi) return m;
-            for (int t = t_lo; t < t_hi; ++t)
-                for (int h = h_lo; h < h_hi; ++h) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (((size_t)t * d.Hi + h) * d.Wi + w) * d.ld);
-                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
-                    m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-                }
-            return m;
-        };
         const int wo0 = seg * WSEG;
-        f32x4 prev = colmax(2 * wo0 - 1);
+        const int w0 = wo0 * SW - d.pW;                       // input column of cm[0]
+        f32x4 cm[NCOL];
+        unsigned live = 0;                                    // columns inside the input that a live window consumes
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            cm[c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            const int w = w0 + c;
+            if (w >= 0 && w < d.Wi && wo0 + (c < 3 ? 0 : (c - 2 + SW - 1) / SW) < d.Wo) live |= 1u << c;
+        }
+        // (t, h) outside, the columns inside: NCOL independent 16-byte loads in flight per row
+        for (int t = t_lo; t < t_hi; ++t)
+            for (int h = h_lo; h < h_hi; ++h) {
+                const float* row = base + (((ptrdiff_t)t * d.Hi + h) * d.Wi + w0) * (ptrdiff_t)d.ld;
+                f32x4 v[NCOL];
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c)
+                    if (live >> c & 1) v[c] = *reinterpret_cast<const f32x4*>(row + (ptrdiff_t)c * d.ld);
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c)
+                    if (live >> c & 1) {
+                        cm[c].x = fmaxf(cm[c].x, v[c].x); cm[c].y = fmaxf(cm[c].y, v[c].y);
+                        cm[c].z = fmaxf(cm[c].z, v[c].z); cm[c].w = fmaxf(cm[c].w, v[c].w);
+                    }
+            }
         float* yrow = y + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo) * ldy + q * 4;
 #pragma unroll
         for (int j = 0; j < WSEG; ++j) {
             const int wo = wo0 + j;
             if (wo < d.Wo) {
-                const f32x4 c0 = colmax(2 * wo), c1 = colmax(2 * wo + 1);
+                const f32x4 a = cm[j * SW], b = cm[j * SW + 1], c = cm[j * SW + 2];
                 f32x4 o;
-                o.x = fmaxf(prev.x, fmaxf(c0.x, c1.x)); o.y = fmaxf(prev.y, fmaxf(c0.y, c1.y));
-                o.z = fmaxf(prev.z, fmaxf(c0.z, c1.z)); o.w = fmaxf(prev.w, fmaxf(c0.w, c1.w));
+                o.x = fmaxf(a.x, fmaxf(b.x, c.x)); o.y = fmaxf(a.y, fmaxf(b.y, c.y));
+                o.z = fmaxf(a.z, fmaxf(b.z, c.z)); o.w = fmaxf(a.w, fmaxf(b.w, c.w));
+                const int wl = wo * SW - d.pW;
+                if (pad_zero && (th_clipped || wl < 0 || wl + 3 > d.Wi)) {
+                    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                }
                 *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ldy) = o;
-                prev = c1;
+            }
+        }
+    }
+}
+
+// 3 x 3 windows along (H, W) with equal stride S in {1, 2}: a thread produces an HSEG x WSEG patch of one
+// (n, to, 4-channel group).  Every input row of the patch's halo is loaded once per temporal tap, reduced along W into
+// WSEG row maxima and folded into the (up to three) output rows whose window holds it: kT * NR * NC loads for
+// HSEG * WSEG outputs (4 x 4, S = 1, kT = 3: 6.75 per output where the W-sliding kernel above needs 13.5 and the
+// generic one 27) -- the stride-1 SAME pools of the Inception branches are L1/L2-request bound, not HBM bound.
+template <int HSEG, int WSEG, int S, int NB>
+__global__ void __launch_bounds__(256) maxpool3d_tile_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
+                                                             float* __restrict__ y, unsigned total) {
+    constexpr int NR = (HSEG - 1) * S + 3, NC = (WSEG - 1) * S + 3;
+    constexpr int RB = NB == 0 ? 1 : (NR + NB - 1) / NB;       // halo rows whose loads are issued together
+    const int f4r = (d.C + 3) / 4;
+    const int ldy = d.ldy ? d.ldy : d.ld;
+    const int wsegs = (d.Wo + WSEG - 1) / WSEG, hsegs = (d.Ho + HSEG - 1) / HSEG;
+    const bool pad_zero = (d.flags & PTX_POOL_PAD_ZERO) != 0;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int q = (int)(i % (unsigned)f4r);
+        unsigned r = i / (unsigned)f4r;
+        const int ws = (int)(r % (unsigned)wsegs);
+        r /= (unsigned)wsegs;
+        const int hs = (int)(r % (unsigned)hsegs);
+        r /= (unsigned)hsegs;
+        const int to = (int)(r % (unsigned)d.To);
+        const int n = (int)(r / (unsigned)d.To);
+        const int t_lo = max(0, to * d.sT - d.pT), t_hi = min(d.Ti, to * d.sT - d.pT + d.kT);
+        const bool t_clipped = (t_hi - t_lo) != d.kT;
+        const int ho0 = hs * HSEG, wo0 = ws * WSEG;
+        const int h0 = ho0 * S - d.pH, w0 = wo0 * S - d.pW;
+        unsigned live_c = 0, live_r = 0;                      // halo columns / rows inside the input that a live window uses
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (w0 + c >= 0 && w0 + c < d.Wi && wo0 + (c < 3 ? 0 : (c - 2 + S - 1) / S) < d.Wo) live_c |= 1u << c;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (h0 + rr >= 0 && h0 + rr < d.Hi && ho0 + (rr < 3 ? 0 : (rr - 2 + S - 1) / S) < d.Ho) live_r |= 1u << rr;
+        f32x4 o[HSEG][WSEG];
+#pragma unroll
+        for (int a = 0; a < HSEG; ++a)
+#pragma unroll
+            for (int b = 0; b < WSEG; ++b) o[a][b] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const float* base = x + ((size_t)n * d.Ti * d.Hi * d.Wi) * d.ld + q * 4;
+        for (int t = t_lo; t < t_hi; ++t) {
+            const float* plane = base + (((ptrdiff_t)t * d.Hi + h0) * d.Wi + w0) * (ptrdiff_t)d.ld;
+#pragma unroll
+            for (int r0 = 0; r0 < NR; r0 += RB) {
+                // NB = 0: one row at a time; the (wave-divergent) skip of a dead row also keeps the compiler from hoisting
+                // every row's loads to the top (256 VGPRs + scratch, measured 2x slower on the big stride-2 pools)
+                if (RB == 1 && !(live_r >> r0 & 1)) continue;
+                f32x4 v[RB][NC];
+#pragma unroll
+                for (int k = 0; k < RB; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        v[k][c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        if (r0 + k < NR && (live_r >> (r0 + k) & 1) && (live_c >> c & 1))
+                            v[k][c] = *reinterpret_cast<const f32x4*>(plane + ((ptrdiff_t)(r0 + k) * d.Wi + c) * d.ld);
+                    }
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int rr = r0 + k;                    // a dead row folds -inf: harmless
+                    if (rr >= NR) break;
+#pragma unroll
+                    for (int b = 0; b < WSEG; ++b) {
+                        f32x4 m;
+                        m.x = fmaxf(v[k][b * S].x, fmaxf(v[k][b * S + 1].x, v[k][b * S + 2].x));
+                        m.y = fmaxf(v[k][b * S].y, fmaxf(v[k][b * S + 1].y, v[k][b * S + 2].y));
+                        m.z = fmaxf(v[k][b * S].z, fmaxf(v[k][b * S + 1].z, v[k][b * S + 2].z));
+                        m.w = fmaxf(v[k][b * S].w, fmaxf(v[k][b * S + 1].w, v[k][b * S + 2].w));
+#pragma unroll
+                        for (int a = 0; a < HSEG; ++a)
+                            if (rr >= a * S && rr <= a * S + 2) {
+                                o[a][b].x = fmaxf(o[a][b].x, m.x); o[a][b].y = fmaxf(o[a][b].y, m.y);
+                                o[a][b].z = fmaxf(o[a][b].z, m.z); o[a][b].w = fmaxf(o[a][b].w, m.w);
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < HSEG; ++a) {
+            const int ho = ho0 + a;
+            if (ho >= d.Ho) break;
+            const int hl = ho * S - d.pH;
+            const bool th_clipped = t_clipped || hl < 0 || hl + 3 > d.Hi;
+            float* yrow = y + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo) * ldy + q * 4;
+#pragma unroll
+            for (int b = 0; b < WSEG; ++b) {
+                const int wo = wo0 + b;
+                if (wo < d.Wo) {
+                    f32x4 v = o[a][b];
+                    const int wl = wo * S - d.pW;
+                    if (pad_zero && (th_clipped || wl < 0 || wl + 3 > d.Wi)) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(yrow + (size_t)wo * ldy) = v;
+                }
             }
         }
     }
@@ -530,11 +649,32 @@ extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float
         if (to != d->To || ho != d->Ho || wo != d->Wo) return fail(PTX_ERR_INVALID, "maxpool3d: output extent mismatch");
     }
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "maxpool3d: misaligned pointer");
-    if (d->flags == 0 && d->kW == 3 && d->sW == 2 && d->pW == 1 && d->Wo >= 8) {
-        constexpr int WSEG = 8;
+    const hipStream_t st = (hipStream_t)stream;
+    if (d->kW == 3 && d->kH == 3 && d->sH == d->sW && (d->sW == 1 || d->sW == 2) && d->pW < 3 && d->pH < 3) {
+        // measured on the config-2/3/4 geometries (scripts/gpu_pool_bench.py): 2 x 2 patches with a whole halo plane in
+        // flight win wherever a launch is short of threads (latency bound); the big stride-1 pools (I3D at batch 8)
+        // take 4 x 4 patches, one halo row in flight.  PTX_POOL_TILE=44|22 forces one of them.
+        static const int tile_env = getenv("PTX_POOL_TILE") ? atoi(getenv("PTX_POOL_TILE")) : 0;
+        const size_t total44 = (size_t)d->N * d->To * cdiv(d->Ho, 4) * cdiv(d->Wo, 4) * (c4 / 4);
+        const bool big = tile_env ? tile_env == 44 : (d->sW == 1 && total44 >= 400000);
+        const int seg = big ? 4 : 2;
+        const size_t total = (size_t)d->N * d->To * cdiv(d->Ho, seg) * cdiv(d->Wo, seg) * (c4 / 4);
+        if (total < (1ull << 31)) {
+            const dim3 g(grid_for(total)), b(256);
+            const unsigned n = (unsigned)total;
+            if (big && d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 1, 0>), g, b, 0, st, *d, x, y, n);
+            else if (big) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 2, 0>), g, b, 0, st, *d, x, y, n);
+            else if (d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 1, 1>), g, b, 0, st, *d, x, y, n);
+            else hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 2, 1>), g, b, 0, st, *d, x, y, n);
+            return hip_check(hipGetLastError(), "maxpool3d launch");
+        }
+    }
+    if (d->kW == 3 && (d->sW == 1 || d->sW == 2) && d->pW < 3 && d->Wo >= 4) {
+        constexpr int WSEG = 4;                               // 8 measured 1.4x slower (fewer threads, same loads in flight)
         const size_t total = (size_t)d->N * d->To * d->Ho * cdiv(d->Wo, WSEG) * (c4 / 4);
-        hipLaunchKernelGGL(maxpool3d_slide_kernel<WSEG>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d, x,
-                           y, total);
+        const dim3 g(grid_for(total)), b(256);
+        if (d->sW == 2) hipLaunchKernelGGL((maxpool3d_slide_kernel<WSEG, 2>), g, b, 0, st, *d, x, y, total);
+        else hipLaunchKernelGGL((maxpool3d_slide_kernel<WSEG, 1>), g, b, 0, st, *d, x, y, total);
         return hip_check(hipGetLastError(), "maxpool3d launch");
     }
     const size_t total4 = (size_t)d->N * d->To * d->Ho * d->Wo * (c4 / 4);

@@ -329,7 +329,13 @@ def test_maxpool(ptx):
     L, lib = ptx._lib, _lib(ptx)
     for (N, T, H, W, Cc, k, s, p) in [(2, 6, 13, 12, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
                                       (1, 1, 15, 15, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
-                                      (2, 5, 8, 8, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1))]:
+                                      (2, 5, 8, 8, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                      (1, 3, 9, 21, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # stride-1 sliding windows
+                                      (1, 2, 6, 19, 8, (1, 3, 3), (1, 1, 1), (0, 1, 0)),
+                                      (1, 2, 5, 35, 12, (2, 3, 3), (2, 2, 2), (1, 0, 1)),
+                                      (1, 4, 6, 19, 8, (2, 2, 3), (2, 2, 1), (1, 1, 1)),       # W-sliding kernel (kH != 3)
+                                      (1, 3, 7, 21, 8, (1, 5, 3), (1, 1, 2), (0, 2, 1)),
+                                      (1, 2, 6, 9, 8, (1, 3, 2), (1, 1, 2), (0, 1, 1))]:       # generic kernel (kW != 3)
         x = rnd(N, Cc, T, H, W, seed=30)
         want = F.max_pool3d(x, k, s, p)
         xd = to_cl(x)
@@ -534,7 +540,9 @@ def test_maxpool_same_slices_copy_and_window_mean(ptx):
     L, lib = ptx._lib, _lib(ptx)
     # TF-"SAME" pooling with zero-valued padding (F.pad + MaxPool3d), output into a channel slice
     for (N, T, H, W, Cc, k, s) in [(2, 5, 14, 14, 24, (1, 3, 3), (1, 2, 2)), (1, 7, 9, 11, 16, (3, 3, 3), (2, 2, 2)),
-                                   (2, 4, 7, 7, 32, (2, 2, 2), (2, 2, 2)), (1, 4, 6, 6, 12, (3, 3, 3), (1, 1, 1))]:
+                                   (2, 4, 7, 7, 32, (2, 2, 2), (2, 2, 2)), (1, 4, 6, 6, 12, (3, 3, 3), (1, 1, 1)),
+                                   (1, 3, 10, 28, 16, (3, 3, 3), (1, 1, 1)), (1, 4, 9, 37, 8, (3, 3, 3), (2, 2, 2)),
+                                   (4, 16, 26, 27, 512, (3, 3, 3), (1, 1, 1))]:     # enough threads for the 4 x 4 patches
         x = rnd(N, Cc, T, H, W, seed=90) - 0.5
         out = [-(-i // st) for i, st in zip((T, H, W), s)]
         tot = [max((o - 1) * st + kk - i, 0) for o, st, kk, i in zip(out, s, k, (T, H, W))]
