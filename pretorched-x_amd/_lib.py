@@ -116,6 +116,10 @@ SIGNATURES = {
     "ptx_ncdhw_to_split4": (C.c_int, [_P, _P, _I, _I, _L, _P]),
     "ptx_conv_stem_x3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv_stem_x3_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "ptx_conv_stem_f32_supported": (C.c_int, [C.POINTER(ConvDesc), _L, _L, _L]),
+    "ptx_stem_f32_weight_elems": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ptx_pack_stem_f32_weight": (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
+    "ptx_conv_stem_f32_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _L, _L, _P, _P, _P, _P]),
     "ptx_packed_weight_elems": (_Z, [C.POINTER(PackDesc)]),
     "ptx_pack_conv_weight": (C.c_int, [C.POINTER(PackDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "ptx_checksum_f32": (C.c_int, [_P, _I, _P, _P]),

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["conv_igemm.hip", "pack_layout.hip", "pool_head.hip", "nonlocal_attn.hip", "conv_stem_x3.hip"]
+SOURCES = ["conv_igemm.hip", "pack_layout.hip", "pool_head.hip", "nonlocal_attn.hip", "conv_stem_x3.hip", "conv_stem_f32.hip"]
 HEADERS = ["ptx_common.h", os.path.join("..", "..", "include", "ptx_amd.h")]
 LIB = os.path.join(PKG, "libptx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

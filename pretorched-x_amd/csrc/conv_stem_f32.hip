@@ -1,0 +1,383 @@
+// RGB stem convolution on the fp32 matrix cores, straight from the caller's NCDHW tensor:
+// Conv3d(3, 64, 7, stride (1,2,2), pad 3) + BN + ReLU of the ResNet3D family (resnet3D.py:153-155), the 2-D ResNet stem
+// (torchvision_models.py), the (1,7,7) spatial stem of the (2+1)D nets (r2plus1d.py:73-88), the SAME-padded I3D stem.
+//
+// Why a dedicated kernel.  On the generic implicit-GEMM tiles the stem is a (7,7,1) conv over a kW-FOLDED copy of the
+// input (ptx_fold_kw_ncdhw: 77 MB -> 308 MB at config 2), and every (kt, kh) tap re-stages its A tile global -> VGPR ->
+// LDS behind a barrier: the fp32 MFMA pipe sits at 75 %, plus the 82 us fold pass.  Here a workgroup owns
+// 512 consecutive outputs of one output frame, stages the INPUT PATCH of a temporal tap once with LDS-DMA -- three
+// channel planes of PR rows x PC floats, exactly the caller's NCDHW rows (16-byte pieces, zero outside the image) --
+// and serves all kH x 7 taps of that frame from it.  No fold, no layout pass: the kernel reads the user tensor.
+//
+// K axis of one (kt, kh) tap: 21 = 3 channels x 7 kw, issued as 11 v_mfma_f32_32x32x2_f32 (k = 2 per instruction; lanes
+// 0-31 hold k0, lanes 32-63 hold k1 =: g).  Pairing keeps the g-dependence of the A address a constant:
+//     j = 3c + p (j < 9): (c, kw = 2p + g)         -- one float apart
+//     j = 9             : (c = g, kw = 6)          -- one plane apart
+//     j = 10            : (c = 2, kw = 6) | zero
+// so a fragment is one ds_read_b32 at (patch row r*sH + kh, column wo*sW + shift + kw) of plane c.  The filter comes
+// from ptx_pack_stem_f32_weight in exactly that order ([tap][64-channel tile][11][2][64] floats, conflict-free reads).
+// Arithmetic: fp32 operands, fp32 accumulate -- the reference's own.
+#include "ptx_common.h"
+#include <algorithm>
+
+namespace ptx {
+
+struct StemF32Args {
+    const float* x;       // NCDHW (strides below, in floats)
+    const float* w;       // [kT*kH][w_tiles][11][2][64]
+    const float* bias;
+    float* y;             // [N][To][Ho][Wo][ldy]
+    int N, Ti, Hi, Wi, To, Ho, Wo, ldy, ncol;
+    int kT, kH, sT, sH, sW, pT, pH;
+    int sn, sc, st;       // batch / channel / frame strides of x
+    int PR, PC, plane;    // patch rows, floats per patch row (multiple of 4), PR * PC
+    int shift, wbase;     // patch column 0 is input column wbase (<= 0, multiple of 4); a window starts at wo*sW + shift
+    int tiles_per_frame, n_tiles, n_pieces, w_tiles;
+    unsigned flags;
+    unsigned x_bytes, w_bytes, y_bytes;
+    unsigned dv_wo[2];
+};
+
+constexpr int kF32Waves = 8;                       // 8 waves x 64 rows: two waves per SIMD
+constexpr int kF32NT = 64 * kF32Waves;
+constexpr int kF32Rows = 64 * kF32Waves;           // outputs per workgroup
+constexpr int kF32BN = 64;                         // output channels per workgroup
+constexpr int kF32PatchMax = 12288;                // floats of one patch buffer: 48 KiB
+constexpr int kF32K2 = 11;                         // MFMAs per (kt, kh) tap
+constexpr int kF32BTile = kF32K2 * 2 * kF32BN;     // floats of one (tap, channel tile) filter block: 5.5 KiB
+constexpr int kF32BBuf = 1536;                     // LDS floats per filter buffer: whole 1-KiB DMA pieces (6 waves)
+constexpr int kF32PiecesPerWave = kF32PatchMax / 4 / 64 / kF32Waves;   // 6
+
+__device__ __forceinline__ unsigned f32_fdiv(unsigned n, const unsigned (&dv)[2]) {
+    return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
+}
+static inline void f32_fdiv_make(unsigned d, unsigned (&out)[2]) {
+    if (d <= 1) { out[0] = 0; out[1] = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    out[0] = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+    out[1] = l - 1;
+}
+
+__global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [2][kF32PatchMax]
+    float* Bs = smem + 2 * kF32PatchMax;                // [3][kF32BBuf]
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile order: the frames of one band of rows follow each other (temporal L2 reuse of the kT-frame window), an XCD
+    // owns a contiguous chunk of the list
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int nt = blockIdx.y;
+    const int to = tile % p.To;
+    int t_ = tile / p.To;
+    const int band = t_ % p.tiles_per_frame;
+    const int n = t_ / p.tiles_per_frame;
+    const int m0 = band * kF32Rows;                     // first output (raster index inside the frame)
+    const int ho_a = (int)f32_fdiv((unsigned)m0, p.dv_wo);
+    const int h_base = ho_a * p.sH - p.pH;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-lane DMA sources of the patch pieces this wave moves (frame independent) ----
+    unsigned a_src[kF32PiecesPerWave];
+    const int pc4 = p.PC >> 2, plane4 = p.plane >> 2;
+#pragma unroll
+    for (int i = 0; i < kF32PiecesPerWave; ++i) {
+        const int q = (wave + kF32Waves * i) * 64 + lane;            // 16-byte piece of the patch
+        const int c = q / plane4;                                     // (once per thread: plain divisions)
+        const int rem = q - c * plane4;
+        const int pr = rem / pc4;
+        const int h = h_base + pr, w = (rem - pr * pc4) * 4 + p.wbase;
+        const bool ok = c < 3 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+        a_src[i] = ok ? (unsigned)((c * p.sc + h * p.Wi + w) * 4) : kOOB;
+    }
+    const unsigned b_src = tid < kF32BTile / 4 ? (unsigned)((nt * kF32BTile + tid * 4) * 4) : kOOB;
+
+    // ---- valid temporal taps (uniform): frames outside the clip contribute nothing ----
+    const int t_first = to * p.sT - p.pT;
+    const int kt_lo = max(0, -t_first), kt_hi = min(p.kT - 1, p.Ti - 1 - t_first);
+    const int n_kt = kt_hi - kt_lo + 1;
+
+    auto issue_a_piece = [&](int buf, int i, int kt) {
+        if (wave + kF32Waves * i < p.n_pieces) {
+            const unsigned fbase = (unsigned)(n * p.sn + (t_first + kt) * p.st) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(As + buf * kF32PatchMax + (wave + kF32Waves * i) * 256), 16,
+                                                     a_src[i] == kOOB ? kOOB : a_src[i] + fbase, 0, 0, 0);
+        }
+    };
+    auto issue_b = [&](int buf, int kt, int kh) {
+        const unsigned tbase = (unsigned)((kt * p.kH + kh) * p.w_tiles * kF32BTile * 4);
+        if (wave * 64 < kF32BTile / 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kF32BBuf + wave * 256), 16,
+                                                     b_src == kOOB ? kOOB : b_src + tbase, 0, 0, 0);
+    };
+
+    // ---- this lane's output rows: ml = m0 + wave * 64 + i * 32 + lane % 32 -> (ho, wo) ----
+    const int g = lane >> 5, l32 = lane & 31;
+    int a_row[2];            // float offset of (patch row (ho - ho_a) * sH, column wo * sW + shift)
+    bool row_ok[2];
+    int m_out[2];
+    const int frame_out = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = m0 + wave * 64 + i * 32 + l32;
+        row_ok[i] = ml < frame_out;
+        const int mm = row_ok[i] ? ml : m0;
+        const int ho = (int)f32_fdiv((unsigned)mm, p.dv_wo);
+        const int wo = mm - ho * p.Wo;
+        a_row[i] = ((ho - ho_a) * p.sH) * p.PC + wo * p.sW + p.shift;
+        m_out[i] = (n * p.To + to) * frame_out + mm;
+    }
+    // K pairing (see the header): five address flavours per row tile, fixed for the whole kernel -- a step only adds its
+    // (patch buffer, kh) offset, so the loop spends ~0.3 VALU instructions per MFMA on addresses (every VALU issue slot is
+    // taken from the MFMA pipe: scripts/micro/mfma_stem_probe.hip)
+    int a_base[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_base[i][0] = a_row[i] + g;                      // j = 0..2 : plane 0, kw = 2p + g
+        a_base[i][1] = a_row[i] + g + p.plane;            // j = 3..5 : plane 1
+        a_base[i][2] = a_row[i] + g + 2 * p.plane;        // j = 6..8 : plane 2
+        a_base[i][3] = a_row[i] + g * p.plane + 6;        // j = 9    : (c = g, kw = 6)
+        a_base[i][4] = a_row[i] + 2 * p.plane + 6;        // j = 10   : (c = 2, kw = 6) | g = 1 multiplies a zero
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- main loop: one step per (kt, kh) tap.  The fragment registers of k-pair group q are refilled for step s + 1 right
+    // after the MFMAs of group q of step s have issued, so no MFMA ever waits on LDS (before: all 8 waves bursting their
+    // ds_reads after the barrier).  Needs tile s + 1 landed at barrier(s): three filter slots, and the next frame's patch
+    // staged over kh = 0 .. kH-2.
+    const int n_steps = n_kt * p.kH;
+    float fa[2][kF32K2], fb[2][kF32K2];
+    auto load_group = [&](int q, const float* Ab, const float* Bb) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int j = q * 3 + t;
+            if (j < kF32K2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i][j] = j < 9 ? Ab[a_base[i][j / 3] + 2 * (j % 3)] : Ab[a_base[i][j - 6]];
+                fb[0][j] = Bb[j * 2 * kF32BN];
+                fb[1][j] = Bb[j * 2 * kF32BN + 32];
+            }
+        }
+    };
+    auto mma_group = [&](int q) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int j = q * 3 + t;
+            if (j < kF32K2) {
+                float a0 = fa[0][j], a1 = fa[1][j];
+                if (j == 10) { a0 = g ? 0.f : a0; a1 = g ? 0.f : a1; }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[0][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[1][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[0][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[1][j], acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+    if (n_steps > 0) {
+        // prologue: the first patch, filter tiles 0 and 1; then the fragments of step 0
+#pragma unroll
+        for (int i = 0; i < kF32PiecesPerWave; ++i) issue_a_piece(0, i, kt_lo);
+        issue_b(0, kt_lo, 0);
+        if (n_steps > 1) issue_b(1, kt_lo, 1);           // (kH >= 2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_group(q, As, Bs + g * kF32BN + l32);
+        const int per = (kF32PiecesPerWave + p.kH - 2) / (p.kH - 1);     // patch pieces per step, kh = 0 .. kH-2
+        int ik = 0, kh = 0, slot = 0;                     // state of step s: frame, row tap, filter slot
+        for (int s = 0; s < n_steps; ++s) {
+            if (s > 0) {
+                // tile s + 1 (issued during step s - 1) has landed for everyone; slot (s + 2) % 3 and, at a frame change,
+                // the other patch buffer are free: their last LDS reads were issued during step s - 2 / s - 1 and consumed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            int kh1 = kh + 1, ik1 = ik;                   // (kt, kh) of steps s + 1 and s + 2
+            if (kh1 == p.kH) { kh1 = 0; ++ik1; }
+            int kh2 = kh1 + 1, ik2 = ik1;
+            if (kh2 == p.kH) { kh2 = 0; ++ik2; }
+            const int slot1 = slot == 2 ? 0 : slot + 1;
+            const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+            if (s + 2 < n_steps) issue_b(slot2, kt_lo + ik2, kh2);
+            if (ik + 1 < n_kt && kh < p.kH - 1) {
+                // the next frame's patch, spread over kh = 0 .. kH-2 (complete at the barrier of this frame's last step)
+                const int lo = kh * per, hi = lo + per;
+#pragma unroll
+                for (int i = 0; i < kF32PiecesPerWave; ++i)
+                    if (i >= lo && i < hi) issue_a_piece((ik & 1) ^ 1, i, kt_lo + ik + 1);
+            }
+            const bool more = s + 1 < n_steps;
+            const float* Ab = As + (ik1 & 1) * kF32PatchMax + kh1 * p.PC;
+            const float* Bb = Bs + slot1 * kF32BBuf + g * kF32BN + l32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mma_group(q);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) load_group(q, Ab, Bb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            kh = kh1; ik = ik1; slot = slot1;
+        }
+    }
+
+    // ---- epilogue: bias (+ folded BN) + ReLU; lane = output channel, 16 rows per accumulator tile ----
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = nt * kF32BN + j * 32 + l32;
+        const bool co_ok = co < p.ncol;
+        const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // accumulator element r of this lane belongs to tile row (r & 3) + 8 * (r >> 2) + 4 * g: fetch that
+                // row's output index / validity from the lane that owns it as an A row
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int m = __shfl(m_out[i], trow, 64);
+                const int ok = __shfl((int)row_ok[i], trow, 64);
+                float v = acc[i][j][r] + bv;
+                v = relu ? fmaxf(v, 0.f) : v;
+                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ok) ? off : kOOB, 0, 0);
+            }
+        }
+    }
+}
+
+// folded K-major filter [tap][Co_pad][Kc] (k = kw * 3 + c, ptx_pack_conv_weight with fold_kw = 1) -> the stem's
+// [tap][Co_pad / 64][11][2][64] blocks
+__global__ void __launch_bounds__(256) pack_stem_f32_kernel(const float* __restrict__ wf, float* __restrict__ out, int taps,
+                                                            int Co_pad, int Kc, int total) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int col = i & 63;
+        int r = i >> 6;
+        const int g = r & 1;
+        r >>= 1;
+        const int j = r % kF32K2;
+        r /= kF32K2;
+        const int tiles = Co_pad / kF32BN;
+        const int nt = r % tiles;
+        const int tap = r / tiles;
+        int c, kw;
+        if (j < 9) { c = j / 3; kw = 2 * (j % 3) + g; }
+        else if (j == 9) { c = g; kw = 6; }
+        else { c = 2; kw = 6; }
+        const bool zero = j == 10 && g == 1;
+        out[i] = zero ? 0.f : wf[((size_t)tap * Co_pad + nt * kF32BN + col) * Kc + kw * 3 + c];
+    }
+}
+
+struct StemF32Geom {
+    int PR, PC, shift, wbase, tiles_per_frame;
+};
+
+static bool stem_f32_geom(const ptx_conv3d_desc* d, StemF32Geom* g) {
+    const int frame = d->Ho * d->Wo;
+    // rows a 512-output raster span can touch
+    const int nrows = std::min(d->Ho, (kF32Rows - 1 + d->Wo - 1) / d->Wo + 1);
+    g->PR = (nrows - 1) * d->sH + d->kH;
+    g->wbase = -((d->pW + 3) / 4 * 4);
+    g->shift = -g->wbase - d->pW;
+    g->PC = ((d->Wo - 1) * d->sW + g->shift + d->kW + 3) / 4 * 4;
+    g->tiles_per_frame = cdiv(frame, kF32Rows);
+    return (int64_t)3 * g->PR * g->PC <= kF32PatchMax;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_conv_stem_f32_supported(const ptx_conv3d_desc* d, int64_t stride_n, int64_t stride_c, int64_t stride_t) {
+    if (!d) return 0;
+    if (d->flags & ~PTX_EPI_RELU) return 0;
+    if (d->Ci != 3 || d->kW != 7 || d->kT < 1 || d->kT > 8 || d->kH < 2 || d->kH > 8 || d->groups > 1 || d->Co_pad % kF32BN) return 0;
+    if (d->sW < 1 || d->sW > 2 || d->sH < 1 || d->sT < 1 || d->Wo < 1 || d->Ho < 1 || d->To < 1 || d->pW < 0 || d->pW > 8) return 0;
+    if (d->Wi % 4 || stride_n % 4 || stride_c % 4 || stride_t % 4) return 0;          // 16-byte DMA pieces of NCDHW rows
+    if (stride_t < (int64_t)d->Hi * d->Wi || stride_c < stride_t || stride_n < stride_c) return 0;
+    StemF32Geom g;
+    if (!stem_f32_geom(d, &g)) return 0;
+    if (((int64_t)(d->N - 1) * stride_n + 3 * stride_c) * 4 >= 0x80000000LL ||
+        (int64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4 >= 0x80000000LL)
+        return 0;
+    auto extent_ok = [](int in, int out, int k, int s, int p) {
+        if (out == (in + 2 * p - k) / s + 1) return true;
+        const int same = (in + s - 1) / s;
+        const int total = std::max((same - 1) * s + k - in, 0);
+        return out == same && p == total / 2;
+    };
+    if (!extent_ok(d->Wi, d->Wo, d->kW, d->sW, d->pW) || !extent_ok(d->Hi, d->Ho, d->kH, d->sH, d->pH) ||
+        !extent_ok(d->Ti, d->To, d->kT, d->sT, d->pT))
+        return 0;
+    return 1;
+}
+
+extern "C" size_t ptx_stem_f32_weight_elems(const ptx_conv3d_desc* d) {
+    if (!d || d->Co_pad <= 0 || d->Co_pad % kF32BN || d->kT <= 0 || d->kH <= 0) return 0;
+    return (size_t)d->kT * d->kH * (d->Co_pad / kF32BN) * kF32BTile;
+}
+
+extern "C" int ptx_pack_stem_f32_weight(const ptx_conv3d_desc* d, const float* w_folded, int Kc, float* w_stem, ptx_stream_t stream) {
+    if (!d || !w_folded || !w_stem) return fail(PTX_ERR_INVALID, "pack_stem_f32: null pointer");
+    if (d->Ci != 3 || d->kW != 7 || Kc < 21 || d->Co_pad % kF32BN || d->kT <= 0 || d->kH <= 0)
+        return fail(PTX_ERR_UNSUPPORTED, "pack_stem_f32: a folded 3-channel, kW = 7 filter with rows of >= 21 floats");
+    const size_t total = ptx_stem_f32_weight_elems(d);
+    if (total >= (1ull << 31)) return fail(PTX_ERR_UNSUPPORTED, "pack_stem_f32: filter too large");
+    hipLaunchKernelGGL(pack_stem_f32_kernel, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w_folded, w_stem, d->kT * d->kH, d->Co_pad, Kc, (int)total);
+    return hip_check(hipGetLastError(), "pack_stem_f32 launch");
+}
+
+extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_t,
+                                     const float* w_stem, const float* bias, float* y, ptx_stream_t stream) {
+    if (!d || !x || !w_stem || !y) return fail(PTX_ERR_INVALID, "conv_stem_f32: null pointer");
+    if (((uintptr_t)x | (uintptr_t)w_stem | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "conv_stem_f32: pointers must be 16-byte aligned");
+    if (!ptx_conv_stem_f32_supported(d, stride_n, stride_c, stride_t))
+        return fail(PTX_ERR_UNSUPPORTED, "conv_stem_f32: needs a 3-channel NCDHW input (W and strides multiples of 4 floats), kW == 7, "
+                    "stride_w <= 2, symmetric or SAME padding, only the ReLU epilogue, and an input patch of at most %d floats", kF32PatchMax);
+    if (d->ldy < d->Co || d->ldy % 4) return fail(PTX_ERR_INVALID, "conv_stem_f32: bad output stride");
+    StemF32Geom g;
+    stem_f32_geom(d, &g);
+    StemF32Args a{};
+    a.x = x; a.w = w_stem; a.bias = bias; a.y = y;
+    a.N = d->N; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.ldy = d->ldy;
+    a.ncol = (d->Co + 3) / 4 * 4;
+    a.kT = d->kT; a.kH = d->kH; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.pT = d->pT; a.pH = d->pH;
+    a.sn = (int)stride_n; a.sc = (int)stride_c; a.st = (int)stride_t;
+    a.PR = g.PR; a.PC = g.PC; a.plane = g.PR * g.PC; a.shift = g.shift; a.wbase = g.wbase;
+    a.tiles_per_frame = g.tiles_per_frame;
+    a.n_tiles = d->N * d->To * g.tiles_per_frame;
+    a.n_pieces = cdiv(3 * a.plane / 4, 64);
+    a.w_tiles = d->Co_pad / kF32BN;
+    a.flags = d->flags;
+    a.x_bytes = (unsigned)(((uint64_t)(d->N - 1) * stride_n + 3ull * stride_c) * 4ull);
+    a.w_bytes = (unsigned)(ptx_stem_f32_weight_elems(d) * 4ull);
+    a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
+    f32_fdiv_make((unsigned)d->Wo, a.dv_wo);
+    constexpr size_t lds = (size_t)(2 * kF32PatchMax + 3 * kF32BBuf) * sizeof(float);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)cdiv(a.ncol, kF32BN));
+    hipLaunchKernelGGL(conv_stem_f32_kernel, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "conv_stem_f32 launch");
+}

@@ -370,9 +370,22 @@ class ConvStep:
 class StemStep:
     """One ptx_conv_stem_x3_fwd launch (split-operand stem read from 4-channel positions)."""
     __slots__ = ("d", "x", "w", "b", "y", "label", "macs", "hbm_bytes")
+    kernel = "conv_stem_x3"
 
     def __call__(self, st):
         check(_lib.lib().ptx_conv_stem_x3_fwd(C.byref(self.d), self.x, self.w, self.b, self.y, st), self.label)
+
+
+class StemF32Step:
+    """One ptx_conv_stem_f32_fwd launch: the RGB stem on the fp32 matrix cores, read straight from the caller's NCDHW
+    tensor (bound per run: plan.in_ptr) -- no fold, no layout pass."""
+    __slots__ = ("d", "plan", "strides", "w", "b", "y", "label", "macs", "hbm_bytes")
+    kernel = "conv_stem_f32"
+
+    def __call__(self, st):
+        sn, sc, stt = self.strides
+        check(_lib.lib().ptx_conv_stem_f32_fwd(C.byref(self.d), self.plan.in_ptr, sn, sc, stt, self.w, self.b, self.y, st),
+              self.label)
 
 
 class Plan:
@@ -601,7 +614,11 @@ class Plan:
         """Split-operand stems skip the kW fold: the input becomes [N,T,H,W,4] (16-byte positions) and
         ptx_conv_stem_x3_fwd serves every (kh, kw) tap of a temporal tap from one staged input patch.  Returns None when
         the kernel does not cover the geometry (the folded implicit-GEMM path then runs)."""
-        if not self.x3 or os.environ.get("PTX_STEM_DIRECT", "1") == "0" or raw.norm is not None or raw.t_step != 1:
+        if os.environ.get("PTX_STEM_DIRECT", "1") == "0" or raw.norm is not None:
+            return None
+        if not self.x3:
+            return self.stem_direct_f32(raw, conv, bn, relu, label)
+        if raw.t_step != 1:
             return None
         if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or raw.C > 4:
             return None
@@ -630,6 +647,48 @@ class Plan:
         y = self.act(raw.N, To, Ho, Wo, conv.out_channels)
         st = StemStep()
         st.d, st.x, st.w, st.b, st.y, st.label = d, _ptr(x4.t), _ptr(pk.w), _ptr(pk.b), _ptr(y.t), label
+        st.macs = raw.N * To * Ho * Wo * conv.out_channels * raw.C * kT * kH * kW
+        st.hbm_bytes = 0
+        self.steps.append(st)
+        self.stem_steps = getattr(self, "stem_steps", 0) + 1
+        return y
+
+    def stem_direct_f32(self, raw, conv, bn, relu, label):
+        """fp32 stems skip the kW fold as well: ptx_conv_stem_f32_fwd LDS-DMAs the input patch of a temporal tap from the
+        user's NCDHW tensor (frame sub-sampling is a stride) and serves every (kh, kw) tap from it.  Returns None when the
+        kernel does not cover the geometry (the folded implicit-GEMM path then runs)."""
+        if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or raw.C != 3 or getattr(self, "f16", False):
+            return None
+        if conv.out_channels <= 32:       # 64-wide channel tiles: SlowFast's 8-channel fast stem keeps the narrow tiles
+            return None
+        (kT, kH, kW), (sT, sH, sW), (pT, pH, pW) = _geom(conv)
+        if getattr(conv, "tf_same", False):     # I3D's Unit3D: out = ceil(in / stride), front pad = total // 2
+            (To, Ho, Wo), (pT, pH, pW) = _same_geometry((raw.T, raw.H, raw.W), (kT, kH, kW), (sT, sH, sW))
+        else:
+            To, Ho, Wo = (raw.T + 2 * pT - kT) // sT + 1, (raw.H + 2 * pH - kH) // sH + 1, (raw.W + 2 * pW - kW) // sW + 1
+        d = ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = raw.N, raw.T, raw.H, raw.W, 3, 0
+        d.To, d.Ho, d.Wo, d.Co = To, Ho, Wo, conv.out_channels
+        d.ldy = _r4(conv.out_channels)
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
+        d.Co_pad = _r128(conv.out_channels)
+        d.flags = PTX_EPI_RELU if relu else 0
+        plane = raw.H * raw.W
+        strides = (raw.C * raw.T_full * plane, raw.T_full * plane, raw.t_step * plane)
+        if min(To, Ho, Wo) < 1 or not self.lib.ptx_conv_stem_f32_supported(C.byref(d), *strides):
+            return None
+        pk = self.pack(conv, bn, fold_kw=True, x3=False)          # [tap][Co_pad][Kc], k = kw * 3 + c, BN folded
+        d.Kc = pk.Kc
+        w2 = torch.empty(self.lib.ptx_stem_f32_weight_elems(C.byref(d)), device=self.dev, dtype=torch.float32)
+        self.keepalive.append(w2)
+        lib, wf, w2p, Kc = self.lib, _ptr(pk.w), _ptr(w2), pk.Kc
+
+        def repack():
+            check(lib.ptx_pack_stem_f32_weight(C.byref(d), wf, Kc, w2p, _stream()), "ptx_pack_stem_f32_weight")
+        self.refreshers.append(repack)
+        y = self.act(raw.N, To, Ho, Wo, conv.out_channels)
+        st = StemF32Step()
+        st.d, st.plan, st.strides, st.w, st.b, st.y, st.label = d, self, strides, w2p, _ptr(pk.b), _ptr(y.t), label
         st.macs = raw.N * To * Ho * Wo * conv.out_channels * raw.C * kT * kH * kW
         st.hbm_bytes = 0
         self.steps.append(st)
@@ -924,6 +983,11 @@ class Plan:
         if out is None:     # user-supplied head module (Identity, Dropout, custom nn.Module): theirs to run
             out = model.head_module(self.pooled.clone())
         return out
+
+    def all_convs(self):
+        """Every convolution launch of the plan in execution order: the implicit-GEMM steps (`conv_steps`, what the
+        autotuner owns) and the direct stem kernels."""
+        return [s for s in self.steps if isinstance(s, (ConvStep, StemStep, StemF32Step))]
 
     def refresh_weights(self, model):
         """Re-pack every filter (and rebuild the weight-derived tables) from `model`'s current tensors."""
@@ -1502,7 +1566,7 @@ class Engine:
     def profile_steps(self, plan, iters=5):
         """HIP-event time of EVERY launch of a compiled (and run) plan on the current stream, convs and HBM-bound
         passes alike: rows of (label, kind, algorithmic bytes, MACs, ms, tile / kernel name).  kind is "conv" for the
-        implicit-GEMM launches, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
+        implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
         rows = []
         st = _stream()
         for stp in plan.steps:
@@ -1516,6 +1580,8 @@ class Engine:
             ms = e0.elapsed_time(e1) / iters
             if isinstance(stp, ConvStep):
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode()))
+            elif isinstance(stp, (StemStep, StemF32Step)):      # the direct stems are convs too, with their own kernels
+                rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
             else:
                 nb, macs = getattr(stp, "hbm_bytes", 0), getattr(stp, "macs", 0)
                 kind = "mem" if nb and not macs else "mfma" if macs else "other"

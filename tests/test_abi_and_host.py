@@ -238,33 +238,42 @@ def test_plan_compiler_matches_survey_worklist(ptx):
     """config 2 = 53 convs, 318.763 GMAC, 23 distinct problems.  The engine
     folds each stage's shortcut-B conv into the block's last conv (one K-concatenated GEMM), so it
     launches 49 kernels for the same 53 convs / the same MACs."""
+    from pretorched_x_amd.engine import StemF32Step
+    import os
+
+    def convs(pl):          # implicit-GEMM launches + the direct stem (its own kernel, not in conv_steps)
+        return pl.all_convs()
+
     m = ptx.resnet3d50(num_classes=339, pretrained=None)
     plan = m.engine().dry_plan(m, (8, 3, 16, 224, 224))
-    assert len(plan.conv_steps) == 49
+    assert len(plan.conv_steps) == 48 and len(convs(plan)) == 49
+    # the stem reads the caller's NCDHW tensor: no fold / layout pass in front of it
+    assert isinstance(plan.steps[0], StemF32Step) and plan.steps[0].strides == (3 * 16 * 224 * 224, 16 * 224 * 224, 224 * 224)
     fused = [s for s in plan.conv_steps if s.x2 is not None]
     assert [s.label for s in fused] == ["layer%d.0.conv3+downsample" % i for i in (1, 2, 3, 4)]
     assert (fused[1].d.x2_C, fused[1].d.x2_sT, fused[1].d.Ci, fused[1].d.Co) == (256, 2, 128, 512)
-    gmac = sum(s.macs for s in plan.conv_steps) / 1e9
+    gmac = sum(s.macs for s in convs(plan)) / 1e9
     assert abs(gmac - 318.763) < 0.01
-    import os
     os.environ["PTX_FUSE_SHORTCUT"] = "0"
+    os.environ["PTX_STEM_DIRECT"] = "0"          # the kW-folded implicit-GEMM stem (the fallback for geometries the kernel refuses)
     try:
         m2 = ptx.resnet3d50(num_classes=339, pretrained=None)
         plan2 = m2.engine().dry_plan(m2, (8, 3, 16, 224, 224))
     finally:
-        del os.environ["PTX_FUSE_SHORTCUT"]
+        del os.environ["PTX_FUSE_SHORTCUT"], os.environ["PTX_STEM_DIRECT"]
+    plan = plan2
     assert len(plan2.conv_steps) == 53
     geom = {s.d.key()[:22] for s in plan2.conv_steps}             # geometry only (no epilogue flags):
     assert len(geom) == 23                                        # C4 covers conv3 and the shortcut
     assert tuple(plan.feat.t.shape) == (8, 1, 7, 7, 2048)
-    stem = plan.conv_steps[0].d
+    stem = plan2.conv_steps[0].d
     assert (stem.Ci, stem.ldx, stem.kT, stem.kH, stem.kW, stem.Kc) == (21, 24, 7, 7, 1, 24)   # kW folded into channels
     for name, shape, gm in [("r2plus1d50", (1, 3, 32, 112, 112), 21.158), ("nonlocalresnet3d50", (1, 3, 32, 112, 112), 22.433),
                             ("nonlocal_r2plus1d50", (1, 3, 32, 112, 112), 24.035), ("resnet18", (1, 3, 224, 224), 1.8136)]:
         kw = dict(pretrained=None) if name in ("nonlocalresnet3d50", "resnet18") else {}
         mm = ptx.__dict__[name](**kw)
         pl = mm.engine().dry_plan(mm, shape)
-        assert abs(sum(s.macs for s in pl.conv_steps) / 1e9 - gm) < 0.01, name
+        assert abs(sum(s.macs for s in convs(pl)) / 1e9 - gm) < 0.01, name
 
 
 def test_every_factory_compiles_a_plan(ptx):
@@ -277,7 +286,7 @@ def test_every_factory_compiles_a_plan(ptx):
         m = ptx.__dict__[name](**kw)
         plan = m.engine().dry_plan(m, (1, 3, 8, 64, 64))
         if depth:     # conv layers of a bottleneck ResNet-d: d - 2 (+4 shortcut convs), 4 of them fused away
-            assert sum(1 + (s.x2 is not None) for s in plan.conv_steps) == depth - 2 + 4 + 1, name
+            assert sum(1 + (getattr(s, "x2", None) is not None) for s in plan.all_convs()) == depth - 2 + 4 + 1, name
         assert plan.feat.C == 512 * m.arch.expansion
     assert ptx.resnet3d200(pretrained=None).last_linear.out_features == 339      # reference quirk (num_classes unused)
     nl10 = ptx.nonlocalresnet3d50(num_nonlocal_blocks=10, pretrained=None)
@@ -341,8 +350,8 @@ def test_slowfast_plan_wiring_without_gpu(ptx):
     slices of one concatenated tensor (no torch.cat), both stems read strided frames."""
     m = ptx.slowfast.resnet50(num_classes=7)
     plan = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
-    steps = {s.label: s for s in plan.conv_steps}
-    assert len(plan.conv_steps) == 102
+    steps = {s.label: s for s in plan.all_convs()}
+    assert len(plan.all_convs()) == 102            # 101 implicit-GEMM launches + the slow pathway's direct stem
     for lat, (co, ld) in {"fast.lateral0": (16, 80), "fast.lateral1": (64, 320), "fast.lateral2": (128, 640),
                           "fast.lateral3": (256, 1280)}.items():
         d = steps[lat].d
@@ -355,10 +364,13 @@ def test_slowfast_plan_wiring_without_gpu(ptx):
     assert (d.x2_C, d.x2_sT, d.x2_sH, d.x2_sW) == (320, 1, 2, 2)
     assert tuple(plan.pooled.shape) == (2, 2304)
     assert steps["fast.conv1"].d.Ti == 32 and steps["slow.conv1"].d.Ti == 4
+    plane = 224 * 224       # the slow stem reads the caller's clip through frame strides (every 16th frame), no copy
+    assert steps["slow.conv1"].strides == (3 * 64 * plane, 64 * plane, 16 * plane)
+    assert not hasattr(steps["fast.conv1"], "strides")      # 8 output channels: the folded stem on the narrow tiles
     # pathway-only modes and the basic-block variant compile too
     for fac, mode, n in ((ptx.slowfast.resnet50, "S", 49), (ptx.slowfast.resnet50, "F", 49), (ptx.slowfast.resnet18, "SF", 45)):
         mm = fac(mode=mode, num_classes=3)
-        assert len(mm.engine().dry_plan(mm, (1, 3, 32, 64, 64)).conv_steps) == n
+        assert len(mm.engine().dry_plan(mm, (1, 3, 32, 64, 64)).all_convs()) == n
     m8 = ptx.slowfast.resnet50(num_classes=5, slow_stride=8)
     with pytest.raises(ptx.PtxError):
         m8.engine().dry_plan(m8, (1, 3, 32, 64, 64))
@@ -398,8 +410,8 @@ def test_standin_models_match_literature_shapes(ptx):
     m = ptx.i3d(400)
     n = sum(p.numel() for p in m.parameters())
     plan = m.engine().dry_plan(m, (1, 3, 64, 224, 224))
-    gmac = sum(s.macs for s in plan.conv_steps) / 1e9
-    assert len(plan.conv_steps) == 57
+    gmac = sum(s.macs for s in plan.all_convs()) / 1e9
+    assert len(plan.all_convs()) == 57
     assert abs(n / 12.3e6 - 1) < 0.05, n
     assert abs(gmac / 108.0 - 1) < 0.05, gmac
     g = ptx.biggan_deep(256)
@@ -431,23 +443,24 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     m = ptx.resnet3d50(num_classes=339, pretrained=None)
     eng = m.engine()
     base = eng.dry_plan(m, (2, 3, 16, 224, 224))
-    assert not base.x3 and not any(s.d.flags & L.PTX_F16X3_OPERANDS for s in base.conv_steps)
+    assert not base.x3 and not any(s.d.flags & L.PTX_F16X3_OPERANDS for s in base.all_convs())
+    assert isinstance(base.steps[0], engine.StemF32Step) and base.stem_steps == 1      # fp32: the direct NCDHW stem
     with pytest.raises(ptx.PtxError):
         eng.precision = "fp8"
     eng.precision = "x3"
     plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
     # the stem leaves the implicit-GEMM list: ptx_conv_stem_x3_fwd reads 4-channel positions, no kW fold
-    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps) - 1 and plan.stem_steps == 1
+    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps) and plan.stem_steps == 1
     stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
     assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"
     assert not any(getattr(s, "label", "") == "fold_kw" for s in plan.steps)
     for s in plan.conv_steps:
         assert s.d.flags & L.PTX_F16X3_OPERANDS and s.d.Kc % 8 == 0, s.label
         assert lib.ptx_conv3d_config_name(s.cfg).decode().endswith("/x3"), s.label
-    assert sum(s.macs for s in plan.conv_steps) + stem.macs == sum(s.macs for s in base.conv_steps)
+    assert sum(s.macs for s in plan.conv_steps) + stem.macs == sum(s.macs for s in base.all_convs())
     monkeypatch.setenv("PTX_STEM_DIRECT", "0")               # the folded implicit-GEMM stem on 32-float rows
     folded = eng.dry_plan(m, (2, 3, 16, 224, 224))
-    assert len(folded.conv_steps) == len(base.conv_steps)
+    assert len(folded.conv_steps) == len(base.all_convs())
     assert (folded.conv_steps[0].d.Kc, folded.conv_steps[0].d.ldx, folded.conv_steps[0].d.Ci) == (32, 32, 21)
     monkeypatch.delenv("PTX_STEM_DIRECT")
     # grouped convs (ResNeXt3D) are not split: they stay on the fp32 / direct tiles

@@ -1307,3 +1307,72 @@ def test_conv_stem_x3_direct(ptx):
     d.flags = L.PTX_EPI_RELU
     assert not lib.ptx_conv_stem_x3_supported(C.byref(d))
     assert lib.ptx_conv_stem_x3_fwd(C.byref(d), _p(xd), _p(wp), _p(bp), _p(yd), _st()) == 2
+
+
+def test_conv_stem_f32_direct(ptx):
+    """ptx_conv_stem_f32_fwd: the RGB stem on the fp32 matrix cores, read straight from the NCDHW tensor (no fold, no
+    layout pass) -- against Conv3d / Conv2d + BN + ReLU in torch fp32.  ResNet3D stem (7^3, stride (1,2,2)), the 2-D ResNet
+    stem, the (1,7,7) spatial stem of R2Plus1D with 110 output channels (two channel tiles, ragged), a strided-in-time stem,
+    full 112-wide rows (a 512-output span touching 6 rows), TF-SAME padding (I3D), and a frame-strided view
+    (`input[:, :, ::2]`) passed as strides."""
+    L, lib = ptx._lib, _lib(ptx)
+    cases = [  # N, T, H, W, Co, (kT,kH,kW), stride, pad, frame step
+        (2, 5, 30, 28, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3), 1),
+        (3, 1, 33, 40, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), 1),
+        (2, 4, 20, 20, 110, (1, 7, 7), (1, 2, 2), (0, 3, 3), 1),
+        (1, 9, 18, 24, 64, (7, 7, 7), (2, 2, 2), (3, 3, 3), 1),
+        (1, 3, 224, 224, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), 1),
+        (2, 6, 21, 24, 64, (7, 7, 7), (2, 2, 2), "same", 1),
+        (2, 4, 26, 36, 64, (3, 7, 7), (1, 1, 1), (1, 3, 3), 2),             # stride-1 windows, every other frame of 8
+    ]
+    for (N, T, H, W, Co, k, s_, p_, step) in cases:
+        full = rnd(N, 3, T * step, H, W, seed=180)
+        x = full[:, :, ::step]
+        w = rnd(Co, 3, *k, seed=181, scale=(3 * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 182)
+        if p_ == "same":
+            outs = [-(-i // st) for i, st in zip((T, H, W), s_)]
+            tot = [max((o - 1) * st + kk - i, 0) for o, st, kk, i in zip(outs, s_, k, (T, H, W))]
+            p_ = tuple(t // 2 for t in tot)
+            xp = F.pad(x, (tot[2] // 2, tot[2] - tot[2] // 2, tot[1] // 2, tot[1] - tot[1] // 2, tot[0] // 2, tot[0] - tot[0] // 2))
+            want = ref_conv(xp, w, s_, (0, 0, 0), bn=bn, relu=True)
+        else:
+            want = ref_conv(x, w, s_, p_, bn=bn, relu=True)
+        To, Ho, Wo = want.shape[2:]
+        xd = full.contiguous().to(DEV)
+        Co_pad = (Co + 127) // 128 * 128
+        Kc = 24
+        pd = L.PackDesc(Co, 3, k[0], k[1], k[2], Kc, Co_pad, 1)
+        wf = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(Co_pad, device=DEV)
+        ts = [t.to(DEV) for t in bn[:4]]
+        wd = w.contiguous().to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                         C.c_float(bn[4]), _p(wf), _p(bp), _st()), "pack folded")
+        ldy = _r4(Co)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, 3, 0
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, ldy
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = k[0], k[1], k[2], s_[0], s_[1], s_[2], p_[0], p_[1], p_[2]
+        d.Kc, d.Co_pad, d.flags = Kc, Co_pad, L.PTX_EPI_RELU
+        plane = H * W
+        sn, sc, st = 3 * T * step * plane, T * step * plane, step * plane
+        assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st), (N, T, H, W)
+        ws = torch.full((lib.ptx_stem_f32_weight_elems(C.byref(d)),), float("nan"), device=DEV)
+        L.check(lib.ptx_pack_stem_f32_weight(C.byref(d), _p(wf), Kc, _p(ws), _st()), "pack stem f32")
+        yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+        L.check(lib.ptx_conv_stem_f32_fwd(C.byref(d), _p(xd), sn, sc, st, _p(ws), _p(bp), _p(yd), _st()), "stem f32")
+        torch.cuda.synchronize()
+        got = from_cl(yd, Co)
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        assert err <= 2e-5, ((N, T, H, W, Co, k, s_, step), err)
+        pad = yd[..., Co:ldy]
+        assert pad.numel() == 0 or bool((pad == 0).all())
+    # refused, not mis-computed: a residual epilogue, a width that is not a multiple of 4, a 5-wide window
+    d.flags = L.PTX_EPI_RELU | L.PTX_EPI_RES_ADD
+    assert not lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st)
+    assert lib.ptx_conv_stem_f32_fwd(C.byref(d), _p(xd), sn, sc, st, _p(ws), _p(bp), _p(yd), _st()) == 2
+    d.flags, d.kW = L.PTX_EPI_RELU, 5
+    assert not lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st)
+    d.kW, d.Wi = 7, 38
+    assert not lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st)

@@ -264,12 +264,12 @@ def test_i3d_standin_and_plan(ptx):
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     assert (y.double() - I3.forward(sd64, x.double())).abs().max().item() < 1e-4
     plan = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
-    assert len(plan.conv_steps) == 57
+    assert len(plan.all_convs()) == 57
     assert (plan.feat.T, plan.feat.H, plan.feat.W, plan.feat.C) == (8, 7, 7, 1024)
-    gmac = sum(s.macs for s in plan.conv_steps) / 2 / 1e9
+    gmac = sum(s.macs for s in plan.all_convs()) / 2 / 1e9
     assert 105 < gmac < 115                                     # literature: ~108 G multiply-adds per 64x224x224 clip
-    stem = plan.conv_steps[0].d
-    assert (stem.To, stem.Ho, stem.Wo, stem.pT, stem.pH, stem.kT, stem.kH, stem.kW) == (32, 112, 112, 2, 2, 7, 7, 1)
+    stem = plan.all_convs()[0].d                                # the direct NCDHW stem, SAME padding: front pads 2
+    assert (stem.To, stem.Ho, stem.Wo, stem.pT, stem.pH, stem.pW, stem.kT, stem.kH, stem.kW) == (32, 112, 112, 2, 2, 2, 7, 7, 7)
     # branch outputs are channel slices of the module output (no torch.cat)
     lab = {s.label: s.d for s in plan.conv_steps}
     assert (lab["Mixed_3b.b0"].ldy, lab["Mixed_3b.b1b"].ldy, lab["Mixed_3b.b3b"].ldy) == (256, 256, 256)
