@@ -38,15 +38,15 @@ struct StemF32Args {
     unsigned dv_wo[2];
 };
 
-constexpr int kF32Waves = 8;                       // 8 waves x 64 rows: two waves per SIMD
+constexpr int kF32Waves = 4;                       // 4 waves x 64 rows; two workgroups share a CU (one wave each per SIMD)
 constexpr int kF32NT = 64 * kF32Waves;
 constexpr int kF32Rows = 64 * kF32Waves;           // outputs per workgroup
 constexpr int kF32BN = 64;                         // output channels per workgroup
-constexpr int kF32PatchMax = 12288;                // floats of one patch buffer: 48 KiB
+constexpr int kF32PatchMax = 12288;                // floats of the patch buffer: 48 KiB
 constexpr int kF32K2 = 11;                         // MFMAs per (kt, kh) tap
 constexpr int kF32BTile = kF32K2 * 2 * kF32BN;     // floats of one (tap, channel tile) filter block: 5.5 KiB
-constexpr int kF32BBuf = 1536;                     // LDS floats per filter buffer: whole 1-KiB DMA pieces (6 waves)
-constexpr int kF32PiecesPerWave = kF32PatchMax / 4 / 64 / kF32Waves;   // 6
+constexpr int kF32BBuf = 1536;                     // LDS floats per filter slot: whole 1-KiB DMA pieces
+constexpr int kF32Pieces = kF32PatchMax / 4 / kF32NT;   // 16-byte patch pieces per thread: 12
 
 __device__ __forceinline__ unsigned f32_fdiv(unsigned n, const unsigned (&dv)[2]) {
     return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
@@ -59,10 +59,12 @@ static inline void f32_fdiv_make(unsigned d, unsigned (&out)[2]) {
     out[1] = l - 1;
 }
 
-__global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args p) {
+// NP: 16-byte patch pieces per thread (4, 8 or 12: the register budget of the staged next patch)
+template <int NP>
+__global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32Args p) {     // 2 waves per SIMD: <= 256 registers
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [2][kF32PatchMax]
-    float* Bs = smem + 2 * kF32PatchMax;                // [3][kF32BBuf]
+    float* As = smem;                                   // [kF32PatchMax]: the patch of the current temporal tap
+    float* Bs = smem + kF32PatchMax;                    // [3][kF32BBuf]: filter tiles of steps s, s + 1, s + 2
     constexpr unsigned kOOB = 0x80000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -83,12 +85,12 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
-    // ---- per-lane DMA sources of the patch pieces this wave moves (frame independent) ----
-    unsigned a_src[kF32PiecesPerWave];
+    // ---- per-thread sources of the patch pieces (frame independent): piece q = tid + 256 i of the three planes ----
+    unsigned a_src[NP];
     const int pc4 = p.PC >> 2, plane4 = p.plane >> 2;
 #pragma unroll
-    for (int i = 0; i < kF32PiecesPerWave; ++i) {
-        const int q = (wave + kF32Waves * i) * 64 + lane;            // 16-byte piece of the patch
+    for (int i = 0; i < NP; ++i) {
+        const int q = tid + kF32NT * i;
         const int c = q / plane4;                                     // (once per thread: plain divisions)
         const int rem = q - c * plane4;
         const int pr = rem / pc4;
@@ -96,46 +98,56 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
         const bool ok = c < 3 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
         a_src[i] = ok ? (unsigned)((c * p.sc + h * p.Wi + w) * 4) : kOOB;
     }
-    const unsigned b_src = tid < kF32BTile / 4 ? (unsigned)((nt * kF32BTile + tid * 4) * 4) : kOOB;
+    unsigned b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + kF32NT * i;
+        b_src[i] = idx < kF32BTile / 4 ? (unsigned)((nt * kF32BTile + idx * 4) * 4) : kOOB;
+    }
 
     // ---- valid temporal taps (uniform): frames outside the clip contribute nothing ----
     const int t_first = to * p.sT - p.pT;
     const int kt_lo = max(0, -t_first), kt_hi = min(p.kT - 1, p.Ti - 1 - t_first);
     const int n_kt = kt_hi - kt_lo + 1;
 
-    auto issue_a_piece = [&](int buf, int i, int kt) {
-        if (wave + kF32Waves * i < p.n_pieces) {
-            const unsigned fbase = (unsigned)(n * p.sn + (t_first + kt) * p.st) * 4u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(As + buf * kF32PatchMax + (wave + kF32Waves * i) * 256), 16,
-                                                     a_src[i] == kOOB ? kOOB : a_src[i] + fbase, 0, 0, 0);
-        }
+    // the patch of the NEXT frame waits in registers (global -> VGPR while this frame computes, VGPR -> LDS at the frame
+    // change): one patch buffer instead of two keeps the workgroup at 66 KiB of LDS, so two of them share a CU and fill
+    // each other's barrier / frame-change / epilogue bubbles
+    f32x4 preg[NP];
+    auto fetch_patch = [&](int kt) {
+        const unsigned fbase = (unsigned)(n * p.sn + (t_first + kt) * p.st) * 4u;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            preg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_src[i] == kOOB ? kOOB : a_src[i] + fbase, 0, 0));
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + kF32NT * i < p.n_pieces) *reinterpret_cast<f32x4*>(As + (tid + kF32NT * i) * 4) = preg[i];
     };
     auto issue_b = [&](int buf, int kt, int kh) {
         const unsigned tbase = (unsigned)((kt * p.kH + kh) * p.w_tiles * kF32BTile * 4);
-        if (wave * 64 < kF32BTile / 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kF32BBuf + wave * 256), 16,
-                                                     b_src == kOOB ? kOOB : b_src + tbase, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (wave * 64 + kF32NT * i < kF32BTile / 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kF32BBuf + (wave * 64 + kF32NT * i) * 4), 16,
+                                                         b_src[i] == kOOB ? kOOB : b_src[i] + tbase, 0, 0, 0);
     };
 
     // ---- this lane's output rows: ml = m0 + wave * 64 + i * 32 + lane % 32 -> (ho, wo) ----
     const int g = lane >> 5, l32 = lane & 31;
-    int a_row[2];            // float offset of (patch row (ho - ho_a) * sH, column wo * sW + shift)
-    bool row_ok[2];
-    int m_out[2];
     const int frame_out = p.Ho * p.Wo;
+    int a_row[2];            // float offset of (patch row (ho - ho_a) * sH, column wo * sW + shift)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int ml = m0 + wave * 64 + i * 32 + l32;
-        row_ok[i] = ml < frame_out;
-        const int mm = row_ok[i] ? ml : m0;
+        const int mm = ml < frame_out ? ml : m0;
         const int ho = (int)f32_fdiv((unsigned)mm, p.dv_wo);
         const int wo = mm - ho * p.Wo;
         a_row[i] = ((ho - ho_a) * p.sH) * p.PC + wo * p.sW + p.shift;
-        m_out[i] = (n * p.To + to) * frame_out + mm;
     }
     // K pairing (see the header): five address flavours per row tile, fixed for the whole kernel -- a step only adds its
-    // (patch buffer, kh) offset, so the loop spends ~0.3 VALU instructions per MFMA on addresses (every VALU issue slot is
-    // taken from the MFMA pipe: scripts/micro/mfma_stem_probe.hip)
+    // kh offset, so the loop spends well under one VALU instruction per MFMA on addresses
     int a_base[2][5];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -155,9 +167,8 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- main loop: one step per (kt, kh) tap.  The fragment registers of k-pair group q are refilled for step s + 1 right
-    // after the MFMAs of group q of step s have issued, so no MFMA ever waits on LDS (before: all 8 waves bursting their
-    // ds_reads after the barrier).  Needs tile s + 1 landed at barrier(s): three filter slots, and the next frame's patch
-    // staged over kh = 0 .. kH-2.
+    // after the MFMAs of group q of step s have issued, so inside a frame no MFMA waits on LDS.  Needs filter tile s + 1
+    // landed at barrier(s): three filter slots.
     const int n_steps = n_kt * p.kH;
     float fa[2][kF32K2], fb[2][kF32K2];
     auto load_group = [&](int q, const float* Ab, const float* Bb) {
@@ -187,22 +198,21 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
         }
     };
     if (n_steps > 0) {
-        // prologue: the first patch, filter tiles 0 and 1; then the fragments of step 0
-#pragma unroll
-        for (int i = 0; i < kF32PiecesPerWave; ++i) issue_a_piece(0, i, kt_lo);
+        // prologue: the first patch (through registers), filter tiles 0 and 1; then the fragments of step 0
+        fetch_patch(kt_lo);
         issue_b(0, kt_lo, 0);
         if (n_steps > 1) issue_b(1, kt_lo, 1);           // (kH >= 2)
+        store_patch();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
 #pragma unroll
         for (int q = 0; q < 4; ++q) load_group(q, As, Bs + g * kF32BN + l32);
-        const int per = (kF32PiecesPerWave + p.kH - 2) / (p.kH - 1);     // patch pieces per step, kh = 0 .. kH-2
         int ik = 0, kh = 0, slot = 0;                     // state of step s: frame, row tap, filter slot
         for (int s = 0; s < n_steps; ++s) {
             if (s > 0) {
-                // tile s + 1 (issued during step s - 1) has landed for everyone; slot (s + 2) % 3 and, at a frame change,
-                // the other patch buffer are free: their last LDS reads were issued during step s - 2 / s - 1 and consumed
+                // filter tile s + 1 (issued during step s - 1) has landed for everyone; slot (s + 2) % 3 is free: its last
+                // reads were issued during step s - 2 and consumed during step s - 1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
@@ -213,30 +223,37 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
             const int slot1 = slot == 2 ? 0 : slot + 1;
             const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
             if (s + 2 < n_steps) issue_b(slot2, kt_lo + ik2, kh2);
-            if (ik + 1 < n_kt && kh < p.kH - 1) {
-                // the next frame's patch, spread over kh = 0 .. kH-2 (complete at the barrier of this frame's last step)
-                const int lo = kh * per, hi = lo + per;
-#pragma unroll
-                for (int i = 0; i < kF32PiecesPerWave; ++i)
-                    if (i >= lo && i < hi) issue_a_piece((ik & 1) ^ 1, i, kt_lo + ik + 1);
-            }
+            if (kh == 0 && ik + 1 < n_kt) fetch_patch(kt_lo + ik + 1);      // lands in registers during this frame
             const bool more = s + 1 < n_steps;
-            const float* Ab = As + (ik1 & 1) * kF32PatchMax + kh1 * p.PC;
+            const bool same_frame = kh1 != 0;
             const float* Bb = Bs + slot1 * kF32BBuf + g * kF32BN + l32;
+            const bool prefetch = more && same_frame;
+            const float* Ab = As + kh1 * p.PC;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 mma_group(q);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) load_group(q, Ab, Bb);
+                if (prefetch) load_group(q, Ab, Bb);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more && !same_frame) {
+                // frame change: every wave is done with the old patch; the staged one moves VGPR -> LDS
+                __syncthreads();
+                store_patch();
+                __syncthreads();
+                asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) load_group(q, As, Bb);
             }
             kh = kh1; ik = ik1; slot = slot1;
         }
     }
 
-    // ---- epilogue: bias (+ folded BN) + ReLU; lane = output channel, 16 rows per accumulator tile ----
+    // ---- epilogue: bias (+ folded BN) + ReLU; lane = output channel, 16 rows per accumulator tile.  Outputs of a tile are
+    // consecutive in (n, to, ho, wo) raster order, so the row index is arithmetic ----
     const bool relu = (p.flags & PTX_EPI_RELU) != 0;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const int m_frame = (n * p.To + to) * frame_out;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = nt * kF32BN + j * 32 + l32;
@@ -246,15 +263,12 @@ __global__ void __launch_bounds__(kF32NT) conv_stem_f32_kernel(const StemF32Args
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // accumulator element r of this lane belongs to tile row (r & 3) + 8 * (r >> 2) + 4 * g: fetch that
-                // row's output index / validity from the lane that owns it as an A row
-                const int trow = (r & 3) + 8 * (r >> 2) + 4 * g;
-                const int m = __shfl(m_out[i], trow, 64);
-                const int ok = __shfl((int)row_ok[i], trow, 64);
+                // accumulator element r of this lane belongs to tile row (r & 3) + 8 * (r >> 2) + 4 * g
+                const int ml = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 float v = acc[i][j][r] + bv;
                 v = relu ? fmaxf(v, 0.f) : v;
-                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ok) ? off : kOOB, 0, 0);
+                const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldy + (unsigned)co) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ml < frame_out) ? off : kOOB, 0, 0);
             }
         }
     }
@@ -362,22 +376,29 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     a.PR = g.PR; a.PC = g.PC; a.plane = g.PR * g.PC; a.shift = g.shift; a.wbase = g.wbase;
     a.tiles_per_frame = g.tiles_per_frame;
     a.n_tiles = d->N * d->To * g.tiles_per_frame;
-    a.n_pieces = cdiv(3 * a.plane / 4, 64);
+    a.n_pieces = 3 * a.plane / 4;                           // 16-byte pieces of the patch (PC % 4 == 0)
     a.w_tiles = d->Co_pad / kF32BN;
     a.flags = d->flags;
     a.x_bytes = (unsigned)(((uint64_t)(d->N - 1) * stride_n + 3ull * stride_c) * 4ull);
     a.w_bytes = (unsigned)(ptx_stem_f32_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
     f32_fdiv_make((unsigned)d->Wo, a.dv_wo);
-    constexpr size_t lds = (size_t)(2 * kF32PatchMax + 3 * kF32BBuf) * sizeof(float);
-    static bool attr_set[64] = {};
+    constexpr size_t lds = (size_t)(kF32PatchMax + 3 * kF32BBuf) * sizeof(float);
+    const int np = cdiv(a.n_pieces, kF32NT);                // pieces per thread: 4 / 8 / 12 registers x 4
+    const void* fn = np <= 4 ? reinterpret_cast<const void*>(conv_stem_f32_kernel<4>)
+                   : np <= 8 ? reinterpret_cast<const void*>(conv_stem_f32_kernel<8>)
+                             : reinterpret_cast<const void*>(conv_stem_f32_kernel<12>);
+    const int vi = np <= 4 ? 0 : np <= 8 ? 1 : 2;
+    static bool attr_set[64][3] = {};
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    if (dev < 0 || dev >= 64 || !attr_set[dev][vi]) {
+        PTX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev][vi] = true;
     }
     const dim3 grid((unsigned)a.n_tiles, (unsigned)cdiv(a.ncol, kF32BN));
-    hipLaunchKernelGGL(conv_stem_f32_kernel, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    if (np <= 4) hipLaunchKernelGGL(conv_stem_f32_kernel<4>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    else if (np <= 8) hipLaunchKernelGGL(conv_stem_f32_kernel<8>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_stem_f32_kernel<12>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "conv_stem_f32 launch");
 }
