@@ -45,7 +45,6 @@ constexpr int kF32BN = 64;                         // output channels per workgr
 constexpr int kF32PatchMax = 12288;                // floats of the patch buffer: 48 KiB
 constexpr int kF32K2 = 11;                         // MFMAs per (kt, kh) tap
 constexpr int kF32BTile = kF32K2 * 2 * kF32BN;     // floats of one (tap, channel tile) filter block: 5.5 KiB
-constexpr int kF32BBuf = 1536;                     // LDS floats per filter slot: whole 1-KiB DMA pieces
 constexpr int kF32Pieces = kF32PatchMax / 4 / kF32NT;   // 16-byte patch pieces per thread: 12
 
 __device__ __forceinline__ unsigned f32_fdiv(unsigned n, const unsigned (&dv)[2]) {
@@ -59,12 +58,24 @@ static inline void f32_fdiv_make(unsigned d, unsigned (&out)[2]) {
     out[1] = l - 1;
 }
 
-// NP: 16-byte patch pieces per thread (4, 8 or 12: the register budget of the staged next patch)
-template <int NP>
-__global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32Args p) {     // 2 waves per SIMD: <= 256 registers
+// the whole patch of temporal tap KT, global -> LDS: piece q = tid + 256 i lands at As + 16 q; lanes past the patch stay
+// out of the DMA (nothing is written for them), pieces outside the image read as zero
+#define PTX_STEM_DMA_PATCH(KT)                                                                                         \
+    do {                                                                                                               \
+        const unsigned fbase_ = (unsigned)(n * p.sn + (t_first + (KT)) * p.st) * 4u;                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_)                                                              \
+            if (tid + kF32NT * i_ < p.n_pieces)                                                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(As + (wave * 64 + kF32NT * i_) * 4), 16,   \
+                                                         a_src[i_] == kOOB ? kOOB : a_src[i_] + fbase_, 0, 0, 0);      \
+    } while (0)
+
+// NP: 16-byte patch pieces per thread (4, 8 or 12).  STAGE: the next frame's patch waits in registers (2 workgroups per CU);
+// else it is LDS-DMA'd at the frame change, exposed, and a third workgroup per CU covers the wait (<= 168 registers).
+template <int NP, bool STAGE>
+__global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [kF32PatchMax]: the patch of the current temporal tap
-    float* Bs = smem + kF32PatchMax;                    // [3][kF32BBuf]: filter tiles of steps s, s + 1, s + 2
+    float* As = smem;                                   // [3 * plane]: the patch of the current temporal tap
+    float* Bs = smem + 3 * p.plane;                     // [3][kF32BTile]: filter tiles of steps s, s + 1, s + 2
     constexpr unsigned kOOB = 0x80000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread sources of the patch pieces (frame independent): piece q = tid + 256 i of the three planes ----
-    unsigned a_src[NP];
+    unsigned a_src[12];       // (sized 12, used to NP: a template-dependent extent here makes hipcc's host pass drop the kernel stub)
     const int pc4 = p.PC >> 2, plane4 = p.plane >> 2;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -100,10 +111,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     }
     unsigned b_src[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + kF32NT * i;
-        b_src[i] = idx < kF32BTile / 4 ? (unsigned)((nt * kF32BTile + idx * 4) * 4) : kOOB;
-    }
+    for (int i = 0; i < 2; ++i) b_src[i] = (unsigned)((nt * kF32BTile + (tid + kF32NT * i) * 4) * 4);
 
     // ---- valid temporal taps (uniform): frames outside the clip contribute nothing ----
     const int t_first = to * p.sT - p.pT;
@@ -129,9 +137,9 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
         const unsigned tbase = (unsigned)((kt * p.kH + kh) * p.w_tiles * kF32BTile * 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (wave * 64 + kF32NT * i < kF32BTile / 4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kF32BBuf + (wave * 64 + kF32NT * i) * 4), 16,
-                                                         b_src[i] == kOOB ? kOOB : b_src[i] + tbase, 0, 0, 0);
+            if (tid + kF32NT * i < kF32BTile / 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kF32BTile + (wave * 64 + kF32NT * i) * 4), 16,
+                                                         b_src[i] + tbase, 0, 0, 0);
     };
 
     // ---- this lane's output rows: ml = m0 + wave * 64 + i * 32 + lane % 32 -> (ho, wo) ----
@@ -199,10 +207,11 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     };
     if (n_steps > 0) {
         // prologue: the first patch (through registers), filter tiles 0 and 1; then the fragments of step 0
-        fetch_patch(kt_lo);
+        if (STAGE) fetch_patch(kt_lo);
+        else PTX_STEM_DMA_PATCH(kt_lo);
         issue_b(0, kt_lo, 0);
         if (n_steps > 1) issue_b(1, kt_lo, 1);           // (kH >= 2)
-        store_patch();
+        if (STAGE) store_patch();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
@@ -223,10 +232,10 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
             const int slot1 = slot == 2 ? 0 : slot + 1;
             const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
             if (s + 2 < n_steps) issue_b(slot2, kt_lo + ik2, kh2);
-            if (kh == 0 && ik + 1 < n_kt) fetch_patch(kt_lo + ik + 1);      // lands in registers during this frame
+            if (STAGE && kh == 0 && ik + 1 < n_kt) fetch_patch(kt_lo + ik + 1);      // lands in registers during this frame
             const bool more = s + 1 < n_steps;
             const bool same_frame = kh1 != 0;
-            const float* Bb = Bs + slot1 * kF32BBuf + g * kF32BN + l32;
+            const float* Bb = Bs + slot1 * kF32BTile + g * kF32BN + l32;
             const bool prefetch = more && same_frame;
             const float* Ab = As + kh1 * p.PC;
 #pragma unroll
@@ -239,7 +248,11 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
             if (more && !same_frame) {
                 // frame change: every wave is done with the old patch; the staged one moves VGPR -> LDS
                 __syncthreads();
-                store_patch();
+                if (STAGE) store_patch();
+                else {
+                    PTX_STEM_DMA_PATCH(kt_lo + ik1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __syncthreads();
                 asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
 #pragma unroll
@@ -272,6 +285,21 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
             }
         }
     }
+}
+
+
+template <int NP, bool STAGE>
+static int launch_stem_f32(const StemF32Args& a, dim3 grid, size_t lds, ptx_stream_t stream) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_f32_kernel<NP, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((kF32PatchMax + 3 * kF32BTile) * sizeof(float))));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_f32_kernel<NP, STAGE>), grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    return PTX_OK;
 }
 
 // folded K-major filter [tap][Co_pad][Kc] (k = kw * 3 + c, ptx_pack_conv_weight with fold_kw = 1) -> the stem's
@@ -383,22 +411,18 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     a.w_bytes = (unsigned)(ptx_stem_f32_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
     f32_fdiv_make((unsigned)d->Wo, a.dv_wo);
-    constexpr size_t lds = (size_t)(kF32PatchMax + 3 * kF32BBuf) * sizeof(float);
-    const int np = cdiv(a.n_pieces, kF32NT);                // pieces per thread: 4 / 8 / 12 registers x 4
-    const void* fn = np <= 4 ? reinterpret_cast<const void*>(conv_stem_f32_kernel<4>)
-                   : np <= 8 ? reinterpret_cast<const void*>(conv_stem_f32_kernel<8>)
-                             : reinterpret_cast<const void*>(conv_stem_f32_kernel<12>);
-    const int vi = np <= 4 ? 0 : np <= 8 ? 1 : 2;
-    static bool attr_set[64][3] = {};
-    int dev = 0;
-    PTX_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev][vi]) {
-        PTX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) attr_set[dev][vi] = true;
-    }
+    const size_t lds = (size_t)(3 * a.plane + 3 * kF32BTile) * sizeof(float);
+    const int np = cdiv(a.n_pieces, kF32NT);                // pieces per thread: 4 / 8 / 12
+    // default: the patch is LDS-DMA'd at the frame change and three workgroups per CU cover each other's waits (config 2:
+    // 1.54 ms); PTX_STEM_F32_MODE=2 stages the next patch through registers instead (two workgroups per CU: 1.62 ms)
+    static const int mode_env = getenv("PTX_STEM_F32_MODE") ? atoi(getenv("PTX_STEM_F32_MODE")) : 1;
+    const bool stage = mode_env == 2;
     const dim3 grid((unsigned)a.n_tiles, (unsigned)cdiv(a.ncol, kF32BN));
-    if (np <= 4) hipLaunchKernelGGL(conv_stem_f32_kernel<4>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
-    else if (np <= 8) hipLaunchKernelGGL(conv_stem_f32_kernel<8>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_stem_f32_kernel<12>, grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    int rc;
+    if (stage) rc = np <= 4 ? launch_stem_f32<4, true>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, true>(a, grid, lds, stream)
+                                                                                      : launch_stem_f32<12, true>(a, grid, lds, stream);
+    else rc = np <= 4 ? launch_stem_f32<4, false>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, false>(a, grid, lds, stream)
+                                                                                  : launch_stem_f32<12, false>(a, grid, lds, stream);
+    if (rc != PTX_OK) return rc;
     return hip_check(hipGetLastError(), "conv_stem_f32 launch");
 }
