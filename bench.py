@@ -257,8 +257,15 @@ def main():
             import re
             tpath = os.path.join("profiles", TRAFFIC_FILE)
             tj = json.load(open(os.path.join(ROOT, tpath)))
-            if dom_name.startswith("conv_stem"):
-                raise KeyError(dom_name)                        # no PMC row of the direct stem kernels yet
+            if dom_name.startswith("conv_stem"):                # the direct stem kernels: one row per kernel name
+                for k, v in tj.items():
+                    if k.startswith(dom_name + "_kernel") and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
+                        traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+                        traffic_source = {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0,
+                                          "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0, "fetch_correction": "none applied "
+                                          "(guide: up to 2x under-report on streaming reads)", "measured_in_this_run": False}
+                        break
+                raise KeyError(dom_name)                        # (leaves the tile-name lookup below)
             tile, waves, mt = dom_name.split("/")[:3]
             stage = dom_name.split("/")[3] if dom_name.count("/") >= 3 else ""
             want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
@@ -277,6 +284,8 @@ def main():
                                       "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0, "fetch_correction": "none applied "
                                       "(guide: up to 2x under-report on streaming reads)", "measured_in_this_run": False}
                     break
+        except KeyError:
+            pass
         except Exception:
             traffic, traffic_source = None, None
         roofline = {

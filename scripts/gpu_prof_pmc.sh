@@ -13,9 +13,12 @@ CMD="python $REPO/bench.py --workload $W --steps ${STEPS:-5} --warmup 2 --no-cpu
 NOTUNE="--no-autotune"
 if [ -n "$PROF_CMD" ]; then CMD="$PROF_CMD"; NOTUNE=""; fi      # any other command (a kernel probe script): W / TAG only name the output
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1; echo "trace exit $?"
+i=0
 for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi      # PASSES="1 3 4": only those counter groups
   tag=$(echo $pmc | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $pmc --kernel-trace -d $OUT/pmc_$tag -o bench -- $CMD $NOTUNE > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag exit $?"
 done
