@@ -173,12 +173,12 @@ int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* desc, const float* x, const floa
 
 /* RGB STEM convolution on the fp32 matrix cores, read straight from the caller's NCDHW tensor -- `conv1` + `bn1` + ReLU of
  * the ResNet3D family (resnet3D.py:153-155 / :204-206), the 2-D ResNet stem (torchvision_models.py), the (1,7,7) spatial
- * stem of R2Plus1D (r2plus1d.py:73-88), the SAME-padded I3D stem.  No fold / layout pass: a workgroup owns 512 consecutive
+ * stem of R2Plus1D (r2plus1d.py:73-88), the SAME-padded I3D stem.  No fold / layout pass: a workgroup owns 256 consecutive
  * outputs of one output frame, LDS-DMAs the three channel planes of the input patch of a temporal tap once (16-byte
  * pieces of the NCDHW rows, zero outside the image) and serves all kH x 7 taps from it; K = 21 runs as 11
  * v_mfma_f32_32x32x2_f32 per tap.  fp32 operands, fp32 accumulate.
- * desc: Ci = 3, kW = 7, stride_w <= 2, symmetric or SAME padding (front pad in pT/pH/pW), flags within PTX_EPI_RELU, Wi % 4
- * == 0; ldx / Kc are ignored.  x: [N][3][T][H][W] fp32 with element strides (stride_n, stride_c, stride_t) -- multiples of
+ * desc: Ci = 3, kW = 7, 2 <= kH <= 8, stride_w <= 2, symmetric or SAME padding (front pad in pT/pH/pW), flags within
+ * PTX_EPI_RELU, Wi % 4 == 0, a patch of at most 12288 floats; ldx / Kc are ignored.  x: [N][3][T][H][W] fp32 with element strides (stride_n, stride_c, stride_t) -- multiples of
  * 4, so `input[:, :, ::step]` (torchvision_models.py frame sub-sampling) is a stride, not a copy -- rows contiguous.
  * w_stem: ptx_pack_stem_f32_weight of the folded K-major filter ([kT*kH][Co_pad][Kc], k = kw*3 + c: ptx_pack_conv_weight
  * with fold_kw = 1, which also folds the BatchNorm), ptx_stem_f32_weight_elems floats.  bias: [Co_pad] from the same pack.

@@ -4,10 +4,13 @@
 //
 // Why a dedicated kernel.  On the generic implicit-GEMM tiles the stem is a (7,7,1) conv over a kW-FOLDED copy of the
 // input (ptx_fold_kw_ncdhw: 77 MB -> 308 MB at config 2), and every (kt, kh) tap re-stages its A tile global -> VGPR ->
-// LDS behind a barrier: the fp32 MFMA pipe sits at 75 %, plus the 82 us fold pass.  Here a workgroup owns
-// 512 consecutive outputs of one output frame, stages the INPUT PATCH of a temporal tap once with LDS-DMA -- three
-// channel planes of PR rows x PC floats, exactly the caller's NCDHW rows (16-byte pieces, zero outside the image) --
-// and serves all kH x 7 taps of that frame from it.  No fold, no layout pass: the kernel reads the user tensor.
+// LDS behind a barrier: the fp32 MFMA pipe sits at 75 %, plus the 82 us fold pass.  Here a workgroup (4
+// waves) owns 256 consecutive outputs of one output frame, stages the INPUT PATCH of a temporal tap once with LDS-DMA --
+// three channel planes of PR rows x PC floats, exactly the caller's NCDHW rows (16-byte pieces, zero outside the image) --
+// and serves all kH x 7 taps of that frame from it.  No fold, no layout pass: the kernel reads the user tensor.  LDS per
+// workgroup = the patch + three 5.5 KiB filter slots (53 KB at config 2), 147 VGPRs: THREE workgroups share a CU and cover
+// each other's frame-change DMA wait, barriers, prologue and epilogue -- what took the kernel from 1.76 to 1.55 ms
+// (one 8-wave workgroup per CU could not be scheduled out of its bubbles).
 //
 // K axis of one (kt, kh) tap: 21 = 3 channels x 7 kw, issued as 11 v_mfma_f32_32x32x2_f32 (k = 2 per instruction; lanes
 // 0-31 hold k0, lanes 32-63 hold k1 =: g).  Pairing keeps the g-dependence of the A address a constant:
@@ -38,14 +41,13 @@ struct StemF32Args {
     unsigned dv_wo[2];
 };
 
-constexpr int kF32Waves = 4;                       // 4 waves x 64 rows; two workgroups share a CU (one wave each per SIMD)
+constexpr int kF32Waves = 4;                       // 4 waves x 64 rows; up to three workgroups share a CU
 constexpr int kF32NT = 64 * kF32Waves;
 constexpr int kF32Rows = 64 * kF32Waves;           // outputs per workgroup
 constexpr int kF32BN = 64;                         // output channels per workgroup
 constexpr int kF32PatchMax = 12288;                // floats of the patch buffer: 48 KiB
 constexpr int kF32K2 = 11;                         // MFMAs per (kt, kh) tap
 constexpr int kF32BTile = kF32K2 * 2 * kF32BN;     // floats of one (tap, channel tile) filter block: 5.5 KiB
-constexpr int kF32Pieces = kF32PatchMax / 4 / kF32NT;   // 16-byte patch pieces per thread: 12
 
 __device__ __forceinline__ unsigned f32_fdiv(unsigned n, const unsigned (&dv)[2]) {
     return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
@@ -351,7 +353,9 @@ extern "C" int ptx_conv_stem_f32_supported(const ptx_conv3d_desc* d, int64_t str
     if (d->Ci != 3 || d->kW != 7 || d->kT < 1 || d->kT > 8 || d->kH < 2 || d->kH > 8 || d->groups > 1 || d->Co_pad % kF32BN) return 0;
     if (d->sW < 1 || d->sW > 2 || d->sH < 1 || d->sT < 1 || d->Wo < 1 || d->Ho < 1 || d->To < 1 || d->pW < 0 || d->pW > 8) return 0;
     if (d->Wi % 4 || stride_n % 4 || stride_c % 4 || stride_t % 4) return 0;          // 16-byte DMA pieces of NCDHW rows
-    if (stride_t < (int64_t)d->Hi * d->Wi || stride_c < stride_t || stride_n < stride_c) return 0;
+    // a plane inside its channel, a channel inside its sample: the buffer descriptor's range is derived from these
+    const int64_t chan_extent = (int64_t)(d->Ti - 1) * stride_t + (int64_t)d->Hi * d->Wi;
+    if (stride_t < (int64_t)d->Hi * d->Wi || stride_c < chan_extent || stride_n < 2 * stride_c + chan_extent) return 0;
     StemF32Geom g;
     if (!stem_f32_geom(d, &g)) return 0;
     if (((int64_t)(d->N - 1) * stride_n + 3 * stride_c) * 4 >= 0x80000000LL ||

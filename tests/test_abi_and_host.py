@@ -513,3 +513,52 @@ def test_biggan_release_layout_and_config_validation(ptx):
     for bad in (dict(ch=12, resolution=128), dict(shared_dim=130), dict(depth=3), dict(dim_z=6)):
         with pytest.raises(ValueError):
             ptx.biggan_deep(bad.pop("resolution", 256), **bad)
+
+
+def test_fp32_stem_plan_wiring_without_gpu(ptx, monkeypatch):
+    """Plan.stem_direct_f32 (dry plans): RGB stems with more than 32 output channels run ptx_conv_stem_f32_fwd on the caller's
+    NCDHW tensor; what the kernel refuses keeps the kW-folded implicit-GEMM stem -- a width that is not a multiple of 4,
+    narrow outputs, uint8 frames, PTX_STEM_DIRECT=0 -- and the C ABI's own gate agrees."""
+    from pretorched_x_amd import engine
+    L, lib = ptx._lib, ptx._lib.lib()
+
+    def stem_kinds(plan):
+        return [type(s).__name__ for s in plan.steps if isinstance(s, (engine.StemF32Step, engine.StemStep))], \
+               [getattr(s, "label", "") for s in plan.steps if getattr(s, "label", "") == "fold_kw"]
+
+    m = ptx.resnet3d18(num_classes=10, pretrained=None)
+    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 64)))
+    assert direct == ["StemF32Step"] and not folds
+    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 66)))          # W % 4 != 0: rows are not 16-byte pieces
+    assert not direct and folds == ["fold_kw"]
+    monkeypatch.setenv("PTX_STEM_DIRECT", "0")
+    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 64)))
+    assert not direct and folds == ["fold_kw"]
+    monkeypatch.delenv("PTX_STEM_DIRECT")
+    # the (2+1)D spatial stem (45 mid channels) and the 2-D ResNet stem go direct; the step carries the NCDHW strides
+    r = ptx.r2plus1d18(num_classes=10)
+    plan = r.engine().dry_plan(r, (1, 3, 8, 64, 64))
+    st = [s for s in plan.steps if isinstance(s, engine.StemF32Step)]
+    assert len(st) == 1 and st[0].label.endswith(".spatial") and (st[0].d.kT, st[0].d.kH, st[0].d.kW) == (1, 7, 7)
+    assert st[0].strides == (3 * 8 * 64 * 64, 8 * 64 * 64, 64 * 64) and st[0].d.Co == r.conv1.spatial_conv.out_channels
+    r2 = ptx.resnet18(num_classes=10, pretrained=None)
+    st = [s for s in r2.engine().dry_plan(r2, (2, 3, 64, 64)).steps if isinstance(s, engine.StemF32Step)]
+    assert len(st) == 1 and (st[0].d.Ti, st[0].d.kT) == (1, 1)
+    # the ABI gate: geometry / flags / strides
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci = 2, 8, 64, 64, 3
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 8, 32, 32, 64, 64
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 7, 7, 7, 1, 2, 2, 3, 3, 3
+    d.Co_pad, d.flags = 128, L.PTX_EPI_RELU
+    sn, sc, st_ = 3 * 8 * 4096, 8 * 4096, 4096
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 1
+    assert lib.ptx_stem_f32_weight_elems(C.byref(d)) == 49 * 2 * 11 * 2 * 64
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_ + 2) == 0        # frame stride not a multiple of 4 floats
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc // 2, st_) == 0       # overlapping channel planes
+    d.flags = L.PTX_EPI_RELU | L.PTX_EPI_RES_ADD
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 0
+    d.flags, d.kH = L.PTX_EPI_RELU, 1
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 0            # (kH >= 2: the patch is staged over kh steps)
+    d.kH, d.Wo, d.Wi = 7, 512, 1024                                                 # a 256-output span of rows no longer fits
+    d.Hi, d.Ho = 64, 32
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), 3 * 8 * 65536, 8 * 65536, 65536) == 0
