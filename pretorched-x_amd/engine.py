@@ -1050,6 +1050,13 @@ def _foldable(conv, x):
     return isinstance(x, RawInput)
 
 
+def _dense16(x):
+    """Contiguous and 16-byte aligned: the kernels read the caller's tensor in 16-byte pieces (a contiguous view whose storage
+    offset is not a multiple of 4 floats gets one aligned copy)."""
+    x = x.contiguous()
+    return x.clone() if x.data_ptr() % 16 else x
+
+
 def _is_replica(model):
     return bool(getattr(model, "_is_replica", False))
 
@@ -1241,7 +1248,7 @@ class Engine:
         big = self._chunked(self.features, model, x)
         if big is not None:
             return big
-        x = x.contiguous()
+        x = _dense16(x)
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
@@ -1352,7 +1359,7 @@ class Engine:
         big = self._chunked(self.forward, model, x)
         if big is not None:
             return big
-        x = x.contiguous()
+        x = _dense16(x)
         with torch.cuda.device(x.device):
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
@@ -1446,7 +1453,7 @@ class Engine:
         if plan is None:
             self._validate(model, x, model.arch.dims)
             with torch.cuda.device(x.device):
-                plan = self.plan_for(model, x.contiguous())
+                plan = self.plan_for(model, _dense16(x))
         with torch.cuda.device(x.device), plan.exclusive():
             return self._autotune(model, x, iters, verbose, persist, only_untuned, plan)
 
@@ -1454,9 +1461,9 @@ class Engine:
         lib = _lib.lib()
         with torch.cuda.device(x.device):
             if plan is None:
-                plan = self.plan_for(model, x.contiguous())
+                plan = self.plan_for(model, _dense16(x))
             plan.bind(model)
-            plan.run_features(x.contiguous())      # make every buffer hold sane data
+            plan.run_features(_dense16(x))      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
             seen = {}
             log = open(os.environ["PTX_TUNE_LOG"], "w") if os.environ.get("PTX_TUNE_LOG") else None
@@ -1532,7 +1539,7 @@ class Engine:
                         stp.label, M, stp.d.Co, stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW,
                         lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
                         2e-9 * stp.macs / best[0]))
-            plan.run_features(x.contiguous())
+            plan.run_features(_dense16(x))
             plan.tuned = True
             if log is not None:
                 log.close()
@@ -1547,9 +1554,9 @@ class Engine:
         with torch.cuda.device(x.device):
             if plan is None:
                 self._validate(model, x, model.arch.dims)
-                plan = self.plan_for(model, x.contiguous())
+                plan = self.plan_for(model, _dense16(x))
                 plan.bind(model)
-                plan.run_features(x.contiguous())
+                plan.run_features(_dense16(x))
             for stp in plan.conv_steps:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 stp(_stream())

@@ -172,6 +172,15 @@ def test_input_validation_on_device(ptx):
     y1 = model(x)
     y2 = model(x.transpose(3, 4).contiguous().transpose(3, 4))
     assert torch.equal(y1, y2)
+    # a contiguous view at a storage offset that is not 16-byte aligned (the direct stem DMAs 16-byte pieces of the
+    # caller's tensor): one aligned copy, same result; a frame-strided view is just strides
+    flat = torch.zeros(x.numel() + 1, device=DEV)
+    flat[1:] = x.reshape(-1)
+    xv = flat[1:].view_as(x)
+    assert xv.data_ptr() % 16 != 0 and xv.is_contiguous()
+    assert torch.equal(model(xv), y1) and torch.equal(model.features(xv), model.features(x))
+    wide = synth_clips(1, 12, 40, 3).to(DEV)
+    assert torch.equal(model(wide[:, :, ::2]), model(wide[:, :, ::2].contiguous()))
 
 
 def test_oversized_batches_are_split(ptx):
