@@ -39,6 +39,11 @@ struct StemF32Args {
     unsigned flags;
     unsigned x_bytes, w_bytes, y_bytes;
     unsigned dv_wo[2];
+    // longest-first tile order inside an XCD's chunk (0 = plain order): output frames grouped by their number of valid
+    // temporal taps, most taps first -- the workgroups that finish a launch are the short ones
+    int lpt, n_classes, groups_per_xcd;
+    unsigned char cls_start[10];      // first entry of class k in `order` (n_classes + 1 entries)
+    unsigned char order[64];          // output frames sorted by (taps desc, frame asc)
 };
 
 constexpr int kF32Waves = 4;                       // 4 waves x 64 rows; up to three workgroups share a CU
@@ -85,10 +90,22 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile order: the frames of one band of rows follow each other (temporal L2 reuse of the kT-frame window), an XCD
     // owns a contiguous chunk of the list
-    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int nt = blockIdx.y;
-    const int to = tile % p.To;
-    int t_ = tile / p.To;
+    int to, t_;                                         // output frame, (n, band) group
+    if (p.lpt) {
+        const int xcd = blockIdx.x % kNumXCD, l = blockIdx.x / kNumXCD;      // workgroup b runs on XCD b % 8
+        int k = 0;
+        while (k + 1 < p.n_classes && l >= (int)p.cls_start[k + 1] * p.groups_per_xcd) ++k;
+        const int first = p.cls_start[k], cnt = p.cls_start[k + 1] - first;
+        const int idx = l - first * p.groups_per_xcd;
+        const int grp = idx / cnt;
+        to = p.order[first + (idx - grp * cnt)];
+        t_ = xcd * p.groups_per_xcd + grp;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+        to = tile % p.To;
+        t_ = tile / p.To;
+    }
     const int band = t_ % p.tiles_per_frame;
     const int n = t_ / p.tiles_per_frame;
     const int m0 = band * kF32Rows;                     // first output (raster index inside the frame)
@@ -415,6 +432,33 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     a.w_bytes = (unsigned)(ptx_stem_f32_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
     f32_fdiv_make((unsigned)d->Wo, a.dv_wo);
+    {
+        const int groups = d->N * g.tiles_per_frame;
+        static const bool lpt_env = !(getenv("PTX_STEM_F32_LPT") && atoi(getenv("PTX_STEM_F32_LPT")) == 0);
+        if (lpt_env && d->To <= 64 && d->To > 1 && groups % kNumXCD == 0) {
+            int taps[64], idx[64];
+            for (int to = 0; to < d->To; ++to) {
+                const int t0 = to * d->sT - d->pT;
+                taps[to] = std::max(0, std::min(d->kT - 1, d->Ti - 1 - t0) - std::max(0, -t0) + 1);
+                idx[to] = to;
+            }
+            std::stable_sort(idx, idx + d->To, [&](int x, int y) { return taps[x] > taps[y]; });
+            int nc = 0;
+            for (int i = 0; i < d->To; ++i) {
+                a.order[i] = (unsigned char)idx[i];
+                if (i == 0 || taps[idx[i]] != taps[idx[i - 1]]) {
+                    if (nc < 9) a.cls_start[nc++] = (unsigned char)i;
+                    else { nc = 99; break; }
+                }
+            }
+            if (nc > 1 && nc <= 9) {          // (one class: nothing to reorder)
+                a.cls_start[nc] = (unsigned char)d->To;
+                a.n_classes = nc;
+                a.groups_per_xcd = groups / kNumXCD;
+                a.lpt = 1;
+            }
+        }
+    }
     const size_t lds = (size_t)(3 * a.plane + 3 * kF32BTile) * sizeof(float);
     const int np = cdiv(a.n_pieces, kF32NT);                // pieces per thread: 4 / 8 / 12
     // default: the patch is LDS-DMA'd at the frame change and three workgroups per CU cover each other's waits (config 2:

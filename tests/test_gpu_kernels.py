@@ -1324,6 +1324,8 @@ def test_conv_stem_f32_direct(ptx):
         (1, 3, 224, 224, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), 1),
         (2, 6, 21, 24, 64, (7, 7, 7), (2, 2, 2), "same", 1),
         (2, 4, 26, 36, 64, (3, 7, 7), (1, 1, 1), (1, 3, 3), 2),             # stride-1 windows, every other frame of 8
+        (8, 5, 30, 28, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3), 1),             # 8 (n, band) groups: longest-first tile order per XCD
+        (4, 6, 40, 40, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), 1),             # two 256-output bands per frame, 3 tap classes
     ]
     for (N, T, H, W, Co, k, s_, p_, step) in cases:
         full = rnd(N, 3, T * step, H, W, seed=180)
