@@ -252,50 +252,57 @@ def main():
         # separate --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; KiB per dispatch, UNCORRECTED
         # (MI355X_MICROARCH.md: FETCH_SIZE may under-report wide streaming reads by up to 2x on gfx950, so the true
         # figure lies in [traffic, traffic + fetch]); null when that file has no row for the dominant tile.
-        traffic, traffic_source = None, None
-        try:
-            import re
-            tpath = os.path.join("profiles", TRAFFIC_FILE)
-            tj = json.load(open(os.path.join(ROOT, tpath)))
-            if dom_name.startswith("conv_stem"):                # the direct stem kernels: one row per kernel name
+        def traffic_for(name):
+            """(bytes, source) of one kernel from the committed PMC table, or (None, None)."""
+            try:
+                import re
+                tpath = os.path.join("profiles", TRAFFIC_FILE)
+                tj = json.load(open(os.path.join(ROOT, tpath)))
+
+                def hit(v):
+                    return ((v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0,
+                            {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0, "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0,
+                             "fetch_correction": "none applied (guide: up to 2x under-report on streaming reads)",
+                             "measured_in_this_run": False})
+                if name.startswith("conv_stem"):                # the direct stem kernels: one row per kernel name
+                    for k, v in tj.items():
+                        if k.startswith(name + "_kernel") and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
+                            return hit(v)
+                    return None, None
+                tile, waves, mt = name.split("/")[:3]
+                stage = name.split("/")[3] if name.count("/") >= 3 else ""
+                want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
+                want_dma = stage.startswith("dma")
+                want_nstage = int(stage[3:]) if len(stage) > 3 else 2
                 for k, v in tj.items():
-                    if k.startswith(dom_name + "_kernel") and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
-                        traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
-                        traffic_source = {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0,
-                                          "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0, "fetch_correction": "none applied "
-                                          "(guide: up to 2x under-report on streaming reads)", "measured_in_this_run": False}
-                        break
-                raise KeyError(dom_name)                        # (leaves the tile-name lookup below)
-            tile, waves, mt = dom_name.split("/")[:3]
-            stage = dom_name.split("/")[3] if dom_name.count("/") >= 3 else ""
-            want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
-            want_dma = stage.startswith("dma")
-            want_nstage = int(stage[3:]) if len(stage) > 3 else 2
-            for k, v in tj.items():
-                m = re.match(r"conv_igemm<([^>(]*)", k)         # names are cut at 60 characters by summarize_prof.py
-                if not m or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
-                    continue
-                targs = [a.strip() for a in m.group(1).split(",")]
-                if len(targs) < 10 or (len(targs) > 10 and targs[10].startswith("t")):     # fp32-operand tiles only
-                    continue
-                if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
-                    traffic = (v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
-                    traffic_source = {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0,
-                                      "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0, "fetch_correction": "none applied "
-                                      "(guide: up to 2x under-report on streaming reads)", "measured_in_this_run": False}
-                    break
-        except KeyError:
-            pass
-        except Exception:
-            traffic, traffic_source = None, None
-        roofline = {
-            "bound": "mfma", "kernel": ("%s_kernel" if dom_name.startswith("conv_stem") else "conv_igemm_kernel<%s>") % dom_name,
-            "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": round(achieved / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "launches_per_step": dom["launches"],
-            "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-            "algorithmic_gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
-        }
+                    m = re.match(r"conv_igemm<([^>(]*)", k)         # names are cut at 60 characters by summarize_prof.py
+                    if not m or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
+                        continue
+                    targs = [a.strip() for a in m.group(1).split(",")]
+                    if len(targs) < 10 or (len(targs) > 10 and targs[10].startswith("t")):     # fp32-operand tiles only
+                        continue
+                    if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
+                        return hit(v)
+            except Exception:
+                pass
+            return None, None
+
+        def roof(name, ms, flop, launches):
+            traffic, traffic_source = traffic_for(name)
+            tf = flop / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": ("%s_kernel" if name.startswith("conv_stem") else "conv_igemm_kernel<%s>") % name,
+                    "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
+                    "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches,
+                    "avg_launch_ms": round(ms / launches, 4), "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3)}
+
+        # `roofline`: the kernel (one template instantiation, as rocprofv3 --stats groups them) with the largest total time
+        # per step -- since the stem got under 1.5 ms that can be a tile class with a dozen launches of different problems;
+        # `roofline_longest_launch`: the single longest launch of the step (the stem), whose average duration is the
+        # one-problem row of the committed rocprofv3 summary
+        roofline = roof(dom_name, dom["ms"], dom["flop"], dom["launches"])
+        ll = max(rows + stem_rows, key=lambda r: r[2])
+        roofline_longest = roof(ll[3], ll[2], 2.0 * ll[1], 1)
+        roofline_longest["label"] = ll[0]
         gflop_per_unit = GFLOP_PER_CLIP if headline else sum(2e-9 * r[1] for r in rows + stem_rows) / plan.shape[0]
         net_tf = gflop_per_unit * 1e9 * clips_per_s / world / 1e12
         roofline_net = {"bound": "mfma", "achieved": round(net_tf, 2), "peak": peak_tf,
@@ -428,7 +435,7 @@ def main():
             "config": {"workload": workload_label,
                        "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
-            "roofline": roofline, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
+            "roofline": roofline, "roofline_longest_launch": roofline_longest, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
             "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
             "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
             "distributed_check": verify, "ranks_seen": ranks_seen,
