@@ -562,3 +562,20 @@ def test_fp32_stem_plan_wiring_without_gpu(ptx, monkeypatch):
     d.kH, d.Wo, d.Wi = 7, 512, 1024                                                 # a 256-output span of rows no longer fits
     d.Hi, d.Ho = 64, 32
     assert lib.ptx_conv_stem_f32_supported(C.byref(d), 3 * 8 * 65536, 8 * 65536, 65536) == 0
+
+
+def test_inputs_are_bound_dense_and_16_byte_aligned(ptx):
+    """engine._dense16: the direct stem DMAs 16-byte pieces of the caller's tensor, so what gets bound is contiguous and
+    16-byte aligned -- as given when it already is (no copy), one copy otherwise."""
+    from pretorched_x_amd.engine import _dense16
+    x = torch.arange(2 * 3 * 4 * 8 * 8, dtype=torch.float32).reshape(2, 3, 4, 8, 8)
+    assert _dense16(x).data_ptr() == x.data_ptr()
+    flat = torch.zeros(x.numel() + 1)
+    flat[1:] = x.reshape(-1)
+    v = flat[1:].view_as(x)                       # contiguous, 4 bytes past a 16-byte boundary
+    assert v.is_contiguous() and v.data_ptr() % 16 != 0
+    d = _dense16(v)
+    assert d.data_ptr() % 16 == 0 and d.is_contiguous() and torch.equal(d, x)
+    s = x[:, :, ::2]                              # frame-strided user view: made contiguous
+    d = _dense16(s)
+    assert d.is_contiguous() and d.data_ptr() % 16 == 0 and torch.equal(d, s)
