@@ -32,51 +32,86 @@ GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md HBM3E peak
-TRAFFIC_FILE = "r02_pmc_traffic.json"   # newest committed PMC traffic table (profiles/), replayed in roofline.traffic
+def _newest_traffic_file():
+    """Newest committed PMC traffic table (profiles/rNN_pmc_traffic.json), replayed in roofline.traffic."""
+    import glob
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return names[-1] if names else "r02_pmc_traffic.json"
+
+
+TRAFFIC_FILE = _newest_traffic_file()
 
 
 def other_workload(name, rank):
-    """(model, state_dict, cpu input, forward(model, device input), cpu oracle fn, units per GPU, unit, label)
-    for the non-headline BASELINE.json configurations."""
+    """(model, weight recipe, make(n, seed) -> n CPU units, units per GPU, forward(model, device input) or None,
+    cpu oracle fn(sd, units, idx), unit, label, parity sample indices or None) for the non-headline BASELINE.json
+    configurations.  `idx`: positions of the sampled units inside this rank's batch (labels of config 5 follow them)."""
     import pretorched_x_amd as ptx
     from oracle import functional as OF
     from pretorched_x_amd.testing import BIGGAN_RECIPE, I3D_RECIPE, synth_state_dict
-    g = torch.Generator().manual_seed(99 + rank)
+
+    def randn(*shape):
+        return lambda n, seed: torch.randn(n, *shape, generator=torch.Generator().manual_seed(seed))
     if name == "cfg1":
-        m, recipe, x = ptx.resnet18(num_classes=1000, pretrained=None), {}, torch.randn(1, 3, 224, 224, generator=g)
-        return m, recipe, x, None, lambda sd, x: OF.forward(OF.ARCHS["resnet18"], sd, x), "images", \
-            "resnet18 2-D forward, 1x3x224x224 (config 1; arithmetic reference = torchvision stand-in, parity unpinned)"
+        m = ptx.resnet18(num_classes=1000, pretrained=None)
+        return m, {}, randn(3, 224, 224), 1, None, lambda sd, x, idx: OF.forward(OF.ARCHS["resnet18"], sd, x), "images", \
+            "resnet18 2-D forward, 1x3x224x224 (config 1; arithmetic reference = torchvision stand-in, parity unpinned)", None
     if name == "cfg3":
         m, recipe = ptx.nonlocal_r2plus1d50(339), dict(inner_bn_damp=0.9, nl_bn_damp=0.05)
-        x = torch.randn(8, 3, 32, 112, 112, generator=g)
-        return m, recipe, x, None, lambda sd, x: OF.forward(OF.ARCHS["nonlocal_r2plus1d50"], sd, x), "clips", \
-            "resnet2p1d50 + NL blocks forward, 8x3x32x112x112 synthetic clips per GPU (config 3)"
+        return m, recipe, randn(3, 32, 112, 112), 8, None, \
+            lambda sd, x, idx: OF.forward(OF.ARCHS["nonlocal_r2plus1d50"], sd, x), "clips", \
+            "resnet2p1d50 + NL blocks forward, 8x3x32x112x112 synthetic clips per GPU (config 3)", None
     if name == "cfg4":
         from oracle import i3d_standin as I3
-        m, recipe, x = ptx.i3d(400), I3D_RECIPE, torch.randn(2, 3, 64, 224, 224, generator=g)
-        return m, recipe, x, None, lambda sd, x: I3.forward(sd, x), "clips", \
-            "I3D (InceptionV1-3D) forward, 2x3x64x224x224 synthetic clips per GPU = 16 over 8 GPUs (config 4; parity unpinned)"
+        m, recipe = ptx.i3d(400), I3D_RECIPE
+        return m, recipe, randn(3, 64, 224, 224), 2, None, lambda sd, x, idx: I3.forward(sd, x), "clips", \
+            "I3D (InceptionV1-3D) forward, 2x3x64x224x224 synthetic clips per GPU = 16 over 8 GPUs (config 4; parity unpinned)", None
     if name in ("cfg5", "cfg5-fp32"):
         from oracle import biggan_standin as BG
         half = name == "cfg5"
         m, recipe = ptx.biggan_deep(256, precision="fp16" if half else "fp32"), BIGGAN_RECIPE
+        g = torch.Generator().manual_seed(99 + rank)
         z = torch.randn(64, 128, generator=g)
         lab = torch.randint(0, 1000, (64,), generator=g)
 
         def fwd(model, zd, lab=lab):
             return model(zd, model.shared(lab.to(zd.device)))
-        return m, recipe, z, fwd, lambda sd, z: BG.forward(sd, z, sd["shared.weight"][lab[:z.shape[0]]]), "images", \
+        # Engine.generate runs batch 64 as two 32-image chunks: the parity sample takes images from BOTH
+        return m, recipe, (lambda n, seed: z[:n]), 64, fwd, \
+            lambda sd, zs, idx: BG.forward(sd, zs, sd["shared.weight"][lab[idx]]), "images", \
             ("BigGAN-deep-256 generator, batch 64 z ~ N(0,1) + class labels per GPU, %s (config 5; parity unpinned)" %
-             ("fp16 MFMA operands, fp32 accumulate / skip / output" if half else "fp32 MFMA path"))
+             ("fp16 MFMA operands, fp32 accumulate / skip / output" if half else "fp32 MFMA path")), [0, 31, 32, 63]
     raise SystemExit("unknown workload %r" % name)
 
 
-def timed_steps(run, units_per_gpu, steps, warmup, dev, sync):
+GLOBAL_BATCH = {"cfg1": 1, "cfg2": 8, "cfg3": 8, "cfg4": 16}      # BASELINE.json configs: the batch the metric is quoted on
+
+
+def local_batch(make, per_gpu, workload, scaling, world, rank):
+    """This rank's input batch and the job's total units per step.
+    weak   (default; the headline's "8 clips per GPU"): every rank draws its own `per_gpu` units (seed 99 + rank);
+           total = per_gpu x N.
+    strong (SURVEY.md 8e "report it too if cheap"; config 4 is strong by construction, 16 clips over 8 GPUs): ONE global
+           batch of BASELINE.json's size, identical on every rank (seed 99), cut into contiguous dim-0 shards exactly as the
+           reference's DataParallel scatter does (parallel.shard_clips; ragged when N does not divide it).  At N = 8 the
+           headline's 8-clip batch leaves ONE clip per GPU.
+    `make(n, seed)` builds n units on the CPU."""
+    from pretorched_x_amd.parallel import shard_clips
+    if scaling == "strong":
+        if workload not in GLOBAL_BATCH:
+            raise SystemExit("--scaling strong: %s has no clip batch to shard" % workload)
+        total = GLOBAL_BATCH[workload]
+        return shard_clips(make(total, 99), world, rank), total
+    return make(per_gpu, 99 + rank), per_gpu * world
+
+
+def timed_steps(run, total_units, steps, warmup, dev, sync):
     """The timed region of the bench contract -- W untimed warm-up steps, then exactly K steps bracketed by a
     barrier + device synchronisation on both sides, MAX over ranks -- followed, for N > 1, by the self-check of
     the clip-parallel step (parallel.verify_gather) OUTSIDE the timed region.  Backend-agnostic: the CPU test
     drives this very function under gloo with a stand-in forward.
-    A step = one forward of this rank's units (+ the one all-gather of logits when N > 1).
+    A step = one forward of this rank's units (+ the one all-gather of logits when N > 1).  `total_units`: units of
+    the WHOLE job per step (weak scaling: units per GPU x N; strong scaling: the fixed global batch, shards may be ragged).
     Returns (elapsed seconds, last step output, verify dict or None)."""
     import torch.distributed as dist
     from pretorched_x_amd.parallel import gather_logits, verify_gather
@@ -85,7 +120,7 @@ def timed_steps(run, units_per_gpu, steps, warmup, dev, sync):
     def step():
         out = run()
         if world > 1 and out.dim() == 2:           # class logits: the path's one collective (images stay sharded)
-            out = gather_logits(out, total=units_per_gpu * world)
+            out = gather_logits(out, total=total_units)
         return out
 
     out = None
@@ -110,9 +145,9 @@ def timed_steps(run, units_per_gpu, steps, warmup, dev, sync):
         elapsed = float(t.item())
         local = run()
         if local.dim() == 2:
-            verify = verify_gather(local, gather_logits(local, total=units_per_gpu * world))
+            verify = verify_gather(local, gather_logits(local, total=total_units))
             # a second, independent forward must reproduce the timed steps' result bit for bit
-            verify["deterministic"] = bool(torch.equal(gather_logits(local, total=units_per_gpu * world), out))
+            verify["deterministic"] = bool(torch.equal(gather_logits(local, total=total_units), out))
             flag = torch.tensor([int(verify["deterministic"])], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             verify["deterministic"] = bool(flag.item())
@@ -129,6 +164,9 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-x3", action="store_true", help="skip the secondary split-precision (x3) leg")
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5-fp32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the headline): a fixed batch PER GPU; strong: BASELINE's global batch (cfg2 / cfg3: 8 "
+                         "clips, cfg4: 16) sharded over the ranks -- at 8 GPUs the headline batch leaves 1 clip per GPU")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -152,19 +190,25 @@ def main():
     f16 = args.workload == "cfg5"
     peak_tf = PEAK_F16_MFMA_TF if f16 else PEAK_F32_MFMA_TF
     tolerance = 5e-2 if f16 else 1e-3         # fp16 operands: builder-chosen bound on |d image| (parity unpinned)
-    fwd, unit, units_per_gpu = None, "clips", CLIPS_PER_GPU
+    fwd, unit, sample_idx = None, "clips", None
     if headline:
         model = ptx.__dict__["resnet3d50"](num_classes=CLASSES, pretrained=None)
         sd = synth_state_dict(model.state_dict(), 1234)
-        x_cpu = synth_clips(CLIPS_PER_GPU, FRAMES, SIZE, 99 + rank)       # per-rank clips
+        make, per_gpu = (lambda n, seed: synth_clips(n, FRAMES, SIZE, seed)), CLIPS_PER_GPU      # per-rank clips
         from oracle import functional as OF_
-        cpu_fn = lambda sd_, x_: OF_.forward(OF_.ARCHS["resnet3d50"], sd_, x_)   # noqa: E731
+        cpu_fn = lambda sd_, x_, idx_: OF_.forward(OF_.ARCHS["resnet3d50"], sd_, x_)   # noqa: E731
         workload_label = ("resnet3d50 (Moments-339) forward, %dx3x%dx%dx%d synthetic clips per GPU, "
                           "random-init weights (seeded recipe)" % (CLIPS_PER_GPU, FRAMES, SIZE, SIZE))
     else:
-        model, recipe, x_cpu, fwd, cpu_fn, unit, workload_label = other_workload(args.workload, rank)
+        model, recipe, make, per_gpu, fwd, cpu_fn, unit, workload_label, sample_idx = other_workload(args.workload, rank)
         sd = synth_state_dict(model.state_dict(), 1234, **recipe)
-        units_per_gpu = x_cpu.shape[0]
+    x_cpu, total_units = local_batch(make, per_gpu, args.workload, args.scaling, world, rank)
+    units_per_gpu = x_cpu.shape[0]                # this rank's share (strong scaling: may be ragged, may be 0 past the batch)
+    if units_per_gpu == 0:
+        raise SystemExit("--scaling strong: %d ranks for a %d-%s batch leaves rank %d without work" % (world, total_units, unit, rank))
+    if args.scaling == "strong":
+        workload_label += " -- STRONG scaling: one %d-%s global batch sharded over %d GPU(s), %d on rank 0" % (
+            total_units, unit[:-1], world, units_per_gpu)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.engine().check_weights = True
@@ -189,7 +233,7 @@ def main():
             from pretorched_x_amd.engine import save_tuned_table
             save_tuned_table(os.environ["PTX_TUNED_OUT"])
 
-    elapsed, out, verify = timed_steps(run, units_per_gpu, args.steps, args.warmup, dev, torch.cuda.synchronize)
+    elapsed, out, verify = timed_steps(run, total_units, args.steps, args.warmup, dev, torch.cuda.synchronize)
     ranks_seen = None
     if world > 1:
         seen = [None] * world
@@ -201,7 +245,7 @@ def main():
                       "tuned_entries_broadcast": tuned_entries}
 
     ms_per_step = 1e3 * elapsed / args.steps
-    clips_per_s = units_per_gpu * world * args.steps / elapsed
+    clips_per_s = total_units * args.steps / elapsed
 
     result = None
     if rank == 0:
@@ -259,14 +303,17 @@ def main():
                 tpath = os.path.join("profiles", TRAFFIC_FILE)
                 tj = json.load(open(os.path.join(ROOT, tpath)))
 
+                meta = tj.get("_meta", {})
+
                 def hit(v):
                     return ((v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0,
-                            {"file": tpath, "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0, "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0,
+                            {"file": tpath, "commit": meta.get("commit"), "command": meta.get("command"),
+                             "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0, "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0,
                              "fetch_correction": "none applied (guide: up to 2x under-report on streaming reads)",
                              "measured_in_this_run": False})
                 if name.startswith("conv_stem"):                # the direct stem kernels: one row per kernel name
                     for k, v in tj.items():
-                        if k.startswith(name + "_kernel") and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
+                        if k.startswith(name + "_kernel") and isinstance(v, dict) and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
                             return hit(v)
                     return None, None
                 tile, waves, mt = name.split("/")[:3]
@@ -276,7 +323,7 @@ def main():
                 want_nstage = int(stage[3:]) if len(stage) > 3 else 2
                 for k, v in tj.items():
                     m = re.match(r"conv_igemm<([^>(]*)", k)         # names are cut at 60 characters by summarize_prof.py
-                    if not m or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
+                    if not m or not isinstance(v, dict) or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
                         continue
                     targs = [a.strip() for a in m.group(1).split(",")]
                     if len(targs) < 10 or (len(targs) > 10 and targs[10].startswith("t")):     # fp32-operand tiles only
@@ -287,13 +334,26 @@ def main():
                 pass
             return None, None
 
+        # FLOP the direct stem kernels actually ISSUE per launch (pruned temporal taps excluded, K padded 21 -> 22): the
+        # host-side twin of SQ_INSTS_MFMA x 4096 from the committed PMC pass
+        issued_by_kernel = {}
+        for stp in plan.steps:
+            if hasattr(stp, "issued_flop"):
+                issued_by_kernel[stp.kernel] = issued_by_kernel.get(stp.kernel, 0.0) + stp.issued_flop()
+
         def roof(name, ms, flop, launches):
             traffic, traffic_source = traffic_for(name)
             tf = flop / (ms * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": ("%s_kernel" if name.startswith("conv_stem") else "conv_igemm_kernel<%s>") % name,
-                    "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
-                    "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches,
-                    "avg_launch_ms": round(ms / launches, 4), "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3)}
+            r = {"bound": "mfma", "kernel": ("%s_kernel" if name.startswith("conv_stem") else "conv_igemm_kernel<%s>") % name,
+                 "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
+                 "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches,
+                 "avg_launch_ms": round(ms / launches, 4), "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3)}
+            # `frac` prices padding taps as work (SURVEY.md 8d allows it); `issued_frac` = MFMA FLOP the kernel really
+            # issues / time / peak -- null for the generic tiles, whose tap pruning is decided per tile at run time
+            iss = issued_by_kernel.get(name)
+            r["issued_gflop_per_launch"] = round(iss / launches / 1e9, 3) if iss else None
+            r["issued_frac"] = round(iss / (ms * 1e-3) / 1e12 / peak_tf, 4) if iss else None
+            return r
 
         # `roofline`: the kernel (one template instantiation, as rocprofv3 --stats groups them) with the largest total time
         # per step -- since the stem got under 1.5 ms that can be a tile class with a dozen launches of different problems;
@@ -314,13 +374,24 @@ def main():
         # ---- CPU baseline: the oracle restatement of the reference path on this box's host cores ----
         cpu = None
         parity = None
+
+        def sample_indices():
+            """Units of this rank's batch that the CPU oracle recomputes: the full batch for config 2; else a bounded
+            sample -- the workload's own picks (config 5: images from BOTH 32-image chunks Engine.generate runs) or the
+            first two."""
+            if headline:
+                return list(range(units_per_gpu))
+            if sample_idx is not None:
+                return [i for i in sample_idx if i < units_per_gpu]
+            return list(range(min(2, units_per_gpu)))
         if not args.no_cpu_baseline and world > 1:
             # N > 1: the CPU baseline is reported at N = 1 only (bench contract), but the line stays
             # self-verifying -- rank 0 checks ITS OWN shard against the oracle (one bounded CPU forward)
-            xs = x_cpu if headline else x_cpu[:min(2, units_per_gpu)]
+            idx = sample_indices()
+            xs = x_cpu[idx]
             torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(1, world))))
-            want = cpu_fn(sd, xs)
-            got = run().cpu()[:xs.shape[0]]
+            want = cpu_fn(sd, xs, idx)
+            got = run().cpu()[idx]
             parity = {"max_abs_dlogits": float((got - want).abs().max().item()),
                       "max_abs_logit": float(want.abs().max().item()),
                       "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
@@ -328,7 +399,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
             ncpu = os.cpu_count() or 1
             # bounded sample: the full batch for config 2, at most 2 units for the heavier configurations
-            xs = x_cpu if headline else x_cpu[:min(2, units_per_gpu)]
+            idx = sample_indices()
+            xs = x_cpu[idx]
             # pick the thread count that runs the reference path fastest on this host (SMT
             # oversubscription makes oneDNN conv3d collapse), then time it: bounded to ~30 s
             cands = sorted({c for c in (16, 32, 64, 128, ncpu // 2) if 1 <= c <= ncpu})
@@ -337,7 +409,7 @@ def main():
             for n in cands:
                 torch.set_num_threads(n)
                 t1 = time.perf_counter()
-                want = cpu_fn(sd, xs)
+                want = cpu_fn(sd, xs, idx)
                 dt = time.perf_counter() - t1
                 if best_t is None or dt < best_t:
                     best_t, best_n = dt, n
@@ -347,18 +419,20 @@ def main():
             times = [best_t]
             while len(times) < 4 and time.perf_counter() < deadline:
                 t1 = time.perf_counter()
-                cpu_fn(sd, xs)
+                cpu_fn(sd, xs, idx)
                 times.append(time.perf_counter() - t1)
             med = sorted(times)[len(times) // 2]
             cpu = {"value": round(xs.shape[0] / med, 3), "unit": "%s/s" % unit, "cores": best_n,
+                   "label": "oracle on %d host threads (the fastest of a bounded thread-count sweep; NOT the node's %d "
+                            "hardware threads -- oneDNN conv3d collapses under SMT oversubscription)" % (best_n, ncpu),
                    "kind": "port", "sample": "%d timed forwards of %s (median), oracle/ (torch CPU fp32, oneDNN) on %d of "
                    "%d host threads" % (len(times), "the full 8x3x16x224x224 batch" if headline else
                                         "%d of the %d %s of a step" % (xs.shape[0], units_per_gpu, unit), best_n, ncpu)}
-            got = run().cpu()[:xs.shape[0]]
+            got = run().cpu()[idx]
             parity = {"max_abs_dlogits": float((got - want).abs().max().item()),
                       "max_abs_logit": float(want.abs().max().item()),
                       "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
-                      "tolerance": tolerance}
+                      "tolerance": tolerance, "units_checked": [int(i) for i in idx]}
 
         # ---- secondary leg: the same workload with Engine.precision = "x3" (fp32 operands split into half pairs,
         # three fp16 MFMAs per product block, fp32 accumulate -- fp32-ACCURATE).  Reported next to
@@ -402,7 +476,7 @@ def main():
                 k["flop"] += 2.0 * macs
                 k["launches"] += 1
             dn, dv = max(byk.items(), key=lambda kv: kv[1]["ms"])
-            rate3 = units_per_gpu * args.steps / el3
+            rate3 = units_per_gpu * args.steps / el3          # (world == 1 here)
             peak3 = PEAK_F16_MFMA_TF / 3.0
             tf3 = gflop_per_unit * 1e9 * rate3 / 1e12
             split = {"precision": "fp32 operands as half (hi, lo) pairs: a.b = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, "
@@ -420,7 +494,7 @@ def main():
                                       "non_conv_ms": round(sum(r[4] for r in rows3 if r[1] not in ("conv", "stem")), 3)},
                      "parity": None}
             if parity is not None:
-                got3 = out3.cpu()[:want.shape[0]]
+                got3 = out3.cpu()[idx]
                 split["parity"] = {"max_abs_dlogits": float((got3 - want).abs().max().item()),
                                    "argmax_equal": bool(torch.equal(got3.argmax(1), want.argmax(1))) if got3.dim() == 2 else None,
                                    "tolerance": tolerance}
@@ -431,13 +505,14 @@ def main():
                        "%s/sec, %s (+ max|d output| vs CPU)" % (unit, args.workload)),
             "value": round(clips_per_s, 2), "unit": "%s/s" % unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
             "config": {"workload": workload_label,
-                       "clips_per_gpu": units_per_gpu, "global_batch": units_per_gpu * world,
+                       "clips_per_gpu": units_per_gpu, "global_batch": total_units,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
             "roofline": roofline, "roofline_longest_launch": roofline_longest, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
             "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
             "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
+            "commit": os.environ.get("PTX_COMMIT"),
             "distributed_check": verify, "ranks_seen": ranks_seen,
         }
     if rank == 0 and os.environ.get("PTX_TUNED_OUT"):      # tile choices of this run (both legs), for tuned_gfx950.json

@@ -178,8 +178,10 @@ int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* desc, const float* x, const floa
  * pieces of the NCDHW rows, zero outside the image) and serves all kH x 7 taps from it; K = 21 runs as 11
  * v_mfma_f32_32x32x2_f32 per tap.  fp32 operands, fp32 accumulate.
  * desc: Ci = 3, kW = 7, 2 <= kH <= 8, stride_w <= 2, symmetric or SAME padding (front pad in pT/pH/pW), flags within
- * PTX_EPI_RELU, Wi % 4 == 0, a patch of at most 12288 floats; ldx / Kc are ignored.  x: [N][3][T][H][W] fp32 with element strides (stride_n, stride_c, stride_t) -- multiples of
- * 4, so `input[:, :, ::step]` (torchvision_models.py frame sub-sampling) is a stride, not a copy -- rows contiguous.
+ * PTX_EPI_RELU, a patch of at most 12288 floats; Kc is ignored.  ldx = ROW PITCH of x in floats (0 = Wi): a multiple of
+ * 4, >= Wi, with the floats [Wi, ldx) of every row zero (ptx_pad_rows makes such a copy for widths that are not multiples
+ * of 4).  x: [N][3][T][H][pitch] fp32 with element strides (stride_n, stride_c, stride_t) -- multiples of
+ * 4, so `input[:, :, ::step]` (torchvision_models.py frame sub-sampling) is a stride, not a copy.
  * w_stem: ptx_pack_stem_f32_weight of the folded K-major filter ([kT*kH][Co_pad][Kc], k = kw*3 + c: ptx_pack_conv_weight
  * with fold_kw = 1, which also folds the BatchNorm), ptx_stem_f32_weight_elems floats.  bias: [Co_pad] from the same pack.
  * y: [N][To][Ho][Wo][ldy] fp32.  ptx_conv_stem_f32_supported: 1 if the descriptor / strides can run here (else use
@@ -236,7 +238,8 @@ typedef struct ptx_pack_desc {
     /* 1: w_packed is written as IEEE halfs (Kc counts halfs, multiple of 8; ptx_packed_weight_elems counts
      * halfs) for PTX_F16_OPERANDS convs.  2: split halfs for PTX_F16X3_OPERANDS convs -- Kc, ld_k, k_off count
      * channels as in the fp32 layout (multiples of 8) and the buffer has the fp32 layout's size, but every 8-channel
-     * block of a row holds 8 hi halfs then 8 lo halfs (hi = half(w), lo = half(w - hi)).  bias_out stays fp32. */
+     * block of a row holds 8 hi halfs then 8 lo halfs (hi = half(w), lo = half((w - hi) * 2^12): the SCALED lo of
+     * PTX_F16X3_OPERANDS, whose cross terms the kernels accumulate separately and fold back by 2^-12).  bias_out stays fp32. */
     int32_t f16;
 } ptx_pack_desc;
 
@@ -276,6 +279,11 @@ int ptx_fold_kw_ncdhw(const float* x, float* y, int32_t N, int32_t C, int32_t T,
 int ptx_fold_kw_strided(const float* x, float* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W,
                         int64_t stride_n, int64_t stride_c, int64_t stride_t, int32_t kW, int32_t sW,
                         int32_t pW, int32_t Wo, int32_t ld, ptx_stream_t stream);
+
+/* y[r][0..W) = x[r][0..W), y[r][W..ld) = 0 for r < rows: gives image rows whose width is not a multiple of 4 floats the
+ * 16-byte pitch the direct stem reads (ptx_conv_stem_f32_fwd with desc.ldx = ld); the reference takes any T/H/W
+ * (torchvision_models.py:448, adaptive pooling).                                                                       */
+int ptx_pad_rows(const float* x, float* y, int64_t rows, int32_t W, int32_t ld, ptx_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Pre-processing edge: the tensor half of TransformImage (transforms/utils.py:72-75) on decoded
@@ -384,15 +392,24 @@ int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float*
  * y [batch][Nq][ld_y] (dv written); channels-last rows, so the operands may be channel slices of one fused
  * theta|phi|g projection and Nk != Nq covers `sub_sample` (max-pooled phi / g, :126-131) and BigGAN's pooled keys.
  * fp32 MFMA throughout; differs from softmax-then-matmul only by fp32 summation order (+ v_exp_f32 rounding).
- * Limits: d, dv multiples of 4, d <= 512 (ptx_nonlocal_supported); larger d: ptx_bgemm_nt + ptx_softmax_rows. */
+ *   mode PTX_NL_SCALE | PTX_NL_RELU: y[b][i][:] = sum_j (relu(theta[b][i] . phi[b][j]) / Nk) g[b][j][:] -- the 'concatenation'
+ *                        affinity (:213-243): the 1x1 conv over cat([theta_i, phi_j]) is a_i + b_j, i.e. the dot product of
+ *                        the 2-vectors theta' = (a_i, 1) and phi' = (1, b_j) (d = 4 rows: two live columns, two zero)
+ * Limits: d, dv multiples of 4, d <= 1024 (ptx_nonlocal_supported); d > 512 (gaussian mode on 1024 channels: theta = x)
+ * streams the theta fragments from global memory instead of registers; larger d: ptx_bgemm_nt + ptx_softmax_rows. */
 #define PTX_NL_SOFTMAX 0
 #define PTX_NL_SCALE 1
 #define PTX_NL_F16 2   /* OR into mode (softmax, d <= 64): both matmuls on v_mfma_f32_16x16x16_f16 -- theta / phi / g / P are rounded
                           to halfs in registers, accumulators / softmax statistics / y stay fp32.  The BigGAN generator's
                           self-attention under its fp16 plan (BASELINE config 5); the video nets keep the fp32 kernel. */
+#define PTX_NL_RELU 8  /* OR into PTX_NL_SCALE: P = relu(S) / Nk (concatenation mode)                                               */
 #define PTX_NL_X3 4    /* OR into mode: fp32-ACCURATE split operands on the same fp16 MFMAs (theta / phi / g / P as (hi, lo) half
                           pairs, a.b = hi.lo + lo.hi + hi.hi, fp32 accumulate) -- the attention of a plan compiled with
-                          Engine.precision = "x3" (PTX_F16X3_OPERANDS convs).  Exclusive with PTX_NL_F16.               */
+                          Engine.precision = "x3" (PTX_F16X3_OPERANDS convs).  Exclusive with PTX_NL_F16.  The lo halves of
+                          theta / phi / g are UNSCALED here (unlike the convs): 22 bits per product for |v| >= 2^-3, fewer
+                          below (lo goes subnormal) -- activations entering an NL block are O(1); the softmax weights, which
+                          are not (P ~ 1 / Nk), are split as 2^12 P with the factor folded into 1 / l.  d > 512 runs the
+                          exact fp32 kernel.                                                                            */
 typedef struct ptx_nonlocal_desc {
     int32_t batch, Nq, Nk, d, dv;
     int32_t ld_theta, ld_phi, ld_g, ld_y;        /* row strides (floats)   */

@@ -26,7 +26,9 @@ PTX_EPI_OUT_F16, PTX_EPI_AFFINE, PTX_EPI_DUAL_RAW, PTX_RES_F16, PTX_PRO_UP2, PTX
 
 
 class PtxError(RuntimeError):
-    pass
+    """`status` carries the library's status code (PTX_ERR_*: 1 invalid, 2 unsupported, 3 HIP, 4 workspace) when the
+    error came from a libptx_amd call, else None."""
+    status = None
 
 
 class ConvDesc(C.Structure):
@@ -92,7 +94,7 @@ class NonlocalDesc(C.Structure):
                [(n, C.c_int64) for n in ("bs_theta", "bs_phi", "bs_g", "bs_y")] + [("mode", C.c_int32)]
 
 
-PTX_NL_SOFTMAX, PTX_NL_SCALE, PTX_NL_F16, PTX_NL_X3 = 0, 1, 2, 4
+PTX_NL_SOFTMAX, PTX_NL_SCALE, PTX_NL_F16, PTX_NL_X3, PTX_NL_RELU = 0, 1, 2, 4, 8
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -127,6 +129,7 @@ SIGNATURES = {
     "ptx_ndhwc_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _L, _I, _P]),
     "ptx_fold_kw_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ptx_fold_kw_strided": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "ptx_pad_rows": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "ptx_frames_u8_to_ncdhw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
     "ptx_fold_kw_frames_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(NormDesc), _P]),
     "ptx_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
@@ -178,4 +181,6 @@ def lib():
 def check(status, what=""):
     if status != 0:
         msg = lib().ptx_last_error().decode(errors="replace")
-        raise PtxError("%s failed (status %d): %s" % (what or "libptx_amd call", status, msg))
+        err = PtxError("%s failed (status %d): %s" % (what or "libptx_amd call", status, msg))
+        err.status = int(status)
+        raise err

@@ -30,7 +30,9 @@
 // fp32 in, fp32 accumulate, bit-exact k-ordered fma chain (cdna_hip_programming.md section 3).
 #include "ptx_common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ptx {
 
@@ -1535,6 +1537,17 @@ static const ConvConfig kConfigs[] = {
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
+// Default tiles are resolved BY NAME (once): inserting or reordering kConfigs entries can then never make a heuristic
+// pick a tile of the wrong operand kind (an fp32 tile for an x3-packed filter computes garbage without an error).
+// A name this build does not have is a build defect: it aborts at the first lookup instead of returning a wrong tile.
+static int cfg_named(const char* name) {
+    for (int i = 0; i < kNumConfigs; ++i)
+        if (!strcmp(kConfigs[i].name, name)) return i;
+    fprintf(stderr, "libptx_amd: default tile configuration \"%s\" is not compiled into this build\n", name);
+    abort();
+}
+#define PTX_TILE(name) ([]() -> int { static const int idx = cfg_named(name); return idx; }())
+
 static int validate_desc(const ptx_conv3d_desc* d) {
     if (!d) return fail(PTX_ERR_INVALID, "conv3d: null descriptor");
     if (d->N <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 ||
@@ -1614,13 +1627,15 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     int cfg;
     if (d->flags & PTX_F16_OPERANDS) {
         const int64_t Mrows = (int64_t)d->N * d->To * d->Ho * d->Wo;
-        return ncol <= 16 ? 86 : ncol <= 32 ? 81 : (Mrows < 8192 ? 80 : (ncol >= 128 ? 74 : 75));
+        return ncol <= 16 ? PTX_TILE("256x16x32/8x1/m16/dma/f16") : ncol <= 32 ? PTX_TILE("64x32x32/2x2/m16/dma/f16")
+               : (Mrows < 8192 ? PTX_TILE("32x64x32/2x2/m16/dma/f16")
+                               : (ncol >= 128 ? PTX_TILE("128x128x32/4x2/m32/dma/f16") : PTX_TILE("128x64x32/4x2/m32/dma/f16")));
     }
     if (d->flags & PTX_F16X3_OPERANDS) {           // split operands: defaults; the tuner refines them
-        if (M < 8192) cfg = ncol >= 128 ? 95 : 94;
-        else if (ncol >= 128 && cdiv64(M, 128) * cdiv(ncol, 128) >= 2 * kNumCU) cfg = 96;
-        else if (M >= 256 * 1024 && ncol <= 64) cfg = 100;
-        else cfg = ncol >= 128 ? 92 : 91;
+        if (M < 8192) cfg = ncol >= 128 ? PTX_TILE("32x128x64/2x2/m16/dma/x3") : PTX_TILE("32x64x64/2x2/m16/dma/x3");
+        else if (ncol >= 128 && cdiv64(M, 128) * cdiv(ncol, 128) >= 2 * kNumCU) cfg = PTX_TILE("128x128x32/2x2/m32/dma/x3");
+        else if (M >= 256 * 1024 && ncol <= 64) cfg = PTX_TILE("256x64x32/4x1/m32/dma/x3");
+        else cfg = ncol >= 128 ? PTX_TILE("64x128x32/2x2/m32/dma/x3") : PTX_TILE("64x64x32/2x2/m32/dma/x3");
         const ConvConfig& c = kConfigs[cfg];
         const int64_t blocks = cdiv64(M, c.BM) * cdiv(ncol, c.BN);
         const int steps = taps * cdiv(d->Kc, c.BK);
@@ -1635,19 +1650,19 @@ extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {
     }
     if (d->groups > 1) {                           // grouped conv: direct tiles sized to the group's output width
         const int cog = d->Co / d->groups;
-        if (cog % 32 == 0) return 37;              // 64x32x32 MFMA tile inside one group
-        return cog % 16 == 0 ? 65 : cog % 8 == 0 ? 64 : 73;
+        if (cog % 32 == 0) return PTX_TILE("64x32x32/2x2/m16/dma");              // 64x32x32 MFMA tile inside one group
+        return cog % 16 == 0 ? PTX_TILE("512x16x4/direct") : cog % 8 == 0 ? PTX_TILE("512x8x4/direct") : PTX_TILE("512x4x4/direct");
     }
     if (d->Kc == 24) {
-        cfg = M >= 256 * 1024 ? 16 : 6;            // kW-folded stem: 8-wave 256x64x24 (register staged)
+        cfg = M >= 256 * 1024 ? PTX_TILE("256x64x24/8x1/m32") : PTX_TILE("128x64x24/2x2/m32");            // kW-folded stem: 8-wave 256x64x24 (register staged)
     } else if (ncol % 48 == 0 && ncol % 64 != 0) {
-        cfg = 39;                                  // (2+1)D mid widths 144 * 2^k: 48-wide N tiles
+        cfg = PTX_TILE("64x48x32/4x1/m16/dma");                                  // (2+1)D mid widths 144 * 2^k: 48-wide N tiles
     } else if (M < 8192) {
-        cfg = ncol >= 128 ? 35 : 30;             // small M: 32-row tiles on 16x16x4 MFMA (DMA)
+        cfg = ncol >= 128 ? PTX_TILE("32x128x32/2x2/m16/dma") : PTX_TILE("32x64x32/2x2/m16/dma");             // small M: 32-row tiles on 16x16x4 MFMA (DMA)
     } else if (ncol >= 128 && taps * d->Kc > 128 && cdiv64(M, 128) * cdiv(ncol, 128) >= 4 * kNumCU) {
-        cfg = 26;                                  // wide output, big grid: 8-wave 128x128 (DMA)
+        cfg = PTX_TILE("128x128x32/4x2/m32/dma");                                  // wide output, big grid: 8-wave 128x128 (DMA)
     } else {
-        cfg = 28;                                  // default: 64x64x16 DMA tiles, 8 workgroups per CU
+        cfg = PTX_TILE("64x64x16/2x2/m32/dma");                                  // default: 64x64x16 DMA tiles, 8 workgroups per CU
     }
     const ConvConfig& c = kConfigs[cfg];
     const int64_t blocks = cdiv64(M, c.BM) * cdiv(ncol, c.BN);
@@ -1776,7 +1791,7 @@ int linear_gemm(const float* x, const float* w, const float* b, float* y, int M,
     a.groups = 1; a.cig = K; a.cog = Nout; a.pps = M;
     a.x_bytes = (unsigned)((uint64_t)M * ldx * 4ull);
     a.w_bytes = (unsigned)((uint64_t)Nout * K * 4ull);
-    const int config = M <= 32 ? 30 : 24;          // 32x64x32 / 64x64x32 LDS-DMA tiles
+    const int config = M <= 32 ? PTX_TILE("32x64x32/2x2/m16/dma") : PTX_TILE("64x64x32/2x2/m32/dma");          // 32x64x32 / 64x64x32 LDS-DMA tiles
     return launch_conv(a, config, 1, 1, nullptr, 0, st);
 }
 }  // namespace ptx
@@ -1942,7 +1957,7 @@ extern "C" int ptx_bgemm_nt(const float* A, const float* B, float* C, int32_t ba
     // C columns [Nn, ldc) are written as zero (B rows >= Nn are read as zero)
     // LDS-DMA tiles: 128x128 (8 waves) when that still yields >= 2 workgroups per CU, else 64x64
     const int64_t blocks128 = cdiv64(M, 128) * cdiv(ldc, 128) * batch;
-    const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? 26 : 24;
+    const int config = (ldc >= 128 && blocks128 >= 2 * kNumCU) ? PTX_TILE("128x128x32/4x2/m32/dma") : PTX_TILE("64x64x32/2x2/m32/dma");
     return launch_conv(a, config, 1, batch, nullptr, 0, (hipStream_t)stream);
 }
 

@@ -31,6 +31,7 @@ struct StemF32Args {
     const float* bias;
     float* y;             // [N][To][Ho][Wo][ldy]
     int N, Ti, Hi, Wi, To, Ho, Wo, ldy, ncol;
+    int pitch;            // floats per input row (>= Wi, multiple of 4; [Wi, pitch) are zero)
     int kT, kH, sT, sH, sW, pT, pH;
     int sn, sc, st;       // batch / channel / frame strides of x
     int PR, PC, plane;    // patch rows, floats per patch row (multiple of 4), PR * PC
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
         const int pr = rem / pc4;
         const int h = h_base + pr, w = (rem - pr * pc4) * 4 + p.wbase;
         const bool ok = c < 3 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
-        a_src[i] = ok ? (unsigned)((c * p.sc + h * p.Wi + w) * 4) : kOOB;
+        a_src[i] = ok ? (unsigned)((c * p.sc + h * p.pitch + w) * 4) : kOOB;
     }
     unsigned b_src[2];
 #pragma unroll
@@ -350,7 +351,7 @@ struct StemF32Geom {
 
 static bool stem_f32_geom(const ptx_conv3d_desc* d, StemF32Geom* g) {
     const int frame = d->Ho * d->Wo;
-    // rows a 512-output raster span can touch
+    // rows a kF32Rows-output raster span can touch
     const int nrows = std::min(d->Ho, (kF32Rows - 1 + d->Wo - 1) / d->Wo + 1);
     g->PR = (nrows - 1) * d->sH + d->kH;
     g->wbase = -((d->pW + 3) / 4 * 4);
@@ -369,10 +370,11 @@ extern "C" int ptx_conv_stem_f32_supported(const ptx_conv3d_desc* d, int64_t str
     if (d->flags & ~PTX_EPI_RELU) return 0;
     if (d->Ci != 3 || d->kW != 7 || d->kT < 1 || d->kT > 8 || d->kH < 2 || d->kH > 8 || d->groups > 1 || d->Co_pad % kF32BN) return 0;
     if (d->sW < 1 || d->sW > 2 || d->sH < 1 || d->sT < 1 || d->Wo < 1 || d->Ho < 1 || d->To < 1 || d->pW < 0 || d->pW > 8) return 0;
-    if (d->Wi % 4 || stride_n % 4 || stride_c % 4 || stride_t % 4) return 0;          // 16-byte DMA pieces of NCDHW rows
+    const int pitch = d->ldx > 0 ? d->ldx : d->Wi;             // floats per input row
+    if (pitch % 4 || pitch < d->Wi || stride_n % 4 || stride_c % 4 || stride_t % 4) return 0;   // 16-byte DMA pieces of NCDHW rows
     // a plane inside its channel, a channel inside its sample: the buffer descriptor's range is derived from these
-    const int64_t chan_extent = (int64_t)(d->Ti - 1) * stride_t + (int64_t)d->Hi * d->Wi;
-    if (stride_t < (int64_t)d->Hi * d->Wi || stride_c < chan_extent || stride_n < 2 * stride_c + chan_extent) return 0;
+    const int64_t chan_extent = (int64_t)(d->Ti - 1) * stride_t + (int64_t)d->Hi * pitch;
+    if (stride_t < (int64_t)d->Hi * pitch || stride_c < chan_extent || stride_n < 2 * stride_c + chan_extent) return 0;
     StemF32Geom g;
     if (!stem_f32_geom(d, &g)) return 0;
     if (((int64_t)(d->N - 1) * stride_n + 3 * stride_c) * 4 >= 0x80000000LL ||
@@ -411,7 +413,7 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     if (!d || !x || !w_stem || !y) return fail(PTX_ERR_INVALID, "conv_stem_f32: null pointer");
     if (((uintptr_t)x | (uintptr_t)w_stem | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "conv_stem_f32: pointers must be 16-byte aligned");
     if (!ptx_conv_stem_f32_supported(d, stride_n, stride_c, stride_t))
-        return fail(PTX_ERR_UNSUPPORTED, "conv_stem_f32: needs a 3-channel NCDHW input (W and strides multiples of 4 floats), kW == 7, "
+        return fail(PTX_ERR_UNSUPPORTED, "conv_stem_f32: needs a 3-channel NCDHW input (row pitch and strides multiples of 4 floats), kW == 7, "
                     "stride_w <= 2, symmetric or SAME padding, only the ReLU epilogue, and an input patch of at most %d floats", kF32PatchMax);
     if (d->ldy < d->Co || d->ldy % 4) return fail(PTX_ERR_INVALID, "conv_stem_f32: bad output stride");
     StemF32Geom g;
@@ -422,6 +424,7 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     a.ncol = (d->Co + 3) / 4 * 4;
     a.kT = d->kT; a.kH = d->kH; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.pT = d->pT; a.pH = d->pH;
     a.sn = (int)stride_n; a.sc = (int)stride_c; a.st = (int)stride_t;
+    a.pitch = d->ldx > 0 ? d->ldx : d->Wi;
     a.PR = g.PR; a.PC = g.PC; a.plane = g.PR * g.PC; a.shift = g.shift; a.wbase = g.wbase;
     a.tiles_per_frame = g.tiles_per_frame;
     a.n_tiles = d->N * d->To * g.tiles_per_frame;

@@ -35,6 +35,7 @@ struct NlArgs {
     int ld_t, ld_p, ld_g, ld_y;
     long long bs_t, bs_p, bs_g, bs_y;
     int q_tiles, scale_only;
+    int relu;               // PTX_NL_RELU: P = relu(S) / Nk (the 'concatenation' affinity, nonlocalnet.py:213-243)
     unsigned p_bytes, g_bytes, t_bytes;
 };
 
@@ -74,9 +75,14 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, half4
     lo = to_half4(a - (float)hi[0], b - (float)hi[1], c - (float)hi[2], d - (float)hi[3]);
 }
 
-template <int D, int DV, bool SOFTMAX, int MODE = 0>
+// TG ("theta from global", D > 512: the 'gaussian' mode at the reference's widths, theta = x with C = 1024 channels,
+// nonlocalnet.py:168-190): a wave's 16 theta rows no longer fit its registers (D / 4 VGPRs), so the B fragments of
+// S^T = phi . theta^T are fetched with 16-byte buffer loads inside the d loop (L2-resident: 64 queries x 4 KiB per
+// workgroup) instead of living in registers.  Same arithmetic and summation order as the register variant.
+template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false>
 __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     constexpr bool F16 = MODE == 1, X3 = MODE == 2;
+    static_assert(!TG || MODE == 0, "theta-from-global is an fp32 variant");
     constexpr int TK = 16;                   // keys per tile
     constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
     constexpr int CB = DV / 64;              // 64-channel output super-blocks (one ds_read_b128 + 4 MFMAs per key group)
@@ -105,13 +111,16 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         const_cast<float*>(p.g + (size_t)b * p.bs_g), 0, p.g_bytes, 0x00020000);
 
     // ---- theta rows of this wave's 16 queries -> registers (the B operand of S^T = phi . theta^T) ----
-    f32x4 qf[QJ];
-#pragma unroll
-    for (int j = 0; j < QJ; ++j) {
+    auto load_theta = [&](int j) -> f32x4 {
         const int col = 16 * j + 4 * gq;
         const unsigned off = ((unsigned)q * (unsigned)p.ld_t + (unsigned)col) * 4u;
-        qf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                              rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
+    };
+    f32x4 qf[TG ? 1 : QJ];
+    if constexpr (!TG) {
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) qf[j] = load_theta(j);
     }
     half4_t qh[QJ], ql[X3 ? QJ : 1];
     if constexpr (F16) {
@@ -196,10 +205,11 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
                 else       { s0 = mfma16h(kh, ql[j], s0); s0 = mfma16h(kl, qh[j], s0); s0 = mfma16h(kh, qh[j], s0); }
                 continue;
             }
+            const f32x4 qv = TG ? load_theta(j) : qf[TG ? 0 : j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (j & 1) s1 = mfma16(kf[e], qf[j][e], s1);
-                else       s0 = mfma16(kf[e], qf[j][e], s0);
+                if (j & 1) s1 = mfma16(kf[e], qv[e], s1);
+                else       s0 = mfma16(kf[e], qv[e], s0);
             }
         }
         f32x4 s = s0 + s1;                    // s[r] = S[q = n][key = 16t + 4*gq + r]
@@ -233,7 +243,10 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
 #pragma unroll
             // keys >= Nk read as zero rows: no mask needed.  Split operands: the 1 / Nk factor moves to the epilogue -- P = S / Nk
             // would sit around 1e-2, where the lo half of a split goes subnormal and the product keeps ~17 bits instead of 22
-            for (int r = 0; r < 4; ++r) pr[r] = X3 ? s[r] : s[r] * inv_nk;
+            for (int r = 0; r < 4; ++r) {
+                const float v = p.relu ? fmaxf(s[r], 0.f) : s[r];
+                pr[r] = X3 ? v : v * inv_nk;
+            }
         }
 
         // ---- O += P . g_tile ----
@@ -253,8 +266,12 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
             continue;
         }
         if constexpr (X3) {
+            // softmax weights are <= 1 and mostly ~1 / Nk: unscaled, their lo half (~2^-11 P) is a SUBNORMAL half for
+            // P < 0.125 and the P . g products keep 13-14 bits.  Split 2^12 P instead (hi <= 4096, lo normal down to
+            // P ~ 3e-5); the factor is a power of two and leaves with 1 / l in the epilogue.
+            constexpr float kPS = SOFTMAX ? 4096.f : 1.f;
             half4_t ph, pl;
-            split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
+            split4(pr[0] * kPS, pr[1] * kPS, pr[2] * kPS, pr[3] * kPS, ph, pl);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 f32x4 vf[4];
@@ -288,6 +305,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         l_run += __shfl_xor(l_run, 16, 64);
         l_run += __shfl_xor(l_run, 32, 64);
         inv = 1.0f / l_run;
+        if constexpr (X3) inv *= 1.0f / 4096.0f;      // the 2^12 carried by the split softmax weights
     }
     float* yb = p.y + (size_t)b * p.bs_y;
 #pragma unroll
@@ -305,7 +323,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     }
 }
 
-template <int D, int DV, bool SOFTMAX, int MODE = 0>
+template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false>
 static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 16 * (D + DV) * sizeof(float);
     const dim3 grid((unsigned)(a.q_tiles * a.batch), (unsigned)cdiv(a.dv, DV));
@@ -313,17 +331,21 @@ static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, MODE>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, MODE, TG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, MODE>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, MODE, TG>), grid, dim3(256), lds, st, a);
     return hip_check(hipGetLastError(), "nonlocal attention launch");
 }
 
 template <int D, int DV>
 static int launch_nl(const NlArgs& a, hipStream_t st) {
     return a.scale_only ? launch_nl_mode<D, DV, false>(a, st) : launch_nl_mode<D, DV, true>(a, st);
+}
+template <int D, int DV>
+static int launch_nl_tg(const NlArgs& a, hipStream_t st) {
+    return a.scale_only ? launch_nl_mode<D, DV, false, 0, true>(a, st) : launch_nl_mode<D, DV, true, 0, true>(a, st);
 }
 template <int D, int DV>
 static int launch_nl_x3(const NlArgs& a, hipStream_t st) {
@@ -336,7 +358,7 @@ using namespace ptx;
 
 extern "C" int ptx_nonlocal_supported(const ptx_nonlocal_desc* d) {
     if (!d) return 0;
-    return d->batch > 0 && d->Nq > 0 && d->Nk > 0 && d->d > 0 && d->dv > 0 && d->d % 4 == 0 && d->dv % 4 == 0 && d->d <= 512 &&
+    return d->batch > 0 && d->Nq > 0 && d->Nk > 0 && d->d > 0 && d->dv > 0 && d->d % 4 == 0 && d->dv % 4 == 0 && d->d <= 1024 &&
            d->batch * (int64_t)((d->Nq + 63) / 64) <= 0x7fffffffLL;
 }
 
@@ -344,13 +366,14 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
                                 ptx_stream_t stream) {
     if (!d || !theta || !phi || !g || !y) return fail(PTX_ERR_INVALID, "nonlocal: null pointer");
     if (!ptx_nonlocal_supported(d))
-        return fail(PTX_ERR_UNSUPPORTED, "nonlocal: need d, dv multiples of 4 and d <= 512 (d=%d dv=%d); use the "
+        return fail(PTX_ERR_UNSUPPORTED, "nonlocal: need d, dv multiples of 4 and d <= 1024 (d=%d dv=%d); use the "
                     "ptx_bgemm_nt / ptx_softmax_rows path", d->d, d->dv);
     if (d->ld_theta < d->d || d->ld_phi < d->d || d->ld_g < d->dv || d->ld_y < d->dv || d->ld_theta % 4 || d->ld_phi % 4 ||
         d->ld_g % 4 || d->ld_y % 4 || d->bs_theta % 4 || d->bs_phi % 4 || d->bs_g % 4 || d->bs_y % 4)
         return fail(PTX_ERR_INVALID, "nonlocal: row / batch strides must be multiples of 4 floats and cover the extents");
     if (((uintptr_t)theta | (uintptr_t)phi | (uintptr_t)g | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "nonlocal: misaligned pointer");
-    if ((d->mode & ~(PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_X3)) || ((d->mode & PTX_NL_F16) && (d->mode & PTX_NL_X3)))
+    if ((d->mode & ~(PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_X3 | PTX_NL_RELU)) || ((d->mode & PTX_NL_F16) && (d->mode & PTX_NL_X3)) ||
+        ((d->mode & PTX_NL_RELU) && !(d->mode & PTX_NL_SCALE)))
         return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
     const uint64_t tb = (uint64_t)d->Nq * d->ld_theta * 4ull, pb = (uint64_t)d->Nk * d->ld_phi * 4ull, gb = (uint64_t)d->Nk * d->ld_g * 4ull;
     if (tb >= 0x80000000ull || pb >= 0x80000000ull || gb >= 0x80000000ull)
@@ -362,6 +385,7 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     a.bs_t = d->bs_theta; a.bs_p = d->bs_phi; a.bs_g = d->bs_g; a.bs_y = d->bs_y;
     a.q_tiles = cdiv(d->Nq, 64);
     a.scale_only = (d->mode & PTX_NL_SCALE) != 0;
+    a.relu = (d->mode & PTX_NL_RELU) != 0;
     a.t_bytes = (unsigned)tb; a.p_bytes = (unsigned)pb; a.g_bytes = (unsigned)gb;
     hipStream_t st = (hipStream_t)stream;
     if (d->mode & PTX_NL_F16) {          // fp16-operand MFMAs: the generator's self-attention shape family only
@@ -369,6 +393,9 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
             return fail(PTX_ERR_UNSUPPORTED, "nonlocal: PTX_NL_F16 covers softmax attention with d <= 64 (d=%d)", d->d);
         return d->dv <= 64 ? launch_nl_mode<64, 64, true, 1>(a, st) : launch_nl_mode<64, 256, true, 1>(a, st);
     }
+    // d > 512 ('gaussian' mode at C = 1024): theta fragments come from global memory; fp32 MFMAs whatever the plan's
+    // precision (the split-operand mode is fp32-accurate by contract, so the exact kernel is a valid stand-in)
+    if (d->d > 512) return launch_nl_tg<1024, 128>(a, st);
     if (d->mode & PTX_NL_X3) {           // split operands: the same tile family as the fp32 kernel
         if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl_x3<32, 128>(a, st);
         if (d->d <= 64) return d->dv <= 64 ? launch_nl_x3<64, 64>(a, st) : launch_nl_x3<64, 256>(a, st);

@@ -512,6 +512,24 @@ extern "C" int ptx_fold_kw_frames_u8(const uint8_t* frames, float* y, int32_t N,
     return hip_check(hipGetLastError(), "fold_kw_frames_u8 launch");
 }
 
+// y[r][0..W) = x[r][0..W), y[r][W..ld) = 0: gives rows whose length is not a multiple of 4 floats a 16-byte pitch
+__global__ void __launch_bounds__(256) pad_rows_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total,
+                                                       int W, int ld) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t r = e / (size_t)ld;
+        const int c = (int)(e - r * (size_t)ld);
+        y[e] = c < W ? x[r * (size_t)W + c] : 0.f;
+    }
+}
+
+extern "C" int ptx_pad_rows(const float* x, float* y, int64_t rows, int32_t W, int32_t ld, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "pad_rows: null pointer");
+    if (rows <= 0 || W <= 0 || ld < W) return fail(PTX_ERR_INVALID, "pad_rows: bad extents (rows=%lld W=%d ld=%d)", (long long)rows, W, ld);
+    const size_t total = (size_t)rows * ld;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, W, ld);
+    return hip_check(hipGetLastError(), "pad_rows launch");
+}
+
 extern "C" int ptx_checksum_f32(const int64_t* table, int32_t n, uint64_t* out, ptx_stream_t stream) {
     if (!table || !out || n <= 0) return fail(PTX_ERR_INVALID, "checksum: null pointer / empty table");
     if (n > 65535) return fail(PTX_ERR_UNSUPPORTED, "checksum: more than 65535 tensors");

@@ -7,7 +7,8 @@ nn.Module calls) and on CPU tensors (BASELINE.json config 1 is literally the CPU
 module is that path: the zoo's own nn.Conv / nn.BatchNorm / nn.Linear children are CALLED, in the reference's op
 order, so autograd, BN running-statistic updates and CPU execution behave as upstream.
 
-Selection rule (`wanted`): training mode, or an input that requires grad, or CPU input with CPU parameters.
+Selection rule (`wanted`): training mode, or an input that requires grad, or CPU input with CPU parameters, or --
+opt-in, `model.engine().autograd = True` -- grad mode on with trainable parameters (eval-mode fine-tuning).
 Never in eval mode on ROCm tensors: that is always the HIP path, which raises when libptx_amd.so is missing or a
 launch fails -- this module is not a fallback for it, and nothing under oracle/ is used here.
 `PTX_EAGER=0` turns it off (those calls then raise PtxError as in round 1).
@@ -38,6 +39,15 @@ def wanted(model, x):
         return False
     if model.training or (torch.is_grad_enabled() and x.requires_grad):
         return True
+    # Opt-in: eval-mode fine-tuning (frozen BN statistics, trainable trunk).  The reference returns a differentiable
+    # output whenever grad mode is on and a parameter requires grad; the HIP engine is forward-only, so by default an
+    # eval-mode call on ROCm tensors returns logits WITHOUT a grad_fn (every nn.Parameter requires grad by default --
+    # routing on that alone would send plain inference to torch.nn).  `model.engine().autograd = True` (or
+    # PTX_AUTOGRAD=1) asks for the reference behaviour: such calls then run the torch.nn children.
+    eng = getattr(model, "_engine", None)
+    if eng is not None and getattr(eng, "autograd", False) and torch.is_grad_enabled():
+        if any(p.requires_grad for p in model.parameters()):
+            return True
     if not x.is_cuda:
         from .engine import _first_weight
         return not _first_weight(model).is_cuda        # CPU model + CPU input; a device mismatch still raises
@@ -70,10 +80,7 @@ def nonlocal_block(nl, x):
     b, c = x.shape[:2]
     sub = bool(getattr(nl, "sub_sample", False))
 
-    def run(m, inp):                      # Sequential(conv, MaxPool3d(2)) when sub-sampling
-        return m(inp)
-
-    g_x = run(nl.g, x)
+    g_x = nl.g(x)                         # Sequential(conv, MaxPool3d(2)) when sub-sampling
     ci = g_x.shape[1]
     g_x = g_x.reshape(b, ci, -1).permute(0, 2, 1)
     if mode == "gaussian":
@@ -82,7 +89,7 @@ def nonlocal_block(nl, x):
         f = F.softmax(torch.matmul(theta_x, phi_x), dim=-1)
     else:
         theta = nl.theta(x)
-        phi = run(nl.phi, x)
+        phi = nl.phi(x)
         if mode == "concatenation":
             th = theta.reshape(b, ci, -1, 1)
             ph = phi.reshape(b, ci, 1, -1)
@@ -160,8 +167,3 @@ def relation(rel, x):
     _count()
     out = rel.relate(x.contiguous().view(-1, rel.num_inputs * rel.in_features))
     return out.view(x.size(0), -1, rel.out_features)
-
-
-def unsupported(model):
-    raise PtxError("%s: no torch.nn (training / CPU) path is provided for this family; the HIP engine needs "
-                   "model.eval() and ROCm tensors" % type(model).__name__)

@@ -33,6 +33,33 @@ _tuned_lock = threading.Lock()
 _cfg_index = None                # configuration name -> index into this build's kConfigs table
 
 
+# Structure epoch: bumped whenever ANY nn.Module in the process registers a parameter, buffer or sub-module (torch's
+# global registration hooks fire from `register_parameter`, i.e. also from `blk.conv2.weight = nn.Parameter(w)`,
+# `model.bn1 = FrozenBN(...)`, weight_norm / parametrize re-parametrisation).  An Engine's cached flat tensor list
+# (`_owner_tensors`) is only valid for the epoch it was built in, so a replaced Parameter / module is noticed by the
+# next forward's (data_ptr, _version) comparison instead of being served from stale packed filters.
+_struct_epoch = [0]
+
+
+def _bump_struct_epoch(*_a, **_k):
+    _struct_epoch[0] += 1
+    return None
+
+
+def _install_struct_hooks():
+    mod = torch.nn.modules.module
+    for name in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+                 "register_module_module_registration_hook"):
+        reg = getattr(mod, name, None)
+        if reg is None:
+            return False
+        reg(_bump_struct_epoch)
+    return True
+
+
+_STRUCT_HOOKS = _install_struct_hooks()
+
+
 def _config_index(name):
     """Index of a tile configuration by NAME in the loaded library (None when this build has no such tile).
     The tuned table stores names, so inserting / reordering kConfigs entries cannot remap it silently."""
@@ -341,16 +368,23 @@ class ConvStep:
     def __call__(self, st):
         try:
             self._launch(st)
-        except PtxError:
+        except PtxError as e:
             # a tile taken from the tuned table that this build / this problem cannot run (a stale or hand-edited
-            # entry): fall back to the library's own default once, loudly, instead of failing the forward
-            if not getattr(self, "from_table", False):
+            # entry): fall back to the library's own default once, loudly, instead of failing the forward.  Only a
+            # REFUSAL qualifies (PTX_ERR_INVALID / PTX_ERR_UNSUPPORTED / PTX_ERR_WORKSPACE: nothing was launched); HIP
+            # launch or asynchronous device errors are genuine faults and propagate.
+            if not getattr(self, "from_table", False) or getattr(e, "status", None) not in (1, 2, 4):
                 raise
             sk = C.c_int(1)
             self.cfg = self.plan.lib.ptx_conv3d_pick_config(C.byref(self.d), C.byref(sk))
             self.split, self.from_table = sk.value, False
+            p = self.plan
+            need = int(p.lib.ptx_conv3d_workspace_bytes(C.byref(self.d), self.split))
+            if need > p.ws_bytes:           # the workspace was sized for the tuned split: grow it for the default one
+                p.ws = torch.zeros(need // 4, device=p.dev, dtype=torch.float32)
+                p.ws_bytes, p.ws_ptr = need, _ptr(p.ws)
             import warnings
-            warnings.warn("pretorched-x_amd: tuned tile for %s rejected by the library; using the default tile" % self.label)
+            warnings.warn("pretorched-x_amd: tuned tile for %s rejected by the library (%s); using the default tile" % (self.label, e))
             self._launch(st)
 
     def _launch(self, st):
@@ -379,13 +413,26 @@ class StemStep:
 class StemF32Step:
     """One ptx_conv_stem_f32_fwd launch: the RGB stem on the fp32 matrix cores, read straight from the caller's NCDHW
     tensor (bound per run: plan.in_ptr) -- no fold, no layout pass."""
-    __slots__ = ("d", "plan", "strides", "w", "b", "y", "label", "macs", "hbm_bytes")
+    __slots__ = ("d", "plan", "strides", "w", "b", "y", "label", "macs", "hbm_bytes", "src")
     kernel = "conv_stem_f32"
+
+    def issued_flop(self):
+        """FLOP of the MFMAs one launch ISSUES (what SQ_INSTS_MFMA x 4096 counts): `macs` prices padding taps as work
+        (SURVEY.md 8d), the kernel skips the temporal taps outside the clip; per workgroup and (kt, kh) step 4 waves x 44
+        v_mfma_f32_32x32x2_f32 (K = 21 padded to 22, 64 channels per tile)."""
+        d = self.d
+        tiles = -(-(d.Ho * d.Wo) // 256) * -(-_r4(d.Co) // 64)
+        steps = 0
+        for to in range(d.To):
+            t0 = to * d.sT - d.pT
+            steps += max(0, min(d.kT - 1, d.Ti - 1 - t0) - max(0, -t0) + 1) * d.kH
+        return float(d.N * tiles * steps * 4 * 44 * 4096)
 
     def __call__(self, st):
         sn, sc, stt = self.strides
-        check(_lib.lib().ptx_conv_stem_f32_fwd(C.byref(self.d), self.plan.in_ptr, sn, sc, stt, self.w, self.b, self.y, st),
-              self.label)
+        # src: a plan-owned fp32 NCDHW buffer (normalised uint8 frames / pitch-padded rows) or None = the caller's tensor
+        x = self.src if self.src is not None else self.plan.in_ptr
+        check(_lib.lib().ptx_conv_stem_f32_fwd(C.byref(self.d), x, sn, sc, stt, self.w, self.b, self.y, st), self.label)
 
 
 class Plan:
@@ -564,6 +611,8 @@ class Plan:
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         key = json.dumps(d.key())
         tuned = tuned_lookup(key, _flags_kind(flags))
+        if tuned is not None and not self.lib.ptx_conv3d_config_supported(C.byref(d), tuned[0]):
+            tuned = None                 # a stale table entry is dropped here, at plan-build time
         st.from_table = tuned is not None
         if tuned is not None:
             st.cfg, st.split = tuned
@@ -614,8 +663,10 @@ class Plan:
         """Split-operand stems skip the kW fold: the input becomes [N,T,H,W,4] (16-byte positions) and
         ptx_conv_stem_x3_fwd serves every (kh, kw) tap of a temporal tap from one staged input patch.  Returns None when
         the kernel does not cover the geometry (the folded implicit-GEMM path then runs)."""
-        if os.environ.get("PTX_STEM_DIRECT", "1") == "0" or raw.norm is not None:
+        if os.environ.get("PTX_STEM_DIRECT", "1") == "0":
             return None
+        if raw.norm is not None and os.environ.get("PTX_STEM_DIRECT_U8", "1") == "0":
+            return None                  # uint8 frames on the round-1 path: normalise + kW fold in one pass
         if not self.x3:
             return self.stem_direct_f32(raw, conv, bn, relu, label)
         if raw.t_step != 1:
@@ -639,9 +690,10 @@ class Plan:
         # one 16-byte position per pixel, already split into (hi4 | lo4) halfs: the NCDHW edge does the split once
         x4 = self.act(raw.N, raw.T, raw.H, raw.W, 4)
         lib, x4p, Nn, Cc, Ss = self.lib, _ptr(x4.t), raw.N, raw.C, raw.T * raw.H * raw.W
+        src = self.stem_source(raw, pitch=raw.W)        # uint8 frames: normalised to fp32 NCDHW first (one 1 B -> 4 B pass)
 
         def to_split4(st, self=self):
-            check(lib.ptx_ncdhw_to_split4(self.in_ptr, x4p, Nn, Cc, Ss, st), "ptx_ncdhw_to_split4")
+            check(lib.ptx_ncdhw_to_split4(src if src is not None else self.in_ptr, x4p, Nn, Cc, Ss, st), "ptx_ncdhw_to_split4")
         self.steps.append(_tag(to_split4, "ncdhw_to_split4", 4 * Nn * Cc * Ss + 16 * Nn * Ss))
         pk = self.pack(conv, bn, fold_kw=True, x3=True, stem4=True)
         y = self.act(raw.N, To, Ho, Wo, conv.out_channels)
@@ -666,17 +718,19 @@ class Plan:
             (To, Ho, Wo), (pT, pH, pW) = _same_geometry((raw.T, raw.H, raw.W), (kT, kH, kW), (sT, sH, sW))
         else:
             To, Ho, Wo = (raw.T + 2 * pT - kT) // sT + 1, (raw.H + 2 * pH - kH) // sH + 1, (raw.W + 2 * pW - kW) // sW + 1
+        pitch = _r4(raw.W)               # rows of a width that is not a multiple of 4 get a zero-padded 16-byte pitch
         d = ConvDesc()
-        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = raw.N, raw.T, raw.H, raw.W, 3, 0
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = raw.N, raw.T, raw.H, raw.W, 3, (pitch if pitch != raw.W else 0)
         d.To, d.Ho, d.Wo, d.Co = To, Ho, Wo, conv.out_channels
         d.ldy = _r4(conv.out_channels)
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
         d.Co_pad = _r128(conv.out_channels)
         d.flags = PTX_EPI_RELU if relu else 0
-        plane = raw.H * raw.W
+        plane = raw.H * pitch
         strides = (raw.C * raw.T_full * plane, raw.T_full * plane, raw.t_step * plane)
         if min(To, Ho, Wo) < 1 or not self.lib.ptx_conv_stem_f32_supported(C.byref(d), *strides):
             return None
+        src = self.stem_source(raw, pitch)
         pk = self.pack(conv, bn, fold_kw=True, x3=False)          # [tap][Co_pad][Kc], k = kw * 3 + c, BN folded
         d.Kc = pk.Kc
         w2 = torch.empty(self.lib.ptx_stem_f32_weight_elems(C.byref(d)), device=self.dev, dtype=torch.float32)
@@ -689,11 +743,49 @@ class Plan:
         y = self.act(raw.N, To, Ho, Wo, conv.out_channels)
         st = StemF32Step()
         st.d, st.plan, st.strides, st.w, st.b, st.y, st.label = d, self, strides, w2p, _ptr(pk.b), _ptr(y.t), label
+        st.src = src
         st.macs = raw.N * To * Ho * Wo * conv.out_channels * raw.C * kT * kH * kW
         st.hbm_bytes = 0
         self.steps.append(st)
         self.stem_steps = getattr(self, "stem_steps", 0) + 1
         return y
+
+    def stem_source(self, raw, pitch):
+        """The fp32 NCDHW tensor a direct stem kernel reads, as a device pointer -- or None when that is the caller's own
+        tensor (fp32 clips whose rows already have a 16-byte pitch: bound per run, plan.in_ptr).  Otherwise the plan owns
+        it and fills it first: decoded uint8 frames [N,T,H,W,C] are normalised by ptx_frames_u8_to_ncdhw (TransformImage's
+        tensor half, transforms/utils.py:72-75; bit-identical to the CPU ops) -- 1 B in, 4 B out per sample, ~5 % of the
+        bytes the kW fold moved -- and rows whose width is not a multiple of 4 are copied to a zero-padded pitch
+        (ptx_pad_rows).  Built once per plan: both SlowFast pathways read the same buffer through their own frame stride."""
+        key = (raw.norm is not None, pitch)
+        cache = self.__dict__.setdefault("_stem_src", {})
+        if key in cache:
+            return cache[key]
+        lib = self.lib
+        N, Cc, Tf, H, W = raw.N, raw.C, raw.T_full, raw.H, raw.W
+        src = None
+        if raw.norm is not None:
+            norm = raw.norm
+            buf = torch.empty((N, Cc, Tf, H, W), device=self.dev, dtype=torch.float32)
+            self.keepalive += [norm, buf]
+            bp = _ptr(buf)
+
+            def to_f32(st, self=self):
+                check(lib.ptx_frames_u8_to_ncdhw(self.in_ptr, bp, N, Tf, H, W, Cc, C.byref(norm), st), "ptx_frames_u8_to_ncdhw")
+            self.steps.append(_tag(to_f32, "frames_u8_to_ncdhw", 5 * N * Cc * Tf * H * W))
+            src = bp
+        if pitch != W:
+            rows = N * Cc * Tf * H
+            buf2 = torch.empty((rows, pitch), device=self.dev, dtype=torch.float32)
+            self.keepalive.append(buf2)
+            b2p, prev = _ptr(buf2), src
+
+            def pad(st, self=self):
+                check(lib.ptx_pad_rows(prev if prev is not None else self.in_ptr, b2p, rows, W, pitch, st), "ptx_pad_rows")
+            self.steps.append(_tag(pad, "pad_rows", 4 * rows * (W + pitch)))
+            src = b2p
+        cache[key] = src
+        return src
 
     def fold_input(self, raw, conv, same_pad=None):
         """raw: RawInput (NCDHW user tensor or uint8 frames).  Emits the fold kernel."""
@@ -761,17 +853,21 @@ class Plan:
         self.steps.append(_tag(step, "maxpool3d", esz * (x.N * x.S * x.C + y.N * To * Ho * Wo * x.C)))
         return y
 
-    def attention(self, th, ph, g, y, scale_only=False, f16=False):
-        """y = softmax(th . ph^T) . g  (or (th . ph^T / Nk) . g) per sample, as one ptx_nonlocal_fwd launch.
-        th [N, Sq, d], ph [N, Sk, d], g [N, Sk, dv], y [N, Sq, dv]: channels-last activations (possibly channel
-        slices).  Returns False -- nothing emitted -- when the fused kernel does not cover the shape (d > 512)
-        or PTX_NL_FUSED=0 asks for the unfused bgemm / softmax / bgemm chain."""
-        from ._lib import NonlocalDesc, PTX_NL_F16, PTX_NL_SCALE, PTX_NL_SOFTMAX, PTX_NL_X3
+    def attention(self, th, ph, g, y, scale_only=False, f16=False, relu=False):
+        """y = softmax(th . ph^T) . g  (or (th . ph^T / Nk) . g, or (relu(th . ph^T) / Nk) . g) per sample, as one
+        ptx_nonlocal_fwd launch.  th [N, Sq, d], ph [N, Sk, d], g [N, Sk, dv], y [N, Sq, dv]: channels-last activations
+        (possibly channel slices).  Returns False -- nothing emitted -- when the fused kernel does not cover the shape
+        (d > 1024) or PTX_NL_FUSED=0 asks for the unfused bgemm / softmax / bgemm chain."""
+        from ._lib import NonlocalDesc, PTX_NL_F16, PTX_NL_RELU, PTX_NL_SCALE, PTX_NL_SOFTMAX, PTX_NL_X3
         d = NonlocalDesc()
         d.batch, d.Nq, d.Nk, d.d, d.dv = th.N, th.S, ph.S, th.C, g.C
         d.ld_theta, d.ld_phi, d.ld_g, d.ld_y = th.ld, ph.ld, g.ld, y.ld
         d.bs_theta, d.bs_phi, d.bs_g, d.bs_y = th.S * th.ld, ph.S * ph.ld, g.S * g.ld, y.S * y.ld
         d.mode = PTX_NL_SCALE if scale_only else PTX_NL_SOFTMAX
+        if relu:
+            if not scale_only:
+                raise PtxError("attention: relu modifies the scale-only affinity")
+            d.mode |= PTX_NL_RELU
         if f16 and not scale_only and th.C <= 64:      # fp16-operand MFMAs (the generator's fp16 plan)
             d.mode |= PTX_NL_F16
         elif self.x3 and os.environ.get("PTX_NL_X3", "1") != "0":      # split operands, like the plan's convs
@@ -786,6 +882,48 @@ class Plan:
         self.steps.append(_tag(step, "nonlocal_attention", 4 * th.N * (th.S * th.C + ph.S * ph.C + g.S * g.C + th.S * g.C),
                                macs=th.N * th.S * ph.S * (th.C + g.C)))
         self.attn_steps = getattr(self, "attn_steps", 0) + 1
+        return True
+
+    def concat_attention(self, th, ph, g, y, nl, label):
+        """The 'concatenation' affinity (nonlocalnet.py:213-243) on the fused attention kernel.  The 1x1 conv over
+        cat([theta_i, phi_j]) is a_i + b_j with a = theta . w[:ci], b = phi . w[ci:] -- the dot product of the 2-vectors
+        (a_i, 1) and (1, b_j) -- so f = relu(a_i + b_j) / N is ptx_nonlocal_fwd's PTX_NL_SCALE | PTX_NL_RELU mode on
+        4-float rows (two live columns), and f . g runs in the same launch: the [N, Sq, Sk] affinity never reaches
+        HBM.  Two small GEMMs produce the rows: Linear(ci -> 4) with weight rows (w_theta, 0, 0, 0) / bias (0, 1, 0, 0)
+        and weight rows (0, w_phi, 0, 0) / bias (1, 0, 0, 0).  Returns False (nothing emitted) under PTX_NL_FUSED=0."""
+        if os.environ.get("PTX_NL_FUSED", "1") == "0":
+            return False
+        ci = th.C
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        wa, wb = torch.zeros((4, ci), **f32), torch.zeros((4, ci), **f32)
+        ba, bb = torch.zeros(4, **f32), torch.zeros(4, **f32)
+        self.keepalive += [wa, wb, ba, bb]
+        proj_ref = self.ref(nl.concat_project[0])
+
+        def refresh():
+            proj = self.get(proj_ref)
+            w = proj.weight.detach().reshape(-1)
+            wa.zero_(); wb.zero_(); ba.zero_(); bb.zero_()
+            wa[0].copy_(w[:ci])
+            wb[1].copy_(w[ci:])
+            ba[1], bb[0] = 1.0, 1.0
+            if proj.bias is not None:
+                ba[0] = proj.bias.detach().reshape(())
+        if torch.device(self.dev).type != "meta":
+            self.refreshers.append(refresh)
+        ta = self.act(th.N, th.T, th.H, th.W, 4)
+        pb = self.act(ph.N, ph.T, ph.H, ph.W, 4)
+        lib = self.lib
+        thp, php, tap, pbp = _ptr(th.t), _ptr(ph.t), _ptr(ta.t), _ptr(pb.t)
+        wap, wbp, bap, bbp = _ptr(wa), _ptr(wb), _ptr(ba), _ptr(bb)
+        Mq, Mk, ldt, ldp = th.N * th.S, ph.N * ph.S, th.ld, ph.ld
+
+        def step(st):
+            check(lib.ptx_linear_fwd(thp, wap, bap, tap, Mq, ci, 4, ldt, 4, 0, st), label + ".concat_a")
+            check(lib.ptx_linear_fwd(php, wbp, bbp, pbp, Mk, ci, 4, ldp, 4, 0, st), label + ".concat_b")
+        self.steps.append(_tag(step, "nonlocal_concat_ab", 4 * (Mq + Mk) * (ci + 4), macs=(Mq + Mk) * ci))
+        if not self.attention(ta, pb, g, y, scale_only=True, relu=True):
+            raise PtxError("%s: the fused concatenation attention refused a supported shape" % label)
         return True
 
     def nonlocal_block(self, x, nl, label):
@@ -820,7 +958,12 @@ class Plan:
             g_act = self.maxpool(g_act, *pool)
         N, Sq, Sk, K = x.N, x.S, ph_act.S, th_act.C
         yatt = self.act(x.N, x.T, x.H, x.W, ci)
-        if mode != "concatenation" and self.attention(th_act, ph_act, g_act, yatt, scale_only=(mode == "dot_product")):
+        fused = False
+        if mode == "concatenation":
+            fused = self.concat_attention(th_act, ph_act, g_act, yatt, nl, label)
+        else:
+            fused = self.attention(th_act, ph_act, g_act, yatt, scale_only=(mode == "dot_product"))
+        if fused:
             # theta^T phi -> softmax (or 1/N) -> . g in ONE launch: the [N, Sq, Sk] affinity never reaches HBM
             if getattr(nl, "bn_layer", True):
                 return self.conv(yatt, self.pack(nl.W[0], nl.W[1]), one, zero, res=x, label=label + ".W")
@@ -1118,6 +1261,11 @@ class Engine:
         #           fp32.  Operand magnitudes must stay inside the half range (|v| < 65504).
         # Changing it drops the compiled plans (set it before the first forward, or call invalidate()).
         self._precision = os.environ.get("PTX_PRECISION", "fp32")
+        # Opt-in autograd routing (eager.wanted): with grad mode on and trainable parameters, eval-mode calls run the
+        # zoo's torch.nn children and return a differentiable output, as the reference does (frozen-BN fine-tuning).
+        # Off by default: every nn.Parameter requires grad, so plain inference without torch.no_grad() would leave
+        # the HIP engine.
+        self.autograd = os.environ.get("PTX_AUTOGRAD", "0") == "1"
 
     @property
     def precision(self):
@@ -1181,15 +1329,19 @@ class Engine:
             raise PtxError("input on %s but parameters on %s" % (x.device, p.device))
 
     def _owner_tensors(self, root):
-        """Flat list of the owner's parameters and buffers, cached until the next invalidate(): walking the
-        module tree costs ~0.4 ms per call for ResNet3D-50, reading 480 version counters ~50 us."""
+        """Flat list of the owner's parameters and buffers, cached until the next invalidate() OR the next parameter /
+        buffer / sub-module registration anywhere in the process (`_struct_epoch`: a trunk Parameter or module replaced
+        by assignment gives the list new tensors, whose data_ptr then differs from the packed filters' signature).
+        Walking the module tree costs ~0.4 ms per call for ResNet3D-50, reading 480 version counters ~50 us."""
         cached = self._tensors
-        if cached is None or cached[0] != self._epoch or cached[1] is not root:
+        # without torch's global registration hooks (older torch) the tree is walked on every forward
+        epoch = (self._epoch, _struct_epoch[0]) if _STRUCT_HOOKS else None
+        if cached is None or epoch is None or cached[0] != epoch or cached[1] is not root:
             ts = list(root.parameters()) + list(root.buffers())
             if not ts and _is_replica(root):             # an orphan replica: its broadcast copies
                 ts = [t for m in root.modules() for t in getattr(m, "_former_parameters", {}).values()]
                 ts += list(root.buffers())
-            cached = self._tensors = (self._epoch, root, ts)
+            cached = self._tensors = (epoch, root, ts)
         return cached[2]
 
     def _signature(self, model):

@@ -12,7 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --workload $W --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-x3 ${BENCH_ARGS}"
 NOTUNE="--no-autotune"
 if [ -n "$PROF_CMD" ]; then CMD="$PROF_CMD"; NOTUNE=""; fi      # any other command (a kernel probe script): W / TAG only name the output
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1; echo "trace exit $?"
+# the trace pass runs with the tuned table too (--no-autotune): tuner launches would pollute the per-kernel averages
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD $NOTUNE > $OUT/trace.log 2>&1; echo "trace exit $?"
 i=0
 for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \

@@ -1,9 +1,13 @@
 """profiles/rNN_pmc_traffic.json from a scripts/gpu_prof_pmc.sh summary: mean FETCH_SIZE / WRITE_SIZE (KiB per dispatch)
 per kernel, the table bench.py replays in `roofline.traffic` (with its provenance).
 
-    python scripts/pmc_traffic_json.py gpurun_out/prof_cfg2_fp32/summary.txt profiles/r02_pmc_traffic.json
+    python scripts/pmc_traffic_json.py gpurun_out/prof_cfg2_fp32/summary.txt profiles/r03_pmc_traffic.json [commit] [command]
+
+`_meta` records the commit the profiled library was built from (PTX_COMMIT or argv[3]: the GPU box has no .git) and the
+profiled command, so bench.py's `roofline.traffic_source` can say which build the replayed counters belong to.
 """
 import json
+import os
 import re
 import sys
 
@@ -20,5 +24,7 @@ for line in open(src):
         m = re.match(r"(.{62})\s+(\d+)\s+([0-9.e+-]+)\s+([0-9.e+-]+)", line)
         if m:
             out.setdefault(m.group(1).strip(), {})[sect + "_KiB"] = float(m.group(3))
+out["_meta"] = {"commit": sys.argv[3] if len(sys.argv) > 3 else os.environ.get("PTX_COMMIT"),
+                "command": sys.argv[4] if len(sys.argv) > 4 else None, "source": src}
 json.dump(out, open(dst, "w"), indent=1)
 print(len(out), "kernels ->", dst)

@@ -386,15 +386,32 @@ def test_bench_workload_table(ptx):
     assert bench.CLIPS_PER_GPU == 8 and abs(bench.GFLOP_PER_CLIP - 79.692) < 1e-9 and bench.PEAK_F32_MFMA_TF == 157.3
     from pretorched_x_amd.testing import synth_state_dict
     for w, units in (("cfg1", 1), ("cfg3", 8), ("cfg4", 2), ("cfg5", 64), ("cfg5-fp32", 64)):
-        model, recipe, x, fwd, cpu_fn, unit, label = bench.other_workload(w, 0)
-        assert x.shape[0] == units and unit in ("clips", "images") and w[3] in label.split("config ")[1][:2]
+        model, recipe, make, per_gpu, fwd, cpu_fn, unit, label, sample_idx = bench.other_workload(w, 0)
+        x = make(per_gpu, 99)
+        assert per_gpu == units and x.shape[0] == units and unit in ("clips", "images") and w[3] in label.split("config ")[1][:2]
         shape = tuple(x.shape) if not w.startswith("cfg5") else (4, 128)
         assert (getattr(model, "precision", "fp32") == "fp16") == (w == "cfg5")
         plan = model.engine().dry_plan(model, shape)
         assert len(plan.conv_steps) > 10
         if w == "cfg1":
             sd = synth_state_dict(model.state_dict(), 1234, **recipe)
-            assert tuple(cpu_fn(sd, x).shape) == (1, 1000)
+            assert tuple(cpu_fn(sd, x, [0]).shape) == (1, 1000)
+        if w.startswith("cfg5"):          # Engine.generate splits batch 64 into 32 + 32: the parity sample spans both chunks
+            assert min(sample_idx) < 32 <= max(sample_idx)
+    # weak scaling: per-rank batches (different seeds); strong: BASELINE's global batch cut like DataParallel's scatter
+    mk = lambda n, seed: torch.full((n, 2), float(seed))            # noqa: E731
+    xb, tot = bench.local_batch(mk, 8, "cfg2", "weak", 4, 3)
+    assert tot == 32 and xb.shape[0] == 8 and float(xb[0, 0]) == 102.0
+    mk2 = lambda n, seed: torch.arange(n, dtype=torch.float32).reshape(n, 1) + 1000 * seed     # noqa: E731
+    shards = [bench.local_batch(mk2, 8, "cfg2", "strong", 8, r) for r in range(8)]
+    assert all(t == 8 and x.shape[0] == 1 for x, t in shards)              # the headline batch at 8 GPUs: ONE clip per GPU
+    assert torch.equal(torch.cat([x for x, _ in shards]), mk2(8, 99))
+    x4 = [bench.local_batch(mk2, 2, "cfg4", "strong", 8, r)[0] for r in range(8)]
+    assert [int(x.shape[0]) for x in x4] == [2] * 8 and torch.equal(torch.cat(x4), mk2(16, 99))      # config 4: 16 clips / 8 GPUs
+    ragged = [bench.local_batch(mk2, 8, "cfg3", "strong", 3, r)[0].shape[0] for r in range(3)]
+    assert ragged == [3, 3, 2]
+    with pytest.raises(SystemExit):
+        bench.local_batch(mk2, 64, "cfg5", "strong", 2, 0)
     with pytest.raises(SystemExit):
         bench.other_workload("cfg9", 0)
 
@@ -517,23 +534,41 @@ def test_biggan_release_layout_and_config_validation(ptx):
 
 def test_fp32_stem_plan_wiring_without_gpu(ptx, monkeypatch):
     """Plan.stem_direct_f32 (dry plans): RGB stems with more than 32 output channels run ptx_conv_stem_f32_fwd on the caller's
-    NCDHW tensor; what the kernel refuses keeps the kW-folded implicit-GEMM stem -- a width that is not a multiple of 4,
-    narrow outputs, uint8 frames, PTX_STEM_DIRECT=0 -- and the C ABI's own gate agrees."""
+    NCDHW tensor -- also for widths that are not multiples of 4 (rows copied to a zero-padded 16-byte pitch, ptx_pad_rows)
+    and for decoded uint8 frames (normalised to fp32 NCDHW by ptx_frames_u8_to_ncdhw first); what the kernel refuses keeps
+    the kW-folded implicit-GEMM stem -- narrow outputs, PTX_STEM_DIRECT=0 -- and the C ABI's own gate agrees."""
     from pretorched_x_amd import engine
     L, lib = ptx._lib, ptx._lib.lib()
 
     def stem_kinds(plan):
         return [type(s).__name__ for s in plan.steps if isinstance(s, (engine.StemF32Step, engine.StemStep))], \
-               [getattr(s, "label", "") for s in plan.steps if getattr(s, "label", "") == "fold_kw"]
+               [getattr(s, "label", "") for s in plan.steps if getattr(s, "label", "") in ("fold_kw", "pad_rows", "frames_u8_to_ncdhw")]
 
     m = ptx.resnet3d18(num_classes=10, pretrained=None)
-    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 64)))
-    assert direct == ["StemF32Step"] and not folds
-    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 66)))          # W % 4 != 0: rows are not 16-byte pieces
-    assert not direct and folds == ["fold_kw"]
+    plan = m.engine().dry_plan(m, (2, 3, 8, 64, 64))
+    direct, edge = stem_kinds(plan)
+    assert direct == ["StemF32Step"] and not edge
+    assert [s for s in plan.steps if isinstance(s, engine.StemF32Step)][0].src is None      # the caller's tensor, bound per run
+    plan = m.engine().dry_plan(m, (2, 3, 8, 64, 66))          # W % 4 != 0: padded pitch 68, then the direct stem
+    direct, edge = stem_kinds(plan)
+    assert direct == ["StemF32Step"] and edge == ["pad_rows"]
+    st = [s for s in plan.steps if isinstance(s, engine.StemF32Step)][0]
+    assert st.d.ldx == 68 and st.d.Wi == 66 and st.src is not None and st.strides == (3 * 8 * 64 * 68, 8 * 64 * 68, 64 * 68)
+    # decoded uint8 frames (Engine.forward_frames): one normalising pass, then the same direct stem -- no kW fold
+    norm = L.NormDesc.make([0.4, 0.4, 0.4], [0.2, 0.2, 0.2], "RGB", [0, 1])
+    planu = engine.Plan(m.engine(), m, (2, 3, 8, 64, 64), torch.device("meta"), norm)
+    direct, edge = stem_kinds(planu)
+    assert direct == ["StemF32Step"] and edge == ["frames_u8_to_ncdhw"]
+    monkeypatch.setenv("PTX_STEM_DIRECT_U8", "0")             # the round-1 path stays selectable: normalise + fold in one pass
+    direct, edge = stem_kinds(engine.Plan(m.engine(), m, (2, 3, 8, 64, 64), torch.device("meta"), norm))
+    assert not direct and edge == ["fold_kw"]
+    monkeypatch.delenv("PTX_STEM_DIRECT_U8")
+    # the stem's own count of issued MFMA work: 11 MFMAs per (kt, kh) tap, temporal taps outside the clip skipped
+    st = [s for s in m.engine().dry_plan(m, (8, 3, 16, 224, 224)).steps if isinstance(s, engine.StemF32Step)][0]
+    assert abs(st.issued_flop() / 1e9 - 197.8) < 0.1 and abs(2e-9 * st.macs - 211.48) < 0.01
     monkeypatch.setenv("PTX_STEM_DIRECT", "0")
-    direct, folds = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 64)))
-    assert not direct and folds == ["fold_kw"]
+    direct, edge = stem_kinds(m.engine().dry_plan(m, (2, 3, 8, 64, 64)))
+    assert not direct and edge == ["fold_kw"]
     monkeypatch.delenv("PTX_STEM_DIRECT")
     # the (2+1)D spatial stem (45 mid channels) and the 2-D ResNet stem go direct; the step carries the NCDHW strides
     r = ptx.r2plus1d18(num_classes=10)
@@ -554,6 +589,13 @@ def test_fp32_stem_plan_wiring_without_gpu(ptx, monkeypatch):
     assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 1
     assert lib.ptx_stem_f32_weight_elems(C.byref(d)) == 49 * 2 * 11 * 2 * 64
     assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_ + 2) == 0        # frame stride not a multiple of 4 floats
+    d.Wi, d.Wo, d.ldx = 62, 31, 64                                                  # odd width behind a 64-float row pitch
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 1
+    d.ldx = 0
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), 3 * 8 * 64 * 62, 8 * 64 * 62, 64 * 62) == 0     # 62-float rows: no 16-byte pieces
+    d.ldx = 60
+    assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 0            # pitch below the width
+    d.Wi, d.Wo, d.ldx = 64, 32, 0
     assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc // 2, st_) == 0       # overlapping channel planes
     d.flags = L.PTX_EPI_RELU | L.PTX_EPI_RES_ADD
     assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st_) == 0
@@ -579,3 +621,70 @@ def test_inputs_are_bound_dense_and_16_byte_aligned(ptx):
     s = x[:, :, ::2]                              # frame-strided user view: made contiguous
     d = _dense16(s)
     assert d.is_contiguous() and d.data_ptr() % 16 == 0 and torch.equal(d, s)
+
+
+def test_every_nonlocal_mode_is_fused_at_the_reference_widths(ptx):
+    """no plan of the eight NonLocalBlock3D combinations materialises the [N, S, S] affinity -- also at
+    the reference's widths (nonlocalresnet3d50: C = 512 / 1024; `gaussian` uses theta = x, i.e. d = C = 1024 > the
+    register-resident 512, nonlocalnet.py:168-190; `concatenation` is relu(a_i + b_j) / N, :213-243).  PTX_NL_FUSED=0
+    still selects the unfused chain."""
+    import os
+    cases = [("embedded_gaussian", False, True), ("embedded_gaussian", True, True), ("dot_product", False, True),
+             ("dot_product", True, False), ("gaussian", False, True), ("gaussian", True, False),
+             ("concatenation", False, True), ("concatenation", True, False)]
+    for width in (512, 1024):
+        for mode, sub, bn in cases:
+            blk = ptx.NonLocalBlock3D(width, mode=mode, sub_sample=sub, bn_layer=bn)
+            plan = blk.engine().dry_plan(blk, (2, width, 2, 8, 8))
+            labels = [getattr(s, "label", "") for s in plan.steps]
+            assert "nonlocal_unfused" not in labels and labels.count("nonlocal_attention") == 1, (width, mode, sub, labels)
+            assert ("nonlocal_concat_ab" in labels) == (mode == "concatenation")
+    os.environ["PTX_NL_FUSED"] = "0"
+    try:
+        blk = ptx.NonLocalBlock3D(64, mode="concatenation")
+        assert "nonlocal_unfused" in [getattr(s, "label", "") for s in blk.engine().dry_plan(blk, (1, 64, 2, 4, 4)).steps]
+    finally:
+        del os.environ["PTX_NL_FUSED"]
+    # the C ABI's own gate: d <= 1024, RELU only with SCALE
+    L, lib = ptx._lib, ptx._lib.lib()
+    d = L.NonlocalDesc()
+    d.batch, d.Nq, d.Nk, d.d, d.dv = 1, 64, 64, 1024, 512
+    d.ld_theta = d.ld_phi = 1024
+    d.ld_g = d.ld_y = 512
+    assert lib.ptx_nonlocal_supported(C.byref(d)) == 1
+    d.d = 1028
+    assert lib.ptx_nonlocal_supported(C.byref(d)) == 0
+
+
+def test_replaced_parameters_and_modules_change_the_weight_signature(ptx):
+    """the engine caches the flat parameter list between forwards; a trunk Parameter or module REPLACED
+    by assignment (new tensor objects, old ones untouched) must still be noticed -- torch's global registration hooks bump
+    engine._struct_epoch, which invalidates the cached list, so the (data_ptr, _version) signature changes."""
+    from pretorched_x_amd import engine
+    assert engine._STRUCT_HOOKS
+    m = ptx.resnet3d10(num_classes=4)
+    eng = m.engine()
+    sig0 = eng._signature(m)
+    assert eng._signature(m) == sig0                                        # stable while nothing changes
+    blk = m.layer1[0]
+    blk.conv2.weight = torch.nn.Parameter(blk.conv2.weight.detach().clone())       # replaced, not edited in place
+    sig1 = eng._signature(m)
+    assert sig1 != sig0
+    m.bn1 = torch.nn.BatchNorm3d(m.bn1.num_features).eval()                         # a replaced module
+    sig2 = eng._signature(m)
+    assert sig2 != sig1
+    with torch.no_grad():
+        blk.conv1.weight.mul_(2.0)                                                  # in-place edits bump _version as before
+    assert eng._signature(m) != sig2
+    # opt-in autograd routing (ADVICE r2, low): eval-mode + grad mode + trainable parameters -> torch.nn path only when asked
+    from pretorched_x_amd import eager
+
+    class FakeCuda(torch.Tensor):
+        is_cuda = True
+    x = torch.zeros(1, 3, 4, 8, 8).as_subclass(FakeCuda)
+    m.eval()
+    assert eng.autograd is False and eager.wanted(m, x) is False
+    eng.autograd = True
+    assert eager.wanted(m, x) is True
+    with torch.no_grad():
+        assert eager.wanted(m, x) is False

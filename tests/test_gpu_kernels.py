@@ -900,6 +900,12 @@ def test_conv_f16_operands(ptx):
     (1, 300, 300, 256, 256, "softmax/x3", "PTX_NL_X3: layer2 width"),
     (2, 90, 90, 40, 24, "scale/x3", "PTX_NL_X3: dot_product mode"),
     (1, 64, 1568, 256, 256, "softmax/x3", "PTX_NL_X3: many key tiles"),
+    (2, 196, 196, 1024, 512, "softmax", "gaussian mode at the reference's layer3 width: theta = x, d = C = 1024 (theta from global)"),
+    (1, 392, 49, 1024, 512, "softmax", "d = 1024 with sub-sampled keys"),
+    (2, 100, 60, 640, 320, "scale", "512 < d < 1024, dot-product scaling"),
+    (2, 90, 70, 4, 24, "relu", "concatenation mode: relu(a_i + b_j) / N as a 2-term dot product on 4-float rows"),
+    (1, 200, 200, 4, 256, "relu/x3", "concatenation mode, split operands"),
+    (2, 196, 196, 1024, 512, "softmax/x3", "d > 512 under an x3 plan: the exact fp32 kernel stands in"),
 ])
 def test_fused_nonlocal_attention(ptx, case):
     """ptx_nonlocal_fwd against the reference's op sequence (nonlocalnet.py:143-166 / :192-211): matmul ->
@@ -917,7 +923,7 @@ def test_fused_nonlocal_attention(ptx, case):
     f = torch.matmul(theta, phi.transpose(1, 2))
     half, x3 = mode.endswith("/f16"), mode.endswith("/x3")
     mode = mode.split("/")[0]
-    f = F.softmax(f, dim=-1) if mode == "softmax" else f / f.size(-1)
+    f = F.softmax(f, dim=-1) if mode == "softmax" else (F.relu(f) if mode == "relu" else f) / f.size(-1)
     want = torch.matmul(f, gv)
     tq, tk = tpg_q.to(DEV), tpg_k.to(DEV)
     ldy = _r4(dv) + 8
@@ -927,7 +933,8 @@ def test_fused_nonlocal_attention(ptx, case):
     desc.ld_theta = desc.ld_phi = desc.ld_g = ld
     desc.ld_y = ldy
     desc.bs_theta, desc.bs_phi, desc.bs_g, desc.bs_y = Nq * ld, Nk * ld, Nk * ld, Nq * ldy
-    desc.mode = (L.PTX_NL_SOFTMAX if mode == "softmax" else L.PTX_NL_SCALE) | (L.PTX_NL_F16 if half else 0) | (L.PTX_NL_X3 if x3 else 0)
+    desc.mode = ((L.PTX_NL_SOFTMAX if mode == "softmax" else L.PTX_NL_SCALE) | (L.PTX_NL_RELU if mode == "relu" else 0) |
+                 (L.PTX_NL_F16 if half else 0) | (L.PTX_NL_X3 if x3 else 0))
     assert lib.ptx_nonlocal_supported(C.byref(desc))
     L.check(lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()), "nonlocal")
     torch.cuda.synchronize()
@@ -937,7 +944,7 @@ def test_fused_nonlocal_attention(ptx, case):
     # fp16 operands: theta / phi / g / P rounded to 11 bits, fp32 accumulate (bound chosen by the builder)
     assert err <= (5e-3 if half else 2e-5) * max(1.0, want.abs().max().item()), (case, err)
     # unsupported widths are refused, not mis-computed
-    desc.d = 1024
+    desc.d = 2048
     assert not lib.ptx_nonlocal_supported(C.byref(desc))
     assert lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()) != 0
 

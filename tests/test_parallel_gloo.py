@@ -66,7 +66,7 @@ def _bench_worker(rank, world, port, total, q, corrupt):
         out = _fake_forward(local)
         return out + calls[0] if (corrupt and rank == 1) else out
 
-    elapsed, out, verify = bench.timed_steps(run, total // world, steps=3, warmup=1, dev=torch.device("cpu"),
+    elapsed, out, verify = bench.timed_steps(run, total, steps=3, warmup=1, dev=torch.device("cpu"),
                                              sync=lambda: None)
     # rank 0 "tunes", everyone adopts its table
     if rank == 0:
@@ -75,6 +75,25 @@ def _bench_worker(rank, world, port, total, q, corrupt):
     has = engine.tuned_snapshot().get("[\"fake-problem\"]")
     ok_out = corrupt or torch.equal(out, _fake_forward(clips))
     q.put((rank, dict(verify), bool(ok_out), calls[0], elapsed > 0, has, n > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _strong_worker(rank, world, port, total, q, workload):
+    """bench.py --scaling strong under gloo: ONE global batch (identical on every rank) cut by bench.local_batch /
+    parallel.shard_clips, timed_steps gathers `total` rows (ragged shards included), rank order == clip order."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    bench.GLOBAL_BATCH = dict(bench.GLOBAL_BATCH, **{workload: total})        # small stand-in batch sizes
+    make = lambda n, seed: torch.randn(n, 3, 2, 4, 4, generator=torch.Generator().manual_seed(seed))     # noqa: E731
+    local, tot = bench.local_batch(make, 8, workload, "strong", world, rank)
+    elapsed, out, verify = bench.timed_steps(lambda: _fake_forward(local), tot, steps=2, warmup=1, dev=torch.device("cpu"),
+                                             sync=lambda: None)
+    want = _fake_forward(make(total, 99))
+    q.put((rank, dict(verify), bool(torch.equal(out, want)), int(local.shape[0]), tot))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,3 +146,14 @@ def test_bench_distributed_check_flags_a_bad_rank():
     for rank, verify, *_ in res:
         assert verify["gather_order_ok"] and verify["replicas_identical"]      # the gather itself is fine ...
         assert verify["deterministic"] is False                                   # ... rank 1's forward is not
+
+
+def test_bench_strong_scaling_shards_one_global_batch():
+    """--scaling strong (cfg2: the fixed 8-clip batch; cfg4: 16 clips over the ranks), equal and ragged shards."""
+    for total, workload in ((8, "cfg2"), (5, "cfg4")):
+        res = _run(total=total, target=_strong_worker, extra=(workload,))
+        per = sorted(n for _, _, _, n, _ in res)
+        assert sum(per) == total and per == sorted([total - total // 2, total // 2]), per
+        for rank, verify, ok, n, tot in res:
+            assert tot == total and ok, (rank, n)
+            assert verify["gather_order_ok"] and verify["replicas_identical"] and verify["deterministic"] and verify["rows"] == total
