@@ -262,11 +262,14 @@ def main():
                     f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
                         label, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
                         stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, split, ms, 2e-9 * macs / ms))
-                for lab, kind, nb, macs, ms, _ in all_rows:
-                    if kind != "conv":
+                for lab, kind, nb, macs, ms, _cfg in all_rows:
+                    if kind == "chain":
+                        f.write("%-34s chain %-40s %8.4f ms %8.1f TF\n" % (lab, _cfg, ms, 2e-9 * macs / ms))
+                    elif kind != "conv":
                         f.write("%-34s %-5s bytes=%-12d macs=%-14d %8.4f ms %8.1f GB/s\n" % (lab, kind, nb, macs, ms, nb / ms / 1e6))
         # the direct stem (ptx_conv_stem_f32_fwd) is a conv too, with its own kernel
-        stem_rows = [(lab, macs, ms, cfg, 1) for lab, kind, nb, macs, ms, cfg in all_rows if kind == "stem"]
+        # ... and so are the chained launches (two convs in one kernel, conv_chain.hip)
+        stem_rows = [(lab, macs, ms, cfg, 1) for lab, kind, nb, macs, ms, cfg in all_rows if kind in ("stem", "chain")]
         by_kernel = {}
         for label, macs, ms, cfg, split in rows + stem_rows:
             k = by_kernel.setdefault(cfg, dict(ms=0.0, flop=0.0, launches=0))
@@ -285,7 +288,7 @@ def main():
                 h["ms"] += ms
                 h["bytes"] += nb
                 h["launches"] += 1
-            elif kind not in ("conv", "stem"):
+            elif kind not in ("conv", "stem", "chain"):
                 other_ms += ms
         roofline_hbm = {k: {"bound": "hbm", "launches": v["launches"], "ms": round(v["ms"], 4),
                             "algorithmic_MB": round(v["bytes"] / 1e6, 2),

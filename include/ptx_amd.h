@@ -155,6 +155,32 @@ int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* desc, const float* x, const float
                         const float* w_packed, const float* bias, float* y, void* workspace,
                         size_t workspace_bytes, int config, int split_k, ptx_stream_t stream);
 
+/*
+ * Chained convolutions: conv -> BN -> ReLU -> 1x1x1 conv -> BN (-> + residual) -> ReLU in ONE launch,
+ *   y[m][co2] = epi2( sum_c1 relu?( conv(x, w_packed)[m][c1] + bias[c1] ) * w2_packed[co2][c1] + bias2[co2] (+ res[m][co2]) )
+ * -- the [M][N1] result of the first conv never reaches HBM: a workgroup parks its [BM][N1] tile in LDS and feeds it to
+ * the second GEMM as the A operand.  Replaces (a) a bottleneck's tail, conv2 (3x3x3) -> bn2 -> relu -> conv3 (1x1x1) ->
+ * bn3 -> `out += residual` -> relu (resnet3D.py:129-142), and (b) the pointwise pairs of the (2+1)D networks: a
+ * "1x1x1" SpatioTemporalConv is spatial_conv (1x1x1) -> bn -> relu -> temporal_conv (1x1x1) through
+ * M = floor(Cin Cout / (Cin + Cout)) mid channels (r2plus1d.py:68-88), followed by the block's own BN (+ residual) + ReLU.
+ *   conv: any dense fp32 conv descriptor (taps, strides, padding as ptx_conv3d_fwd; flags within PTX_EPI_RELU: the ReLU
+ *         BETWEEN the two convs; ldy is ignored); N1 = conv->Co must fit ONE N tile of the chained tile configuration
+ *         (32 / 64 / 128 -- ptx_conv3d_chain_supported).  A strided pointwise PAIR is expressed by composing the strides
+ *         in `conv` (the tail's positions are the final output positions).
+ *   tail: a 1x1x1 / unit-stride descriptor over the first conv's OUTPUT positions (N, Ti/Hi/Wi = conv's N, To/Ho/Wo),
+ *         Ci = conv->Co, Kc >= round_up(Ci, 4) (its packed filter [Co_pad][Kc], ptx_pack_conv_weight), flags within
+ *         PTX_EPI_RELU | PTX_EPI_RES_ADD (res: same shape as y, row stride ldr), ldy = row stride of y.
+ * Arithmetic: both GEMMs on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 in the same k order as the unfused launches on tiles of
+ * the same MFMA shape -- bit-identical to ptx_conv3d_fwd followed by ptx_conv3d_fwd.  config < 0: ptx_conv3d_chain_pick_config.
+ */
+int ptx_conv3d_chain_num_configs(void);
+const char* ptx_conv3d_chain_config_name(int config);
+int ptx_conv3d_chain_supported(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail, int config);
+int ptx_conv3d_chain_pick_config(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail);
+int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail, const float* x, const float* w_packed,
+                         const float* bias, const float* w2_packed, const float* bias2, const float* res, float* y,
+                         int config, ptx_stream_t stream);
+
 /* Small-Cin STEM convolution with split operands (PTX_F16X3_OPERANDS), read straight from a channels-last input whose
  * positions are 16 bytes (Ci <= 4, ldx == 4) -- `conv1` of the ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D
  * stems, the (1,7,7) spatial stem of R2Plus1D (r2plus1d.py:73-88).  A workgroup stages the input patch of one temporal

@@ -115,6 +115,11 @@ SIGNATURES = {
     "ptx_conv3d_fused_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(ConvFusedExt), _P, _Z, C.c_int,
                                        C.c_int, _P]),
     "ptx_conv3d_dual_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _Z, C.c_int, C.c_int, _P]),
+    "ptx_conv3d_chain_num_configs": (C.c_int, []),
+    "ptx_conv3d_chain_config_name": (C.c_char_p, [C.c_int]),
+    "ptx_conv3d_chain_supported": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int]),
+    "ptx_conv3d_chain_pick_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
+    "ptx_conv3d_chain_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "ptx_ncdhw_to_split4": (C.c_int, [_P, _P, _I, _I, _L, _P]),
     "ptx_conv_stem_x3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv_stem_x3_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),

@@ -70,6 +70,34 @@ def _config_index(name):
     return _cfg_index.get(name)
 
 
+_chain_index = None              # chained-tile configuration name -> index (ptx_conv3d_chain_config_name)
+
+
+def _chain_config_index(name):
+    global _chain_index
+    if _chain_index is None:
+        lib = _lib.lib()
+        _chain_index = {lib.ptx_conv3d_chain_config_name(i).decode(): i for i in range(lib.ptx_conv3d_chain_num_configs())}
+    return _chain_index.get(name)
+
+
+def chain_key(d, d2):
+    return "chain:" + json.dumps(d.key() + d2.key())
+
+
+def chain_lookup(key):
+    """Tuned chained-tile index of a (conv, tail) problem pair, or None."""
+    ent = _tuned_table().get(key)
+    return None if ent is None else _chain_config_index(ent[0])
+
+
+def chain_store(key, cfg_index):
+    name = _lib.lib().ptx_conv3d_chain_config_name(int(cfg_index)).decode()
+    table = _tuned_table()
+    with _tuned_lock:
+        table[key] = (name, 1)
+
+
 def _tuned_table():
     global _tuned
     with _tuned_lock:
@@ -401,6 +429,20 @@ class ConvStep:
                                             p.ws_ptr, p.ws_bytes, self.cfg, self.split, st), self.label)
 
 
+class ChainStep:
+    """One ptx_conv3d_chain_fwd launch: conv -> BN -> ReLU -> 1x1x1 conv -> BN (-> + residual) -> ReLU, the intermediate
+    tile kept in LDS (conv_chain.hip)."""
+    __slots__ = ("d", "d2", "x", "w", "b", "w2", "b2", "res", "y", "cfg", "plan", "label", "macs", "hbm_bytes", "key")
+
+    @property
+    def kernel(self):
+        return _lib.lib().ptx_conv3d_chain_config_name(self.cfg).decode()
+
+    def __call__(self, st):
+        check(_lib.lib().ptx_conv3d_chain_fwd(C.byref(self.d), C.byref(self.d2), self.x, self.w, self.b, self.w2, self.b2,
+                                              self.res, self.y, self.cfg, st), self.label)
+
+
 class StemStep:
     """One ptx_conv_stem_x3_fwd launch (split-operand stem read from 4-channel positions)."""
     __slots__ = ("d", "x", "w", "b", "y", "label", "macs", "hbm_bytes")
@@ -448,6 +490,9 @@ class Plan:
         self.lib = _lib.lib()
         self.steps = []          # callables(stream)
         self.conv_steps = []
+        self.chain_steps = []    # ChainStep launches (two convs each; tuned over their own tile table)
+        # chained convs (conv -> 1x1x1 conv in one launch): fp32 plans; PTX_CHAIN=0 keeps every conv its own launch
+        self.chain = os.environ.get("PTX_CHAIN", "1") != "0" and getattr(engine, "precision", "fp32") == "fp32"
         self.packs = []
         self.acts = []
         self._pack_cache = {}
@@ -628,11 +673,80 @@ class Plan:
         self.conv_steps.append(st)
         return (y, raw_act) if raw else y
 
+    def conv_chain(self, x, pk, stride, padding, pk2, relu1=True, relu2=False, res=None, label="chain", y=None):
+        """conv(x, pk) -> [ReLU] -> 1x1x1 conv (pk2) -> [+ res] -> [ReLU] as ONE launch (ptx_conv3d_chain_fwd), or None when
+        the pair does not qualify -- the caller then emits the two convs separately.  Qualifies: fp32 plan, dense unfolded
+        filters, a pointwise tail whose K axis is the first conv's output, at most 128 intermediate channels (one N tile
+        holds the whole intermediate row), a same-shape residual (or none), and enough rows to fill the chip from M tiles
+        alone (the tail's N slices run inside one workgroup: M >= PTX_CHAIN_MIN_M, default 8192)."""
+        if not self.chain or isinstance(x, RawInput) or getattr(x, "f16", False):
+            return None
+        for p_ in (pk, pk2):
+            if getattr(p_, "x3", False) or getattr(p_, "f16", False) or getattr(p_, "groups", 1) > 1 or getattr(p_, "fold_kw", False) \
+                    or not isinstance(p_, Packed):
+                return None
+        # 32 .. PTX_CHAIN_MAX_N1 intermediate channels: narrower convs (SlowFast's fast pathway: 8 / 16 planes) keep their
+        # 16-wide / direct tiles -- a 32-wide chained tile would pad their work 2-4x
+        if pk2.k_eff != (1, 1, 1) or pk2.Ci != pk.Co or pk.Co < 32 or _r4(pk.Co) > min(128, int(os.environ.get("PTX_CHAIN_MAX_N1", "128"))):
+            return None
+        kT, kH, kW = pk.k_eff
+        sT, sH, sW = stride
+        pT, pH, pW = padding
+        To, Ho, Wo = (x.T + 2 * pT - kT) // sT + 1, (x.H + 2 * pH - kH) // sH + 1, (x.W + 2 * pW - kW) // sW + 1
+        M = x.N * To * Ho * Wo
+        if min(To, Ho, Wo) < 1 or M < int(os.environ.get("PTX_CHAIN_MIN_M", "8192")):
+            return None
+        if res is not None and (res.N, res.T, res.H, res.W, res.C) != (x.N, To, Ho, Wo, pk2.Co):
+            return None
+        if y is not None and ((y.N, y.T, y.H, y.W, y.C) != (x.N, To, Ho, Wo, pk2.Co) or getattr(y, "f16", False)):
+            return None
+        d = ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, _r4(pk.Co)
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
+        d.Kc, d.Co_pad, d.groups = pk.Kc, pk.Co_pad, 1
+        d.flags = PTX_EPI_RELU if relu1 else 0
+        ld_out = y.ld if y is not None else _r4(pk2.Co)
+        d2 = ConvDesc()
+        d2.N, d2.Ti, d2.Hi, d2.Wi, d2.Ci, d2.ldx = x.N, To, Ho, Wo, pk.Co, _r4(pk.Co)
+        d2.To, d2.Ho, d2.Wo, d2.Co, d2.ldy = To, Ho, Wo, pk2.Co, ld_out
+        d2.kT = d2.kH = d2.kW = d2.sT = d2.sH = d2.sW = 1
+        d2.Kc, d2.Co_pad, d2.groups = pk2.Kc, pk2.Co_pad, 1
+        d2.flags = (PTX_EPI_RELU if relu2 else 0) | (PTX_EPI_RES_ADD if res is not None else 0)
+        d2.ldr = res.ld if res is not None else 0
+        key = chain_key(d, d2)
+        cfg = chain_lookup(key)
+        if cfg is None or not self.lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg):
+            cfg = self.lib.ptx_conv3d_chain_pick_config(C.byref(d), C.byref(d2))
+        if cfg < 0 or not self.lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg):
+            return None
+        if y is None:
+            y = self.act(x.N, To, Ho, Wo, pk2.Co)
+        if y.ld != _r4(pk2.Co) and pk2.Co % 4:
+            raise PtxError("%s: a channel-slice output needs Co %% 4 == 0" % label)
+        st = ChainStep()
+        st.d, st.d2, st.cfg, st.key, st.plan, st.label = d, d2, cfg, key, self, label
+        st.x, st.w, st.b, st.w2, st.b2, st.y = _ptr(x.t), _ptr(pk.w), _ptr(pk.b), _ptr(pk2.w), _ptr(pk2.b), _ptr(y.t)
+        st.res = _ptr(res.t) if res is not None else C.c_void_p(0)
+        st.macs = M * (pk.Co * getattr(pk, "real_ci", pk.Ci) * kT * kH * kW + pk2.Co * pk.Co)
+        st.hbm_bytes = 0
+        self.steps.append(st)
+        self.chain_steps.append(st)
+        return y
+
     def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv", y=None):
         """nn.Conv{2,3}d or a (2+1)D pair, followed by `bn`, with the epilogue fused."""
         if hasattr(conv, "spatial_conv"):      # r2plus1d.py:85-88
             ks, ss, ps = _geom(conv.spatial_conv)
             fold = _foldable(conv.spatial_conv, x)
+            kt, st_, pt = _geom(conv.temporal_conv)
+            if not fold and ks == (1, 1, 1) and kt == (1, 1, 1) and res_kind is None and ps == (0, 0, 0) and pt == (0, 0, 0):
+                # a "1x1x1" SpatioTemporalConv = two pointwise GEMMs through the mid channels (r2plus1d.py:68-88): ONE chained
+                # launch, strides composed (the pair's output positions index the input directly)
+                yc = self.conv_chain(x, self.pack(conv.spatial_conv, conv.bn), tuple(a * b for a, b in zip(ss, st_)), (0, 0, 0),
+                                     self.pack(conv.temporal_conv, bn), relu1=True, relu2=relu, res=res, label=label + ".pair", y=y)
+                if yc is not None:
+                    return yc
             mid = self.stem_direct(x, conv.spatial_conv, conv.bn, True, label + ".spatial") if fold else None
             if mid is None:
                 mid = self.conv(x if not fold else self.fold_input(x, conv.spatial_conv),
@@ -1058,9 +1172,20 @@ class Plan:
             res, kind = x, None
         if arch.block in ("bottleneck", "resnext", "wide"):
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
-            o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
-            o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
-                             label=name + ".conv3", y=out)
+            tail = None
+            if (kind is None and isinstance(blk.conv2, (nn.Conv3d, nn.Conv2d)) and isinstance(blk.conv3, (nn.Conv3d, nn.Conv2d))
+                    and not getattr(blk.conv2, "tf_same", False)):
+                # the bottleneck's tail conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu (resnet3D.py:129-142)
+                # as one chained launch: conv2's output tile never leaves the workgroup
+                k2, s2, p2 = _geom(blk.conv2)
+                tail = self.conv_chain(o, self.pack(blk.conv2, blk.bn2), s2, p2, self.pack(blk.conv3, blk.bn3), relu1=True,
+                                       relu2=True, res=res, label=name + ".conv2+conv3", y=out)
+            if tail is not None:
+                o = tail
+            else:
+                o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
+                o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
+                                 label=name + ".conv3", y=out)
         else:
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, res=res, res_kind=kind, res_stride=s,
@@ -1130,7 +1255,7 @@ class Plan:
     def all_convs(self):
         """Every convolution launch of the plan in execution order: the implicit-GEMM steps (`conv_steps`, what the
         autotuner owns) and the direct stem kernels."""
-        return [s for s in self.steps if isinstance(s, (ConvStep, StemStep, StemF32Step))]
+        return [s for s in self.steps if isinstance(s, (ConvStep, ChainStep, StemStep, StemF32Step))]
 
     def refresh_weights(self, model):
         """Re-pack every filter (and rebuild the weight-derived tables) from `model`'s current tensors."""
@@ -1476,7 +1601,7 @@ class Engine:
             if plan.tuned:
                 return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
-                   for s in plan.conv_steps):
+                   for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
 
@@ -1691,6 +1816,44 @@ class Engine:
                         stp.label, M, stp.d.Co, stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW,
                         lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
                         2e-9 * stp.macs / best[0]))
+            # chained launches: time every chained tile that holds the intermediate row
+            seen_c = {}
+            for stp in plan.chain_steps:
+                if stp.key in seen_c:
+                    stp.cfg = seen_c[stp.key]
+                    continue
+                if only_untuned and chain_lookup(stp.key) is not None:
+                    continue
+                best = None
+                for cfg in range(lib.ptx_conv3d_chain_num_configs()):
+                    if not lib.ptx_conv3d_chain_supported(C.byref(stp.d), C.byref(stp.d2), cfg):
+                        continue
+                    keep, stp.cfg = stp.cfg, cfg
+                    try:
+                        stp(_stream())
+                    except PtxError:
+                        stp.cfg = keep
+                        continue
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        stp(_stream())
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / iters
+                    if log is not None:
+                        log.write("%s\t%s\t%.4f ms\t%.1f TF\n" % (stp.label, lib.ptx_conv3d_chain_config_name(cfg).decode(), ms,
+                                                                  2e-9 * stp.macs / ms))
+                    if best is None or ms < best[0]:
+                        best = (ms, cfg)
+                    stp.cfg = keep
+                if best is not None:
+                    stp.cfg = best[1]
+                    seen_c[stp.key] = best[1]
+                    chain_store(stp.key, best[1])
+                    if verbose:
+                        print("tune %-34s -> %-28s %.3f ms  %.1f TF" % (stp.label, lib.ptx_conv3d_chain_config_name(best[1]).decode(),
+                                                                       best[0], 2e-9 * stp.macs / best[0]))
             plan.run_features(_dense16(x))
             plan.tuned = True
             if log is not None:
@@ -1741,6 +1904,8 @@ class Engine:
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode()))
             elif isinstance(stp, (StemStep, StemF32Step)):      # the direct stems are convs too, with their own kernels
                 rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
+            elif isinstance(stp, ChainStep):                    # two convs in one launch, its own tile table
+                rows.append((stp.label, "chain", 0, stp.macs, ms, stp.kernel))
             else:
                 nb, macs = getattr(stp, "hbm_bytes", 0), getattr(stp, "macs", 0)
                 kind = "mem" if nb and not macs else "mfma" if macs else "other"

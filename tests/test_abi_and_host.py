@@ -246,7 +246,21 @@ def test_plan_compiler_matches_survey_worklist(ptx):
 
     m = ptx.resnet3d50(num_classes=339, pretrained=None)
     plan = m.engine().dry_plan(m, (8, 3, 16, 224, 224))
-    assert len(plan.conv_steps) == 48 and len(convs(plan)) == 49
+    # round 3: bottleneck tails conv2 -> conv3 (+ residual) of the blocks without a shortcut conv run as ONE chained launch
+    # where the intermediate row fits a tile (<= 128 planes) and M fills the chip: layer1.{1,2}, layer2.{1,2,3}
+    from pretorched_x_amd.engine import ChainStep
+    chains = [s for s in plan.steps if isinstance(s, ChainStep)]
+    assert [s.label for s in chains] == ["layer%d.%d.conv2+conv3" % lb for lb in ((1, 1), (1, 2), (2, 1), (2, 2), (2, 3))]
+    assert (chains[0].d.kT, chains[0].d.Co, chains[0].d2.Co, chains[0].d2.flags) == (3, 64, 256, 3)       # RELU | RES_ADD
+    assert len(plan.conv_steps) == 38 and len(convs(plan)) == 44
+    os.environ["PTX_CHAIN"] = "0"
+    try:
+        m0 = ptx.resnet3d50(num_classes=339, pretrained=None)
+        plan0 = m0.engine().dry_plan(m0, (8, 3, 16, 224, 224))
+    finally:
+        del os.environ["PTX_CHAIN"]
+    assert len(plan0.conv_steps) == 48 and len(convs(plan0)) == 49 and not plan0.chain_steps
+    assert abs(sum(s.macs for s in convs(plan0)) - sum(s.macs for s in convs(plan))) < 1
     # the stem reads the caller's NCDHW tensor: no fold / layout pass in front of it
     assert isinstance(plan.steps[0], StemF32Step) and plan.steps[0].strides == (3 * 16 * 224 * 224, 16 * 224 * 224, 224 * 224)
     fused = [s for s in plan.conv_steps if s.x2 is not None]
@@ -255,12 +269,13 @@ def test_plan_compiler_matches_survey_worklist(ptx):
     gmac = sum(s.macs for s in convs(plan)) / 1e9
     assert abs(gmac - 318.763) < 0.01
     os.environ["PTX_FUSE_SHORTCUT"] = "0"
+    os.environ["PTX_CHAIN"] = "0"                # one launch per conv: the SURVEY work-list itself
     os.environ["PTX_STEM_DIRECT"] = "0"          # the kW-folded implicit-GEMM stem (the fallback for geometries the kernel refuses)
     try:
         m2 = ptx.resnet3d50(num_classes=339, pretrained=None)
         plan2 = m2.engine().dry_plan(m2, (8, 3, 16, 224, 224))
     finally:
-        del os.environ["PTX_FUSE_SHORTCUT"], os.environ["PTX_STEM_DIRECT"]
+        del os.environ["PTX_FUSE_SHORTCUT"], os.environ["PTX_STEM_DIRECT"], os.environ["PTX_CHAIN"]
     plan = plan2
     assert len(plan2.conv_steps) == 53
     geom = {s.d.key()[:22] for s in plan2.conv_steps}             # geometry only (no epilogue flags):
@@ -286,7 +301,8 @@ def test_every_factory_compiles_a_plan(ptx):
         m = ptx.__dict__[name](**kw)
         plan = m.engine().dry_plan(m, (1, 3, 8, 64, 64))
         if depth:     # conv layers of a bottleneck ResNet-d: d - 2 (+4 shortcut convs), 4 of them fused away
-            assert sum(1 + (getattr(s, "x2", None) is not None) for s in plan.all_convs()) == depth - 2 + 4 + 1, name
+            from pretorched_x_amd.engine import ChainStep
+            assert sum(1 + (getattr(s, "x2", None) is not None) + isinstance(s, ChainStep) for s in plan.all_convs()) == depth - 2 + 4 + 1, name
         assert plan.feat.C == 512 * m.arch.expansion
     assert ptx.resnet3d200(pretrained=None).last_linear.out_features == 339      # reference quirk (num_classes unused)
     nl10 = ptx.nonlocalresnet3d50(num_nonlocal_blocks=10, pretrained=None)
@@ -345,9 +361,18 @@ def test_shard_bounds():
             assert all(chunks[i][1] == chunks[i + 1][0] for i in range(world - 1))
 
 
-def test_slowfast_plan_wiring_without_gpu(ptx):
+def test_slowfast_plan_wiring_without_gpu(ptx, monkeypatch):
     """Dry plan (meta device) of SlowFast-50: lateral convs and the stages' last convs write channel
     slices of one concatenated tensor (no torch.cat), both stems read strided frames."""
+    from pretorched_x_amd.engine import ChainStep
+    m = ptx.slowfast.resnet50(num_classes=7)
+    planc = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
+    # chained bottleneck tails write the concat slices too: the slow pathway's 64 / 128-plane blocks and the fast pathway's
+    # 32 / 64-plane ones (narrower planes keep their 16-wide / direct tiles)
+    ch = {s.label: s for s in planc.steps if isinstance(s, ChainStep)}
+    assert ch["slow.res2.2.conv2+conv3"].d2.ldy == 320 and ch["slow.res2.2.conv2+conv3"].d.Co == 64
+    assert all(32 <= s.d.Co <= 128 for s in ch.values()) and not any(l.startswith("fast.res2") for l in ch)
+    monkeypatch.setenv("PTX_CHAIN", "0")             # the rest of this test reads the one-launch-per-conv wiring
     m = ptx.slowfast.resnet50(num_classes=7)
     plan = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
     steps = {s.label: s for s in plan.all_convs()}
@@ -467,7 +492,9 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     eng.precision = "x3"
     plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
     # the stem leaves the implicit-GEMM list: ptx_conv_stem_x3_fwd reads 4-channel positions, no kW fold
-    assert plan.x3 and len(plan.conv_steps) == len(base.conv_steps) and plan.stem_steps == 1
+    # (split-operand plans keep one launch per conv: the chained tiles are fp32-MFMA tiles)
+    assert plan.x3 and not plan.chain_steps and len(plan.conv_steps) == len(base.conv_steps) + 2 * len(base.chain_steps)
+    assert plan.stem_steps == 1
     stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
     assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"
     assert not any(getattr(s, "label", "") == "fold_kw" for s in plan.steps)
@@ -477,7 +504,7 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     assert sum(s.macs for s in plan.conv_steps) + stem.macs == sum(s.macs for s in base.all_convs())
     monkeypatch.setenv("PTX_STEM_DIRECT", "0")               # the folded implicit-GEMM stem on 32-float rows
     folded = eng.dry_plan(m, (2, 3, 16, 224, 224))
-    assert len(folded.conv_steps) == len(base.all_convs())
+    assert len(folded.conv_steps) == len(base.all_convs()) + len(base.chain_steps)
     assert (folded.conv_steps[0].d.Kc, folded.conv_steps[0].d.ldx, folded.conv_steps[0].d.Ci) == (32, 32, 21)
     monkeypatch.delenv("PTX_STEM_DIRECT")
     # grouped convs (ResNeXt3D) are not split: they stay on the fp32 / direct tiles

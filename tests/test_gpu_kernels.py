@@ -1385,3 +1385,159 @@ def test_conv_stem_f32_direct(ptx):
     assert not lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st)
     d.kW, d.Wi = 7, 38
     assert not lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st)
+
+
+def test_conv_stem_f32_padded_pitch(ptx):
+    """Widths that are not multiples of 4 floats: ptx_pad_rows copies the NCDHW rows to a zero-padded 16-byte pitch and
+    ptx_conv_stem_f32_fwd reads them with desc.ldx = pitch (the reference takes any T/H/W, torchvision_models.py:448)."""
+    L, lib = ptx._lib, _lib(ptx)
+    for (N, T, H, W, Co, k, s_, p_) in [(2, 4, 18, 30, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+                                         (1, 1, 33, 45, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+                                         (2, 5, 20, 22, 110, (1, 7, 7), (1, 2, 2), (0, 3, 3))]:
+        x = rnd(N, 3, T, H, W, seed=190)
+        w = rnd(Co, 3, *k, seed=191, scale=(3 * k[0] * k[1] * k[2]) ** -0.5)
+        bn = make_bn(Co, 192)
+        want = ref_conv(x, w, s_, p_, bn=bn, relu=True)
+        To, Ho, Wo = want.shape[2:]
+        pitch = _r4(W)
+        xd = x.contiguous().to(DEV)
+        xp = torch.full((N * 3 * T * H, pitch), float("nan"), device=DEV)
+        L.check(lib.ptx_pad_rows(_p(xd), _p(xp), N * 3 * T * H, W, pitch, _st()), "pad_rows")
+        torch.cuda.synchronize()
+        xpc = xp.cpu().reshape(N, 3, T, H, pitch)
+        assert torch.equal(xpc[..., :W], x) and bool((xpc[..., W:] == 0).all())
+        Co_pad = (Co + 127) // 128 * 128
+        Kc = 24
+        pd = L.PackDesc(Co, 3, k[0], k[1], k[2], Kc, Co_pad, 1)
+        wf = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(Co_pad, device=DEV)
+        ts = [t.to(DEV) for t in bn[:4]]
+        wd = w.contiguous().to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), None, _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]),
+                                         C.c_float(bn[4]), _p(wf), _p(bp), _st()), "pack folded")
+        ldy = _r4(Co)
+        d = L.ConvDesc()
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, 3, pitch
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, Co, ldy
+        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = k[0], k[1], k[2], s_[0], s_[1], s_[2], p_[0], p_[1], p_[2]
+        d.Kc, d.Co_pad, d.flags = Kc, Co_pad, L.PTX_EPI_RELU
+        plane = H * pitch
+        sn, sc, st = 3 * T * plane, T * plane, plane
+        assert lib.ptx_conv_stem_f32_supported(C.byref(d), sn, sc, st), (N, T, H, W)
+        ws = torch.full((lib.ptx_stem_f32_weight_elems(C.byref(d)),), float("nan"), device=DEV)
+        L.check(lib.ptx_pack_stem_f32_weight(C.byref(d), _p(wf), Kc, _p(ws), _st()), "pack stem f32")
+        yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+        L.check(lib.ptx_conv_stem_f32_fwd(C.byref(d), _p(xp), sn, sc, st, _p(ws), _p(bp), _p(yd), _st()), "stem f32 (pitch)")
+        torch.cuda.synchronize()
+        got = from_cl(yd, Co)
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        assert err <= 2e-5, ((N, T, H, W, Co), err)
+
+
+def _pack_plain(ptx, w, bn, bias=None):
+    """BN-folded K-major packed filter + bias on the device (fp32, unfolded)."""
+    L, lib = ptx._lib, _lib(ptx)
+    Co, Ci, kT, kH, kW = w.shape
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd = w.contiguous().to(DEV)
+    null = C.c_void_p(0)
+    bnargs, eps, keep = [null] * 4, 0.0, [wd]
+    if bn is not None:
+        ts = [t.contiguous().to(DEV) for t in bn[:4]]
+        keep += ts
+        bnargs, eps = [_p(t) for t in ts], bn[4]
+    bd = bias.to(DEV) if bias is not None else None
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd) if bd is not None else null, *bnargs, C.c_float(eps),
+                                     _p(wp), _p(bp), _st()), "pack")
+    torch.cuda.synchronize()
+    return pd, wp, bp
+
+
+CHAIN_CASES = [
+    # name, N,T,H,W, Ci, N1, Co2, k, stride, pad, relu1, relu2, residual
+    ("bottleneck tail 3x3x3 -> 1x1x1 + residual", 2, 4, 14, 15, 64, 64, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True, True),
+    ("(2+1)D pointwise pair 64 -> 51 -> 256 + residual", 2, 3, 13, 14, 64, 51, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, True, True),
+    ("pointwise pair 256 -> 51 -> 64, ReLU out, no residual", 1, 4, 12, 12, 256, 51, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, True, False),
+    ("strided pair 256 -> 85 -> 128 (composed stride 2,2,2), linear output", 2, 4, 12, 14, 256, 85, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0), True, False, False),
+    ("narrow mid 64 -> 32 -> 64", 2, 2, 9, 11, 64, 32, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, True, False),
+    ("mid 102 (128-wide N tile): 512 -> 102 -> 512 + residual", 1, 2, 10, 9, 512, 102, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, True, True),
+    ("layer2 tail 3x3x3 stride 2 -> 1x1x1, 128 planes", 1, 4, 12, 12, 128, 128, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1), True, True, False),
+    ("(1,3,3) conv -> ragged tail 144 -> 100 -> 36, no inner ReLU", 1, 3, 10, 10, 144, 100, 36, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CHAIN_CASES, ids=[c[0] for c in CHAIN_CASES])
+def test_conv_chain(ptx, case):
+    """ptx_conv3d_chain_fwd (conv -> BN -> ReLU -> 1x1x1 conv -> BN -> + residual -> ReLU in one launch, the intermediate
+    tile in LDS) on EVERY chained tile that holds the intermediate row, against (a) the op sequence in torch fp32 on the
+    CPU and (b) the two launches it replaces on the plain tiles of the same MFMA shape -- bit for bit (same k order:
+    VERDICT r2 #3 'bit-exactness test vs the unfused pair')."""
+    L, lib = ptx._lib, _lib(ptx)
+    _, N, T, H, W, Ci, N1, Co2, k, s_, p_, relu1, relu2, with_res = case
+    x = rnd(N, Ci, T, H, W, seed=400 + Ci)
+    w1 = rnd(N1, Ci, *k, seed=401, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
+    w2 = rnd(Co2, N1, 1, 1, 1, seed=402, scale=N1 ** -0.5)
+    bn1, bn2 = make_bn(N1, 403), make_bn(Co2, 404)
+    mid = ref_conv(x, w1, s_, p_, bn=bn1, relu=relu1)
+    To, Ho, Wo = mid.shape[2:]
+    res = rnd(N, Co2, To, Ho, Wo, seed=405) if with_res else None
+    want = ref_conv(mid, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res)
+    pd1, wp1, bp1 = _pack_plain(ptx, w1, bn1)
+    pd2, wp2, bp2 = _pack_plain(ptx, w2, bn2)
+    xd = to_cl(x)
+    rd = to_cl(res) if with_res else None
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, xd.shape[-1]
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, N1, _r4(N1)
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = k[0], k[1], k[2], s_[0], s_[1], s_[2], p_[0], p_[1], p_[2]
+    d.Kc, d.Co_pad, d.flags = pd1.Kc, pd1.Co_pad, (L.PTX_EPI_RELU if relu1 else 0)
+    ldy = _r4(Co2) + 8                                   # a row stride wider than the written columns
+    d2 = L.ConvDesc()
+    d2.N, d2.Ti, d2.Hi, d2.Wi, d2.Ci, d2.ldx = N, To, Ho, Wo, N1, _r4(N1)
+    d2.To, d2.Ho, d2.Wo, d2.Co, d2.ldy = To, Ho, Wo, Co2, ldy
+    d2.kT = d2.kH = d2.kW = d2.sT = d2.sH = d2.sW = 1
+    d2.Kc, d2.Co_pad = pd2.Kc, pd2.Co_pad
+    d2.flags = (L.PTX_EPI_RELU if relu2 else 0) | (L.PTX_EPI_RES_ADD if with_res else 0)
+    d2.ldr = rd.shape[-1] if with_res else 0
+    plain = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
+    null = C.c_void_p(0)
+    ran = 0
+    for cfg in range(lib.ptx_conv3d_chain_num_configs()):
+        name = lib.ptx_conv3d_chain_config_name(cfg).decode()
+        assert name.endswith("/dma/chain")
+        bn_tile = int(name.split("x")[1])
+        ok = lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg)
+        assert bool(ok) == (_r4(N1) <= bn_tile), (name, N1)
+        if not ok:
+            yd = torch.zeros((N, To, Ho, Wo, ldy), device=DEV)
+            assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
+                                            _p(rd) if with_res else null, _p(yd), cfg, _st()) == 2      # refused, not mis-computed
+            continue
+        yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+        L.check(lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
+                                         _p(rd) if with_res else null, _p(yd), cfg, _st()), "chain " + name)
+        torch.cuda.synchronize()
+        got = from_cl(yd, Co2)
+        close(got, want, 2e-5)
+        assert bool((yd[..., Co2:_r4(Co2)] == 0).all()) and bool(torch.isnan(yd[..., _r4(Co2):]).all()), name   # pad cols zero, beyond untouched
+        ran += 1
+        base = name[:-len("/chain")]
+        if base in plain:                                # the two launches it replaces, same tile / MFMA shape: bit-identical
+            mid_g = hip_conv(ptx, x, w1, s_, p_, bn=bn1, relu=relu1, cfg=plain[base], split=1)
+            two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=plain[base], split=1)
+            assert torch.equal(got, two), (name, (got - two).abs().max().item())
+    assert ran >= 1
+    # config < 0: the library's own pick
+    yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+    L.check(lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
+                                     _p(rd) if with_res else null, _p(yd), -1, _st()), "chain auto")
+    torch.cuda.synchronize()
+    close(from_cl(yd, Co2), want, 2e-5)
+    # refused: a residual on the FIRST conv, a non-pointwise tail, mismatched positions
+    d.flags |= L.PTX_EPI_RES_ADD
+    assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0
+    d.flags &= ~L.PTX_EPI_RES_ADD
+    d2.Wi += 1
+    assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0

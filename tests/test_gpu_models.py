@@ -646,6 +646,41 @@ def test_biggan_generator_fp16(ptx):
     assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))
 
 
+def test_biggan_generator_full_batch_both_chunks(ptx):
+    """BASELINE config 5 at its own size: batch 64.  Engine.generate runs it as two 32-image chunks (the 256^2 stage of a
+    64-image batch exceeds the 2 GiB per-launch limit); ALL 64 images -- both chunks -- are compared with the stand-in
+    oracle (the second chunk used to go unchecked).  fp16 operands, the builder's 5e-2 bound (parity
+    unpinned: no BigGAN source in the reference snapshot), and every image must also equal the one a batch-32 call of
+    its own chunk produces (chunking is invisible)."""
+    from oracle import biggan_standin as BG
+    from pretorched_x_amd.testing import BIGGAN_RECIPE
+    G = ptx.biggan_deep(256, precision="fp16")
+    sd = synth_state_dict(G.state_dict(), 1234, **BIGGAN_RECIPE)
+    G.load_state_dict(sd)
+    G = G.to(DEV).eval()
+    g = torch.Generator().manual_seed(64)
+    z, lab = torch.randn(64, 128, generator=g), torch.randint(0, 1000, (64,), generator=g)
+    y = G.shared(lab.to(DEV))
+    img = G(z.to(DEV), y)
+    torch.cuda.synchronize()
+    assert tuple(img.shape) == (64, 3, 256, 256)
+    plans = list(G.engine()._plans.values())
+    assert len(plans) == 1 and plans[0].shape[0] in (32, 64)            # one plan; 32 = both chunks served by it
+    chunked = plans[0].shape[0] == 32
+    second = G(z[32:].to(DEV), y[32:])
+    assert torch.equal(img[32:], second) and torch.equal(img[:32], G(z[:32].to(DEV), y[:32]))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    got = img.cpu()
+    worst = 0.0
+    for i in range(0, 64, 8):                                            # bounded CPU memory: 8 images per oracle call
+        with torch.no_grad():
+            want = BG.forward(sd, z[i:i + 8], sd["shared.weight"][lab[i:i + 8]])
+        err = (got[i:i + 8] - want).abs()
+        worst = max(worst, err.max().item())
+        assert err.max().item() <= 5e-2 and err.mean().item() <= 3e-3, (i, err.max().item(), err.mean().item())
+    print("biggan-deep-256 fp16, batch 64 (%s): max|d image| over all 64 images = %.3e" % ("2 x 32" if chunked else "one launch set", worst))
+
+
 def test_dataparallel_replicas_share_one_plan_per_device(ptx):
     """torch.nn.DataParallel (reference examples/imagenet_eval.py:136, nonlocalnet.py:604) rebuilds its replicas
     on every forward and runs them from worker threads.  Two replicas on the one device of this box: across 3
