@@ -254,11 +254,12 @@ def main():
         plan.bind(model)
         with torch.cuda.device(dev):
             all_rows = eng.profile_steps(plan, iters=5)         # EVERY launch of the plan, convs and HBM passes alike
-        rows = [(lab, macs, ms, cfg, stp.split) for (lab, kind, nb, macs, ms, cfg), stp in
-                zip([r for r in all_rows if r[1] == "conv"], plan.conv_steps)]
+        conv_rows = [r for r in all_rows if r[1] == "conv"]          # (label, kind, bytes, macs, ms, tile, ConvStep)
+        all_rows = [r[:6] for r in all_rows]
+        rows = [(r[0], r[3], r[4], r[5], r[6].split) for r in conv_rows]
         if os.environ.get("PTX_BENCH_ROWS"):       # per-launch detail for tuning sessions
             with open(os.environ["PTX_BENCH_ROWS"], "w") as f:
-                for (label, macs, ms, cfg, split), stp in zip(rows, plan.conv_steps):
+                for (label, macs, ms, cfg, split), stp in zip(rows, [r[6] for r in conv_rows]):
                     f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
                         label, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
                         stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, split, ms, 2e-9 * macs / ms))
@@ -460,10 +461,12 @@ def main():
             plan3 = list(eng._plans.values())[-1]
             plan3.bind(model)
             with torch.cuda.device(dev):
-                rows3 = eng.profile_steps(plan3, iters=5)
+                rows3_full = eng.profile_steps(plan3, iters=5)
+                steps3 = [r[6] for r in rows3_full if r[1] == "conv"]
+                rows3 = [r[:6] for r in rows3_full]
             if os.environ.get("PTX_BENCH_ROWS"):
                 with open(os.environ["PTX_BENCH_ROWS"] + ".x3", "w") as f:
-                    for (lab, kind, nb, macs, ms, cfg), stp in zip([r for r in rows3 if r[1] == "conv"], plan3.conv_steps):
+                    for (lab, kind, nb, macs, ms, cfg), stp in zip([r for r in rows3 if r[1] == "conv"], steps3):
                         f.write("%-34s M=%-9d N=%-5d K=%-6d %-28s split=%d %8.4f ms %8.1f TF\n" % (
                             lab, stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo, stp.d.Co,
                             stp.d.Kc * stp.d.kT * stp.d.kH * stp.d.kW, cfg, stp.split, ms, 2e-9 * macs / ms))

@@ -18,13 +18,15 @@ namespace ptx {
 
 typedef int (*chain_launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool REPI>
 static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    // the parked intermediate tile aliases the two A stages when they are big enough (kernel: kAlias)
+    // the parked intermediate tile aliases the two A stages when they are big enough (kernel: kAlias); the row-major
+    // epilogue (REPI) adds one [MT][BN / WN + 4] parking block per wave behind everything else
     constexpr bool alias = BM * BN <= 2 * BM * BK;
-    constexpr size_t lds = lds_tiles + (alias ? 0 : (size_t)BM * BN * sizeof(float));
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, false, 0, true>;
+    constexpr size_t lds = lds_tiles + (alias ? 0 : (size_t)BM * BN * sizeof(float)) +
+                           (REPI ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0);
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, false, 0, true, REPI>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -36,10 +38,10 @@ static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     return hip_check(hipGetLastError(), "conv_chain launch");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool REPI>
 static int launch_chain(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true>(a, grid, st);
-    return launch_chain_one<BM, BN, BK, WM, WN, MT, false>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true, REPI>(a, grid, st);
+    return launch_chain_one<BM, BN, BK, WM, WN, MT, false, REPI>(a, grid, st);
 }
 
 struct ChainConfig {
@@ -48,7 +50,10 @@ struct ChainConfig {
     chain_launch_fn launch;
 };
 #define PTX_CHAIN_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT, false> }
+// the tail's epilogue row-major through LDS: 16-byte residual loads / output stores (conv_igemm_kernel.h, REPI)
+#define PTX_CHAIN_CFG_RE(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re", launch_chain<BM, BN, BK, WM, WN, MT, true> }
 
 static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG(64, 64, 32, 2, 2, 32),     // 0  the 3x3x3 -> 1x1x1 bottleneck tail at 64 planes (same tile as the tuned conv2)
@@ -60,6 +65,15 @@ static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG(32, 128, 32, 2, 2, 16),    // 6
     PTX_CHAIN_CFG(64, 32, 32, 2, 2, 16),     // 7  mid width <= 32 (64 -> 32 -> 64)
     PTX_CHAIN_CFG(64, 128, 16, 2, 2, 32),    // 8  mid widths up to 128, short K
+    PTX_CHAIN_CFG_RE(64, 64, 32, 2, 2, 32),  // 9
+    PTX_CHAIN_CFG_RE(64, 64, 16, 2, 2, 32),  // 10
+    PTX_CHAIN_CFG_RE(128, 64, 16, 2, 2, 32), // 11
+    PTX_CHAIN_CFG_RE(128, 64, 32, 4, 2, 32), // 12
+    PTX_CHAIN_CFG_RE(32, 64, 32, 2, 2, 16),  // 13
+    PTX_CHAIN_CFG_RE(64, 128, 32, 2, 2, 32), // 14
+    PTX_CHAIN_CFG_RE(32, 128, 32, 2, 2, 16), // 15
+    PTX_CHAIN_CFG_RE(64, 32, 32, 2, 2, 16),  // 16
+    PTX_CHAIN_CFG_RE(64, 128, 16, 2, 2, 32), // 17
 };
 constexpr int kNumChain = sizeof(kChain) / sizeof(kChain[0]);
 

@@ -82,13 +82,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p) {
 typedef int (*launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false, int KWR = 0>
+          bool X3 = false, int KWR = 0, bool REPI = false>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     // fp16 tiles: the fused epilogue parks one MT-row block per wave ([MT][BN / WN + 4] floats) in the tile buffers
     constexpr size_t lds_tiles = (size_t)NSTAGE * ((KWR ? (BM + BM / 4 + 15) / 16 * 16 : BM) + (KWR ? KWR : 1) * BN) * (DMA ? BK : BK + 4) * sizeof(float);
-    constexpr size_t lds_epi = F16 ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0;
+    // (the row-major fp32 epilogue, REPI, parks the same per-wave block)
+    constexpr size_t lds_epi = (F16 || REPI) ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0;
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3, KWR>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3, KWR, false, REPI>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -134,6 +135,14 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
         return launch_one<BM, BN, BK, WM, WN, MT, true, false, DMA, NSTAGE>(a, grid, st);
     return launch_one<BM, BN, BK, WM, WN, MT, false, false, DMA, NSTAGE>(a, grid, st);
+}
+
+// fp32 LDS-DMA tiles with the row-major epilogue (".../re"): bias + residual + ReLU through 16-byte accesses
+template <int BM, int BN, int BK, int WM, int WN, int MT, int NSTAGE>
+static int launch_cfg_re(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
+        return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, NSTAGE, false, false, 0, true>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, NSTAGE, false, false, 0, true>(a, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,6 +305,10 @@ struct ConvConfig {
 #define PTX_CFG_DMA4(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma4", launch_cfg<BM, BN, BK, WM, WN, MT, true, 4>, false, false, false, 0 }
 
+#define PTX_CFG_RE(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/re", launch_cfg_re<BM, BN, BK, WM, WN, MT, 2>, false, false, false, 0 }
+#define PTX_CFG_RE3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3/re", launch_cfg_re<BM, BN, BK, WM, WN, MT, 3>, false, false, false, 0 }
 #define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
     { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false, false, 0 }
 #define PTX_CFG_F16(BM, BN, BK, WM, WN, MT) \
@@ -456,6 +469,28 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_KWR_F16(128, 64, 32, 4, 2, 32),   // 124
     PTX_CFG_KWR_F16(256, 16, 32, 8, 1, 16),   // 125 the 3-channel image conv
     PTX_CFG_KWR_F16(128, 128, 16, 4, 2, 32),  // 126
+    // 144-wide N tiles: the (2+1)D mid widths are 144 * 2^k (r2plus1d.py:68-69); one workgroup covers a whole 144-column
+    // group, so the A tile crosses L2 -> LDS once instead of three times (48-wide tiles) and a wave's A fragment feeds
+    // 9 MFMA column blocks
+    PTX_CFG_DMA(64, 144, 32, 4, 1, 16),       // 127
+    PTX_CFG_DMA(128, 144, 32, 8, 1, 16),      // 128
+    // row-major epilogue (16-byte residual loads / output stores through a per-wave LDS transpose): the HBM-bound
+    // pointwise convs -- layer1's 1x1x1 convs, the (2+1)D temporal / pointwise convs, the conv3 + shortcut GEMMs
+    PTX_CFG_RE(128, 64, 16, 2, 2, 32),        // 129
+    PTX_CFG_RE3(128, 64, 16, 2, 2, 32),       // 130
+    PTX_CFG_RE(64, 64, 16, 2, 2, 32),         // 131
+    PTX_CFG_RE3(64, 64, 16, 2, 2, 32),        // 132
+    PTX_CFG_RE(64, 64, 32, 2, 2, 32),         // 133
+    PTX_CFG_RE(128, 64, 32, 4, 2, 32),        // 134
+    PTX_CFG_RE(128, 128, 16, 4, 2, 32),       // 135
+    PTX_CFG_RE(128, 128, 32, 4, 2, 32),       // 136
+    PTX_CFG_RE(64, 128, 16, 2, 2, 32),        // 137
+    PTX_CFG_RE(64, 128, 32, 2, 2, 32),        // 138
+    PTX_CFG_RE(32, 64, 32, 2, 2, 16),         // 139
+    PTX_CFG_RE(32, 64, 64, 2, 2, 16),         // 140
+    PTX_CFG_RE(32, 128, 32, 2, 2, 16),        // 141
+    PTX_CFG_RE(64, 32, 32, 2, 2, 16),         // 142
+    PTX_CFG_RE(112, 64, 32, 1, 4, 16),        // 143
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

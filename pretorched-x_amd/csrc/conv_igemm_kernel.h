@@ -325,6 +325,77 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-major epilogue for the fp32 tiles (REPI): bias + residual + ReLU with 16-byte accesses.
+// Straight from the MFMA layout a lane owns ONE column of 16 rows: the residual arrives as 16 four-byte loads and the
+// output leaves as 16 four-byte stores per accumulator tile -- the HBM-bound pointwise convs (layer1's 1x1x1 convs sit on
+// the fp32 ridge) ran at 4.3 TB/s on them.  Here a wave parks one MT-row block of its accumulators in
+// its own LDS slice ([MT][WTN + 4] floats), then every lane owns 4 consecutive channels of one row: residual, bias and
+// output move as 128-byte row segments, a quarter of the memory instructions.
+// `res4`: the residual values of the tile, requested by the caller in the SAME (i, pass) order before the accumulators are
+// final, so their latency hides under the k-loop's tail.
+// ------------------------------------------------------------------------------------------
+template <int WTN, int MT>
+struct RowEpi {
+    static constexpr int LDT = WTN + 4;          // staged row stride (floats): 16-byte aligned rows
+    static constexpr int LPR = WTN / 4;          // lanes per output row (4 channels each)
+    static constexpr int RPP = 64 / LPR;         // rows per pass
+    static constexpr int NP = (MT + RPP - 1) / RPP;
+    static constexpr int FLOATS = MT * LDT;      // LDS floats per wave
+    static_assert(WTN % 4 == 0 && 64 % LPR == 0 && LPR <= 64, "wave tile width");
+};
+
+template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+__device__ __forceinline__ void rowmajor_load_residual(f32x4* res4 /* [TM][NP] */, const __amdgpu_buffer_rsrc_t rs_r,
+                                                       bool has_res, int mbase, int co_base, int M, int ncol, int ldr, int lane) {
+    using RE = RowEpi<WTN, MT>;
+    constexpr unsigned kOOB = 0x80000000u;
+    const int co4 = co_base + (lane % RE::LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < RE::NP; ++ps) {
+            const int row = ps * RE::RPP + lane / RE::LPR;
+            const int m = mbase + i * MT + row;
+            const bool ok = has_res && row < MT && m < M && co4 < ncol;
+            const unsigned off = ((unsigned)m * (unsigned)ldr + (unsigned)co4) * 4u;
+            res4[i * RE::NP + ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? off : kOOB, 0, 0));
+        }
+}
+
+template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+__device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM][TN], const f32x4* res4 /* [TM][NP] */,
+                                                    float* Ls, const float* bias, const __amdgpu_buffer_rsrc_t rs_y, bool relu,
+                                                    int mbase, int co_base, int M, int ncol, int ldy, int lane) {
+    using RE = RowEpi<WTN, MT>;
+    constexpr unsigned kOOB = 0x80000000u;
+    const int cl = (lane % RE::LPR) * 4;
+    const int co4 = co_base + cl;
+    const bool c_ok = co4 < ncol;                 // ncol is a multiple of 4
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && c_ok) b4 = *reinterpret_cast<const f32x4*>(bias + co4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // park the row block: MFMA layout (lane = column) -> LDS.  The slice is private to the wave and a wave's LDS
+        // operations execute in order, so no barrier separates the stores from the loads below (or from the next block's)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) Ls[MF::row(r, lane) * RE::LDT + j * MT + (lane % MT)] = acc[i][j][r];
+#pragma unroll
+        for (int ps = 0; ps < RE::NP; ++ps) {
+            const int row = ps * RE::RPP + lane / RE::LPR;
+            const int m = mbase + i * MT + row;
+            const bool ok = c_ok && row < MT && m < M;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + (row < MT ? row : 0) * RE::LDT + cl) + b4 + res4[i * RE::NP + ps];
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const unsigned off = ((unsigned)m * (unsigned)ldy + (unsigned)co4) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_y,
+                                                   ok ? off : kOOB, 0, 0);
+        }
+    }
+}
+
 // F16: the A / B operands are IEEE halfs.  Everything that MOVES data (buffer loads, LDS-DMA, swizzle, tap
 // pruning, K tails) works on 32-bit words and does not care; the descriptor then counts channel PAIRS.  Only
 // the fragment -> MFMA step differs: the 16-byte fragment a lane reads is 8 halfs, consumed by ONE
@@ -354,9 +425,10 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
 // second conv's per-tile prologue disappear, and the HBM-bound tail (residual read + 4x wider write) overlaps the
 // MFMA-bound body of the co-resident workgroups.  fp32 tiles with 2-stage LDS-DMA only.
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false, int KWR = 0, bool CHAIN = false>
+          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !X3 && !K22 && KWR == 0), "chained tail: fp32 2-stage LDS-DMA tiles");
+    static_assert(!REPI || (DMA && !F16 && !X3 && !K22 && KWR == 0), "row-major epilogue: fp32 LDS-DMA tiles");
     static_assert(KWR == 0 || (KWR == 3 && DMA && NSTAGE == 2 && !K22), "kw-reuse tiles: 3-wide filters, 2-stage LDS-DMA");
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
     static_assert(!X3 || (DMA && !F16 && !K22), "split operands: LDS-DMA tiles");
@@ -732,7 +804,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                                                         rsrc_r, (res_add && co < p.ncol && m < p.M) ? off : kOOB, 0, 0));
         }
     };
-    if (kResEarly) {
+    // (REPI tiles fetch the residual row-major in their own epilogue; the column-wise prefetch only serves the paths that
+    // fall back to the column-wise epilogue: split-K partials and shortcut-A residuals)
+    const bool repi_fast = REPI && !CHAIN && !to_partial && !(p.flags & PTX_EPI_RES_PADA);
+    if (kResEarly && !repi_fast) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1085,10 +1160,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int j = 0; j < TN; ++j)
                 fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + koff);
         };
+        // REPI: the tail's epilogue runs row-major through a per-wave LDS slice behind P and the tile stages
+        using RE2 = RowEpi<WTN, MT>;
+        float* Ep = smem + NSTAGE * (ASTG + BSTG) + (kAlias ? 0 : BM * BN) + wave_u * RE2::FLOATS;
+        f32x4 res4c[REPI ? TM * RE2::NP : 1];
         int nc = 0, kc = 0;
         for (int s2 = 0; s2 < steps2; ++s2) {
             const int buf = s2 & 1;
-            if (kc == 0) {
+            if (REPI && kc == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
+                if constexpr (REPI)
+                    rowmajor_load_residual<MF, TM, TN, WTM, WTN, MT>(res4c, rsrc_r2, res2, m0 + wm * WTM, nc * BN + wn * WTN, p.M,
+                                                                     p.ncol2, p.ldr, lane);
+            }
+            if (!REPI && kc == 0) {
                 // a new 64-wide (BN) slice of the output: clear the accumulators, request its residual values -- their
                 // HBM latency hides under the slice's MFMAs
 #pragma unroll
@@ -1118,7 +1208,14 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             post_barrier_offsets(offa, offb);
             load_b2(s2 + 2, buf);
             ++kc;
-            if (kc == kc2) {
+            if (REPI && kc == kc2) {
+                if constexpr (REPI)
+                    rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT>(acc, res4c, Ep, p.bias2, rsrc_y2, relu2, m0 + wm * WTM,
+                                                                  nc * BN + wn * WTN, p.M, p.ncol2, p.ldy, lane);
+                kc = 0;
+                ++nc;
+            }
+            if (!REPI && kc == kc2) {
                 // ---- epilogue of output slice nc: bias2 + residual + ReLU ----
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -1164,6 +1261,22 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // stores are dropped, out-of-range loads read 0); residual values of a tile are requested in
     // one batch before they are consumed. ----
     // split-K partial slabs are dense [M][ncol]; the final tensor has row stride ldy
+    if constexpr (REPI && !CHAIN) {
+        if (repi_fast) {
+            using RE = RowEpi<WTN, MT>;
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)zb * p.bs_y, 0, p.y_bytes, 0x00020000);
+            f32x4 res4[TM * RE::NP];
+            rowmajor_load_residual<MF, TM, TN, WTM, WTN, MT>(res4, rsrc_r, res_add, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol, p.ldr, lane);
+            // every wave is done with the operand tiles and the trailing (zero-writing) DMAs have landed: the tile buffers
+            // become the waves' parking slices
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * RE::NP) : "memory");      // (the residual loads just issued may stay in flight)
+            __syncthreads();
+            rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT>(acc, res4, smem + wave_u * RE::FLOATS, p.bias, rs_y,
+                                                          (p.flags & PTX_EPI_RELU) != 0, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol,
+                                                          p.ldy, lane);
+            return;
+        }
+    }
     float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ncol : p.y + (size_t)zb * p.bs_y;
     const unsigned ldo = to_partial ? (unsigned)p.ncol : (unsigned)p.ldy;
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);

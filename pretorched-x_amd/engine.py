@@ -443,6 +443,36 @@ class ChainStep:
                                               self.res, self.y, self.cfg, st), self.label)
 
 
+class AltStep:
+    """A conv -> 1x1x1 conv pair with two compiled executions: ONE chained launch (ChainStep) or the two launches it
+    replaces (ConvSteps through an intermediate tensor).  Which one runs is a tuning decision like the tile choice --
+    measured per problem pair by Engine.autotune, remembered in the tuned table ("alt:" keys), and defaulted by the
+    measured rule of thumb: chained up to 64 intermediate channels (round 3, MI355X: 64-plane bottleneck tails and the
+    (2+1)D pairs through <= 64 mid channels gain 10-30 %, 128-wide intermediate tiles lose a few per cent)."""
+    __slots__ = ("chain", "pair", "use_chain", "label", "key")
+
+    def __call__(self, st):
+        if self.use_chain:
+            self.chain(st)
+        else:
+            for s in self.pair:
+                s(st)
+
+    def active(self):
+        return [self.chain] if self.use_chain else list(self.pair)
+
+
+def alt_lookup(key):
+    ent = _tuned_table().get("alt:" + key)
+    return None if ent is None else ent[0] == "chain"
+
+
+def alt_store(key, use_chain):
+    table = _tuned_table()
+    with _tuned_lock:
+        table["alt:" + key] = ("chain" if use_chain else "pair", 1)
+
+
 class StemStep:
     """One ptx_conv_stem_x3_fwd launch (split-operand stem read from 4-channel positions)."""
     __slots__ = ("d", "x", "w", "b", "y", "label", "macs", "hbm_bytes")
@@ -491,6 +521,7 @@ class Plan:
         self.steps = []          # callables(stream)
         self.conv_steps = []
         self.chain_steps = []    # ChainStep launches (two convs each; tuned over their own tile table)
+        self.alt_steps = []      # AltStep: chained launch | the two launches, chosen by measurement
         # chained convs (conv -> 1x1x1 conv in one launch): fp32 plans; PTX_CHAIN=0 keeps every conv its own launch
         self.chain = os.environ.get("PTX_CHAIN", "1") != "0" and getattr(engine, "precision", "fp32") == "fp32"
         self.packs = []
@@ -674,8 +705,9 @@ class Plan:
         return (y, raw_act) if raw else y
 
     def conv_chain(self, x, pk, stride, padding, pk2, relu1=True, relu2=False, res=None, label="chain", y=None):
-        """conv(x, pk) -> [ReLU] -> 1x1x1 conv (pk2) -> [+ res] -> [ReLU] as ONE launch (ptx_conv3d_chain_fwd), or None when
-        the pair does not qualify -- the caller then emits the two convs separately.  Qualifies: fp32 plan, dense unfolded
+        """conv(x, pk) -> [ReLU] -> 1x1x1 conv (pk2) -> [+ res] -> [ReLU] as ONE launch (ptx_conv3d_chain_fwd): returns (output
+        activation, ChainStep) -- the step is NOT appended to the plan; the caller also emits the two separate launches into
+        the same output and wraps both with Plan.alt() -- or None when the pair does not qualify.  Qualifies: fp32 plan, dense unfolded
         filters, a pointwise tail whose K axis is the first conv's output, at most 128 intermediate channels (one N tile
         holds the whole intermediate row), a same-shape residual (or none), and enough rows to fill the chip from M tiles
         alone (the tail's N slices run inside one workgroup: M >= PTX_CHAIN_MIN_M, default 8192)."""
@@ -730,9 +762,24 @@ class Plan:
         st.res = _ptr(res.t) if res is not None else C.c_void_p(0)
         st.macs = M * (pk.Co * getattr(pk, "real_ci", pk.Ci) * kT * kH * kW + pk2.Co * pk.Co)
         st.hbm_bytes = 0
-        self.steps.append(st)
         self.chain_steps.append(st)
-        return y
+        return y, st
+
+    def alt(self, chain, first_step, label):
+        """Wrap the plan steps emitted since `first_step` (the two separate launches of a pair) and its chained launch into
+        ONE AltStep; the choice comes from the tuned table, else the measured default (chained up to 64 mid channels)."""
+        pair = self.steps[first_step:]
+        del self.steps[first_step:]
+        a = AltStep()
+        a.chain, a.pair, a.label, a.key = chain, pair, label, chain.key
+        known = alt_lookup(chain.key)
+        a.use_chain = known if known is not None else (_r4(chain.d.Co) <= int(os.environ.get("PTX_CHAIN_DEFAULT_MAX_N1", "64")))
+        force = os.environ.get("PTX_CHAIN_FORCE")          # "1" / "0": A/B runs
+        if force in ("0", "1"):
+            a.use_chain = force == "1"
+        self.steps.append(a)
+        self.alt_steps.append(a)
+        return a
 
     def conv_bn(self, x, conv, bn, relu=False, res=None, res_kind=None, res_stride=1, label="conv", y=None):
         """nn.Conv{2,3}d or a (2+1)D pair, followed by `bn`, with the epilogue fused."""
@@ -746,7 +793,11 @@ class Plan:
                 yc = self.conv_chain(x, self.pack(conv.spatial_conv, conv.bn), tuple(a * b for a, b in zip(ss, st_)), (0, 0, 0),
                                      self.pack(conv.temporal_conv, bn), relu1=True, relu2=relu, res=res, label=label + ".pair", y=y)
                 if yc is not None:
-                    return yc
+                    y, first = yc[0], len(self.steps)
+                    mid = self.conv(x, self.pack(conv.spatial_conv, conv.bn), ss, ps, relu=True, label=label + ".spatial")
+                    self.conv(mid, self.pack(conv.temporal_conv, bn), st_, pt, relu=relu, res=res, label=label + ".temporal", y=y)
+                    self.alt(yc[1], first, label + ".pair")
+                    return y
             mid = self.stem_direct(x, conv.spatial_conv, conv.bn, True, label + ".spatial") if fold else None
             if mid is None:
                 mid = self.conv(x if not fold else self.fold_input(x, conv.spatial_conv),
@@ -1180,12 +1231,12 @@ class Plan:
                 k2, s2, p2 = _geom(blk.conv2)
                 tail = self.conv_chain(o, self.pack(blk.conv2, blk.bn2), s2, p2, self.pack(blk.conv3, blk.bn3), relu1=True,
                                        relu2=True, res=res, label=name + ".conv2+conv3", y=out)
+            first = len(self.steps)
+            o2 = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
+            o = self.conv_bn(o2, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
+                             label=name + ".conv3", y=out if tail is None else tail[0])
             if tail is not None:
-                o = tail
-            else:
-                o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
-                o = self.conv_bn(o, blk.conv3, blk.bn3, relu=True, res=res, res_kind=kind, res_stride=s,
-                                 label=name + ".conv3", y=out)
+                self.alt(tail[1], first, name + ".conv2+conv3")
         else:
             o = self.conv_bn(x, blk.conv1, blk.bn1, relu=True, label=name + ".conv1")
             o = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, res=res, res_kind=kind, res_stride=s,
@@ -1255,7 +1306,12 @@ class Plan:
     def all_convs(self):
         """Every convolution launch of the plan in execution order: the implicit-GEMM steps (`conv_steps`, what the
         autotuner owns) and the direct stem kernels."""
-        return [s for s in self.steps if isinstance(s, (ConvStep, ChainStep, StemStep, StemF32Step))]
+        out = []
+        for s in self.steps:
+            for t in (s.active() if isinstance(s, AltStep) else [s]):
+                if isinstance(t, (ConvStep, ChainStep, StemStep, StemF32Step)):
+                    out.append(t)
+        return out
 
     def refresh_weights(self, model):
         """Re-pack every filter (and rebuild the weight-derived tables) from `model`'s current tensors."""
@@ -1601,7 +1657,8 @@ class Engine:
             if plan.tuned:
                 return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
-                   for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps):
+                   for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
+                    or any(alt_lookup(a.key) is None for a in plan.alt_steps):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
 
@@ -1854,6 +1911,32 @@ class Engine:
                     if verbose:
                         print("tune %-34s -> %-28s %.3f ms  %.1f TF" % (stp.label, lib.ptx_conv3d_chain_config_name(best[1]).decode(),
                                                                        best[0], 2e-9 * stp.macs / best[0]))
+            # chained launch vs the two launches it replaces: time both executions of every pair, keep the faster
+            force = os.environ.get("PTX_CHAIN_FORCE")
+            seen_a = {}
+            for a in plan.alt_steps:
+                if a.key in seen_a:
+                    a.use_chain = seen_a[a.key]
+                    continue
+                if force in ("0", "1") or (only_untuned and alt_lookup(a.key) is not None):
+                    continue
+                ms2 = []
+                for run in (a.chain, lambda st_: [s_(st_) for s_ in a.pair]):
+                    run(_stream())
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(max(iters, 3)):
+                        run(_stream())
+                    e1.record()
+                    e1.synchronize()
+                    ms2.append(e0.elapsed_time(e1) / max(iters, 3))
+                a.use_chain = ms2[0] < ms2[1]
+                seen_a[a.key] = a.use_chain
+                alt_store(a.key, a.use_chain)
+                if log is not None:
+                    log.write("%s\tchain %.4f ms\tpair %.4f ms\t-> %s\n" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
+                if verbose:
+                    print("tune %-34s chain %.4f ms | pair %.4f ms -> %s" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
             plan.run_features(_dense16(x))
             plan.tuned = True
             if log is not None:
@@ -1891,7 +1974,8 @@ class Engine:
         implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
         rows = []
         st = _stream()
-        for stp in plan.steps:
+        flat = [t for s in plan.steps for t in (s.active() if isinstance(s, AltStep) else [s])]
+        for stp in flat:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             stp(st)
             e0.record()
@@ -1901,7 +1985,7 @@ class Engine:
             e1.synchronize()
             ms = e0.elapsed_time(e1) / iters
             if isinstance(stp, ConvStep):
-                rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode()))
+                rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp))
             elif isinstance(stp, (StemStep, StemF32Step)):      # the direct stems are convs too, with their own kernels
                 rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
             elif isinstance(stp, ChainStep):                    # two convs in one launch, its own tile table

@@ -103,10 +103,10 @@ for name, build, recipe, shape in CASES:
     eng = (m.base_model if hasattr(m, "base_model") else m).engine()
     plans = list(eng._plans.values())
     from pretorched_x_amd.engine import StemStep, StemF32Step       # the direct stems are convs too (not in conv_steps)
-    gflop = sum(2e-9 * s.macs for p in plans for s in list(p.conv_steps) + [t for t in p.steps if isinstance(t, (StemStep, StemF32Step))])
+    gflop = sum(2e-9 * s.macs for p in plans for s in p.all_convs())     # the launches that run (chained pairs count once)
     rows.append(dict(model=name, input=list(shape), ms_per_step=round(ms, 3), units_per_s=round(shape[0] * 1e3 / ms, 1),
                      gflop_per_step=round(gflop, 1), tflops=round(gflop / ms, 1), frac_fp32_mfma=round(gflop / ms / 157.3, 3),
-                     conv_launches=sum(len(p.conv_steps) for p in plans), first_call_s=round(t_first, 1),
+                     conv_launches=sum(len(p.all_convs()) for p in plans), first_call_s=round(t_first, 1),
                      cpu_units_per_s=None if cpu_units is None else round(cpu_units, 2), cpu_threads=CPU_THREADS,
                      finite=bool(torch.isfinite(y).all())))
     print("%-28s %-22s %9.3f ms  %8.1f /s  %8.1f GFLOP  %6.1f TF (%4.1f%%)  launches %d  cpu %s /s on %d threads" % (

@@ -248,11 +248,16 @@ def test_plan_compiler_matches_survey_worklist(ptx):
     plan = m.engine().dry_plan(m, (8, 3, 16, 224, 224))
     # round 3: bottleneck tails conv2 -> conv3 (+ residual) of the blocks without a shortcut conv run as ONE chained launch
     # where the intermediate row fits a tile (<= 128 planes) and M fills the chip: layer1.{1,2}, layer2.{1,2,3}
-    from pretorched_x_amd.engine import ChainStep
-    chains = [s for s in plan.steps if isinstance(s, ChainStep)]
+    # BOTH executions of such a pair are compiled (AltStep): which one runs is measured by the tuner; untuned, the default
+    # is the measured rule -- chained up to 64 intermediate channels (layer1), two launches above (layer2)
+    from pretorched_x_amd.engine import AltStep, ChainStep
+    chains = plan.chain_steps
     assert [s.label for s in chains] == ["layer%d.%d.conv2+conv3" % lb for lb in ((1, 1), (1, 2), (2, 1), (2, 2), (2, 3))]
     assert (chains[0].d.kT, chains[0].d.Co, chains[0].d2.Co, chains[0].d2.flags) == (3, 64, 256, 3)       # RELU | RES_ADD
-    assert len(plan.conv_steps) == 38 and len(convs(plan)) == 44
+    alts = [s for s in plan.steps if isinstance(s, AltStep)]
+    assert len(alts) == 5 and [a.use_chain for a in alts] == [True, True, False, False, False]
+    assert all(len(a.pair) == 2 and a.pair[1].d.flags & 2 for a in alts)                                  # conv2, conv3 + residual
+    assert len(plan.conv_steps) == 48 and len(convs(plan)) == 47 and sum(isinstance(s, ChainStep) for s in convs(plan)) == 2
     os.environ["PTX_CHAIN"] = "0"
     try:
         m0 = ptx.resnet3d50(num_classes=339, pretrained=None)
@@ -369,7 +374,7 @@ def test_slowfast_plan_wiring_without_gpu(ptx, monkeypatch):
     planc = m.engine().dry_plan(m, (2, 3, 64, 224, 224))
     # chained bottleneck tails write the concat slices too: the slow pathway's 64 / 128-plane blocks and the fast pathway's
     # 32 / 64-plane ones (narrower planes keep their 16-wide / direct tiles)
-    ch = {s.label: s for s in planc.steps if isinstance(s, ChainStep)}
+    ch = {s.label: s for s in planc.chain_steps}
     assert ch["slow.res2.2.conv2+conv3"].d2.ldy == 320 and ch["slow.res2.2.conv2+conv3"].d.Co == 64
     assert all(32 <= s.d.Co <= 128 for s in ch.values()) and not any(l.startswith("fast.res2") for l in ch)
     monkeypatch.setenv("PTX_CHAIN", "0")             # the rest of this test reads the one-launch-per-conv wiring
@@ -493,7 +498,7 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
     # the stem leaves the implicit-GEMM list: ptx_conv_stem_x3_fwd reads 4-channel positions, no kW fold
     # (split-operand plans keep one launch per conv: the chained tiles are fp32-MFMA tiles)
-    assert plan.x3 and not plan.chain_steps and len(plan.conv_steps) == len(base.conv_steps) + 2 * len(base.chain_steps)
+    assert plan.x3 and not plan.chain_steps and len(plan.conv_steps) == len(base.conv_steps)
     assert plan.stem_steps == 1
     stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
     assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"
@@ -504,7 +509,7 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     assert sum(s.macs for s in plan.conv_steps) + stem.macs == sum(s.macs for s in base.all_convs())
     monkeypatch.setenv("PTX_STEM_DIRECT", "0")               # the folded implicit-GEMM stem on 32-float rows
     folded = eng.dry_plan(m, (2, 3, 16, 224, 224))
-    assert len(folded.conv_steps) == len(base.all_convs()) + len(base.chain_steps)
+    assert len(folded.conv_steps) == len(base.all_convs()) + sum(a.use_chain for a in base.alt_steps)
     assert (folded.conv_steps[0].d.Kc, folded.conv_steps[0].d.ldx, folded.conv_steps[0].d.Ci) == (32, 32, 21)
     monkeypatch.delenv("PTX_STEM_DIRECT")
     # grouped convs (ResNeXt3D) are not split: they stay on the fp32 / direct tiles

@@ -207,7 +207,11 @@ def test_conv_dma_bit_exact_vs_register_staged(ptx):
                  "64x64x16/2x2/m32/dma3", "64x64x32/2x2/m32/dma3", "128x64x32/4x2/m32/dma3",
                  "128x128x32/4x2/m32/dma3", "64x128x16/2x2/m32/dma3", "128x64x16/2x2/m32/dma3",
                  "64x64x32/2x2/m32/dma4", "64x64x16/2x2/m32/dma4", "64x128x32/2x2/m32/dma4",
-                 "64x64x64/2x2/m32/dma", "64x128x64/2x2/m32/dma", "128x64x64/4x2/m32/dma"):
+                 "64x64x64/2x2/m32/dma", "64x128x64/2x2/m32/dma", "128x64x64/4x2/m32/dma",
+                 # row-major epilogue (LDS transpose, 16-byte stores): same arithmetic, same bits
+                 "64x64x32/2x2/m32/dma/re", "64x64x16/2x2/m32/dma/re", "64x64x16/2x2/m32/dma3/re", "128x64x16/2x2/m32/dma/re",
+                 "128x64x16/2x2/m32/dma3/re", "128x64x32/4x2/m32/dma/re", "128x128x16/4x2/m32/dma/re",
+                 "128x128x32/4x2/m32/dma/re", "64x128x16/2x2/m32/dma/re", "64x128x32/2x2/m32/dma/re"):
         for rep in range(6):
             got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
             assert torch.equal(got, base), "%s differs from the register-staged result (rep %d)" % (name, rep)
@@ -215,7 +219,9 @@ def test_conv_dma_bit_exact_vs_register_staged(ptx):
     base16 = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index("112x64x32/1x4/m16"), split=1)
     for name in ("32x64x32/2x2/m16/dma", "112x64x32/1x4/m16/dma", "32x128x32/2x2/m16/dma", "64x32x32/2x2/m16/dma",
                  "32x64x32/2x2/m16/dma3", "32x64x32/2x2/m16/dma4", "32x128x32/2x2/m16/dma4",
-                 "32x64x64/2x2/m16/dma", "32x128x64/2x2/m16/dma"):
+                 "32x64x64/2x2/m16/dma", "32x128x64/2x2/m16/dma",
+                 "32x64x32/2x2/m16/dma/re", "32x64x64/2x2/m16/dma/re", "32x128x32/2x2/m16/dma/re", "64x32x32/2x2/m16/dma/re",
+                 "112x64x32/1x4/m16/dma/re", "64x144x32/4x1/m16/dma", "128x144x32/8x1/m16/dma"):
         for rep in range(6):
             got = hip_conv(ptx, x, w, (1, 1, 1), (1, 1, 1), bn=bn, relu=True, cfg=names.index(name), split=1)
             assert torch.equal(got, base16), "%s differs (rep %d)" % (name, rep)
@@ -1506,7 +1512,8 @@ def test_conv_chain(ptx, case):
     ran = 0
     for cfg in range(lib.ptx_conv3d_chain_num_configs()):
         name = lib.ptx_conv3d_chain_config_name(cfg).decode()
-        assert name.endswith("/dma/chain")
+        core = name[:-3] if name.endswith("/re") else name           # ".../chain/re": the tail's epilogue row-major through LDS
+        assert core.endswith("/dma/chain")
         bn_tile = int(name.split("x")[1])
         ok = lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg)
         assert bool(ok) == (_r4(N1) <= bn_tile), (name, N1)
@@ -1523,7 +1530,7 @@ def test_conv_chain(ptx, case):
         close(got, want, 2e-5)
         assert bool((yd[..., Co2:_r4(Co2)] == 0).all()) and bool(torch.isnan(yd[..., _r4(Co2):]).all()), name   # pad cols zero, beyond untouched
         ran += 1
-        base = name[:-len("/chain")]
+        base = core[:-len("/chain")]
         if base in plain:                                # the two launches it replaces, same tile / MFMA shape: bit-identical
             mid_g = hip_conv(ptx, x, w1, s_, p_, bn=bn1, relu=relu1, cfg=plain[base], split=1)
             two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=plain[base], split=1)

@@ -667,8 +667,10 @@ def test_biggan_generator_full_batch_both_chunks(ptx):
     plans = list(G.engine()._plans.values())
     assert len(plans) == 1 and plans[0].shape[0] in (32, 64)            # one plan; 32 = both chunks served by it
     chunked = plans[0].shape[0] == 32
-    second = G(z[32:].to(DEV), y[32:])
-    assert torch.equal(img[32:], second) and torch.equal(img[:32], G(z[:32].to(DEV), y[:32]))
+    # chunking is invisible: an image of the 64-batch == the same image from a direct call of its own 32-image chunk, up to
+    # the last bits of the fp16 operand roundings (measured 1.5e-4; see scripts/gpu_biggan_chunk_probe.py)
+    second, first = G(z[32:].to(DEV), y[32:]), G(z[:32].to(DEV), y[:32])
+    assert (img[32:] - second).abs().max().item() <= 2e-3 and (img[:32] - first).abs().max().item() <= 2e-3
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     got = img.cpu()
     worst = 0.0
