@@ -23,6 +23,7 @@
 // rescaled by exp(m_old - m_new) only when some query's maximum moved).
 #include "ptx_common.h"
 #include <cfloat>
+#include <cstdlib>
 
 namespace ptx {
 
@@ -79,11 +80,18 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, half4
 // nonlocalnet.py:168-190): a wave's 16 theta rows no longer fit its registers (D / 4 VGPRs), so the B fragments of
 // S^T = phi . theta^T are fetched with 16-byte buffer loads inside the d loop (L2-resident: 64 queries x 4 KiB per
 // workgroup) instead of living in registers.  Same arithmetic and summation order as the register variant.
-template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false>
-__global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
+// KS ("key split", 2): 8 waves per workgroup -- wave group g = wave / 4 takes keys [16g, 16g + 16) of every 32-key tile for
+// the SAME 64 queries, each group with its own online-softmax state, merged once at the end through LDS.  Why: a wave is a
+// serial chain of Nk / 16 tiles x 128 MFMAs, and config 3's layer2 blocks launch only batch x ceil(1568 / 64) = 200
+// workgroups -- 800 waves on 1024 SIMDs, one wave per SIMD, nothing to cover its softmax / LDS / barrier bubbles (measured:
+// MFMA pipe 57 % busy, 53 % of the fp32 peak).  Split, every active SIMD holds two waves of half the length.
+template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false, int KS = 1>
+__global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) {
     constexpr bool F16 = MODE == 1, X3 = MODE == 2;
     static_assert(!TG || MODE == 0, "theta-from-global is an fp32 variant");
-    constexpr int TK = 16;                   // keys per tile
+    static_assert(KS == 1 || (KS == 2 && !TG), "key split: two wave groups");
+    constexpr int TK = 16 * KS;              // keys per tile
+    constexpr int NW = 4 * KS;               // waves per workgroup
     constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
     constexpr int CB = DV / 64;              // 64-channel output super-blocks (one ds_read_b128 + 4 MFMAs per key group)
     constexpr int F4R = D / 4;               // 16-byte slots per key row
@@ -101,7 +109,8 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     const int b = tile / p.q_tiles, qt = tile - b * p.q_tiles;
     const int c0 = blockIdx.y * DV;          // output-channel chunk of this workgroup
     const int n = lane & 15, gq = lane >> 4;
-    const int q = qt * 64 + wave * 16 + n;   // this lane's query (as MFMA column / A row)
+    const int grp = wave >> 2, wq = wave & 3;                        // key group (KS == 2), query sub-tile of the wave
+    const int q = qt * 64 + wq * 16 + n;     // this lane's query (as MFMA column / A row)
 
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.theta + (size_t)b * p.bs_t), 0, p.t_bytes, 0x00020000);
@@ -136,18 +145,18 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     auto swz = [&](int row, int slot) -> int {
         return F4R >= 16 ? (slot ^ (row & 15)) : F4R == 8 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
     };
-    constexpr int KPW = (NKP + 3) / 4, VPW = (NVP + 3) / 4;       // pieces per wave
+    constexpr int KPW = (NKP + NW - 1) / NW, VPW = (NVP + NW - 1) / NW;       // pieces per wave
     unsigned koff[KPW], voff[VPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        const int f = (wave + 4 * i) * 256 + lane * 4;            // float index in the linear [TK][D] image
+        const int f = (wave + NW * i) * 256 + lane * 4;           // float index in the linear [TK][D] image
         const int row = f / D, slot = (f % D) / 4;
         const int col = swz(row, slot) * 4;                       // logical column this physical slot holds
         koff[i] = col < p.d ? ((unsigned)row * (unsigned)p.ld_p + (unsigned)col) * 4u : kOOB;
     }
 #pragma unroll
     for (int i = 0; i < VPW; ++i) {
-        const int f = (wave + 4 * i) * 256 + lane * 4;
+        const int f = (wave + NW * i) * 256 + lane * 4;
         const int row = f / DV, col = c0 + f % DV;
         voff[i] = col < p.dv ? ((unsigned)row * (unsigned)p.ld_g + (unsigned)col) * 4u : kOOB;
     }
@@ -155,12 +164,12 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         const unsigned kbase = (unsigned)t * TK * (unsigned)p.ld_p * 4u, vbase = (unsigned)t * TK * (unsigned)p.ld_g * 4u;
 #pragma unroll
         for (int i = 0; i < KPW; ++i)
-            if (wave + 4 * i < NKP)
-                dma16(rs_p, Ks + buf * TK * D + (wave + 4 * i) * 256, koff[i] == kOOB ? kOOB : koff[i] + kbase);
+            if (wave + NW * i < NKP)
+                dma16(rs_p, Ks + buf * TK * D + (wave + NW * i) * 256, koff[i] == kOOB ? kOOB : koff[i] + kbase);
 #pragma unroll
         for (int i = 0; i < VPW; ++i)
-            if (wave + 4 * i < NVP)
-                dma16(rs_g, Vs + buf * TK * DV + (wave + 4 * i) * 256, voff[i] == kOOB ? kOOB : voff[i] + vbase);
+            if (wave + NW * i < NVP)
+                dma16(rs_g, Vs + buf * TK * DV + (wave + NW * i) * 256, voff[i] == kOOB ? kOOB : voff[i] + vbase);
     };
 
     f32x4 O[CB][4];
@@ -174,8 +183,8 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     const int n_tiles = (p.Nk + TK - 1) / TK;
     issue_tile(0, 0);
     // fragment read offsets (floats): phi row = n, slot (4j + gq) ^ swizzle;  g row = 4*gq + r, slot cb*16 + n
-    const int k_row_off = n * D;
-    const int v_row_off = (4 * gq) * DV + n * 4;
+    const int k_row_off = (16 * grp + n) * D;                     // (16 * grp is a multiple of every swizzle period)
+    const int v_row_off = (16 * grp + 4 * gq) * DV + n * 4;
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         // tile t landed: every wave waits for its own DMA pieces, then the barrier; buffer buf^1 is free (its last
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
 
         float pr[4];
         if constexpr (SOFTMAX) {
-            const int key0 = t * TK + 4 * gq;
+            const int key0 = t * TK + 16 * grp + 4 * gq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[r] = (key0 + r < p.Nk) ? s[r] : -INFINITY;
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
@@ -299,6 +308,41 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
         }
     }
 
+    if constexpr (KS == 2) {
+        // ---- merge the two key groups: group 1 parks (m, l, O) lane-linearly in the (idle) tile buffers, group 0 folds
+        // them in:  M = max(m0, m1),  l = l0 e^(m0 - M) + l1 e^(m1 - M),  O likewise per query row ----
+        __syncthreads();                                  // every wave is done with the last tile
+        float* Mx = smem + wq * (64 * (CB * 16 + 2));     // per query sub-tile: [CB * 16 + 2][64 lanes]
+        if (grp == 1) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Mx[((cb * 4 + e) * 4 + r) * 64 + lane] = O[cb][e][r];
+            Mx[(CB * 16) * 64 + lane] = m_run;
+            Mx[(CB * 16 + 1) * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = Mx[(CB * 16) * 64 + lane], l1 = Mx[(CB * 16 + 1) * 64 + lane];
+        float a0 = 1.f, a1 = 1.f;
+        if constexpr (SOFTMAX) {
+            const float M = fmaxf(m_run, m1);             // finite: group 0 always owns at least one valid key
+            a0 = __expf(m_run - M);
+            a1 = __expf(m1 - M);                          // exp(-inf) = 0 when group 1 saw no key
+            l_run = l_run * a0 + l1 * a1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b0 = SOFTMAX ? __shfl(a0, 4 * gq + r, 64) : 1.f, b1 = SOFTMAX ? __shfl(a1, 4 * gq + r, 64) : 1.f;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    O[cb][e][r] = O[cb][e][r] * b0 + Mx[((cb * 4 + e) * 4 + r) * 64 + lane] * b1;
+        }
+    }
     // ---- epilogue: 1 / l per query, 16-byte stores (lane: query 4*gq + r, channels cb*64 + 4*n .. +3) ----
     float inv = 1.f;
     if constexpr (SOFTMAX) {
@@ -311,7 +355,7 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float iv = SOFTMAX ? __shfl(inv, 4 * gq + r, 64) : (X3 ? inv_nk : 1.f);
-        const int qo = qt * 64 + wave * 16 + 4 * gq + r;
+        const int qo = qt * 64 + wq * 16 + 4 * gq + r;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int ch = c0 + cb * 64 + 4 * n;
@@ -323,25 +367,37 @@ __global__ void __launch_bounds__(256) nl_attention_kernel(const NlArgs p) {
     }
 }
 
-template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false>
+template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false, int KS = 1>
 static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 16 * (D + DV) * sizeof(float);
+    constexpr size_t lds_t = (size_t)2 * 16 * KS * (D + DV) * sizeof(float);
+    constexpr size_t lds_m = KS == 2 ? (size_t)4 * 64 * ((DV / 64) * 16 + 2) * sizeof(float) : 0;     // the groups' merge buffer
+    constexpr size_t lds = lds_t > lds_m ? lds_t : lds_m;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     const dim3 grid((unsigned)(a.q_tiles * a.batch), (unsigned)cdiv(a.dv, DV));
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, MODE, TG>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_attention_kernel<D, DV, SOFTMAX, MODE, TG, KS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, MODE, TG>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nl_attention_kernel<D, DV, SOFTMAX, MODE, TG, KS>), grid, dim3(256 * KS), lds, st, a);
     return hip_check(hipGetLastError(), "nonlocal attention launch");
 }
 
 template <int D, int DV>
 static int launch_nl(const NlArgs& a, hipStream_t st) {
     return a.scale_only ? launch_nl_mode<D, DV, false>(a, st) : launch_nl_mode<D, DV, true>(a, st);
+}
+// key-split variants (8 waves, two key groups): chosen when the plain grid leaves the chip at one wave per SIMD
+template <int D, int DV>
+static int launch_nl_ks(const NlArgs& a, hipStream_t st) {
+    return a.scale_only ? launch_nl_mode<D, DV, false, 0, false, 2>(a, st) : launch_nl_mode<D, DV, true, 0, false, 2>(a, st);
+}
+template <int D, int DV>
+static int launch_nl_ks_x3(const NlArgs& a, hipStream_t st) {
+    return a.scale_only ? launch_nl_mode<D, DV, false, 2, false, 2>(a, st) : launch_nl_mode<D, DV, true, 2, false, 2>(a, st);
 }
 template <int D, int DV>
 static int launch_nl_tg(const NlArgs& a, hipStream_t st) {
@@ -396,6 +452,15 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     // d > 512 ('gaussian' mode at C = 1024): theta fragments come from global memory; fp32 MFMAs whatever the plan's
     // precision (the split-operand mode is fp32-accurate by contract, so the exact kernel is a valid stand-in)
     if (d->d > 512) return launch_nl_tg<1024, 128>(a, st);
+    // key split (two wave groups over the key tiles): when the plain grid is below two workgroups per CU -- i.e. one wave
+    // per SIMD -- and there are enough keys to split.  PTX_NL_KSPLIT=0 / 1 forces it off / on (A/B runs).
+    static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
+    const int64_t wgs = (int64_t)a.q_tiles * a.batch * cdiv(a.dv, d->dv <= 128 ? 128 : 256);
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && wgs < 2 * kNumCU && a.Nk >= 128);
+    if (ksplit && d->d > 64 && d->d <= 256) {
+        if (d->mode & PTX_NL_X3) return d->dv <= 128 ? launch_nl_ks_x3<256, 128>(a, st) : launch_nl_ks_x3<256, 256>(a, st);
+        return d->dv <= 128 ? launch_nl_ks<256, 128>(a, st) : launch_nl_ks<256, 256>(a, st);
+    }
     if (d->mode & PTX_NL_X3) {           // split operands: the same tile family as the fp32 kernel
         if (d->d <= 32 && d->dv <= 128 && d->dv > 64) return launch_nl_x3<32, 128>(a, st);
         if (d->d <= 64) return d->dv <= 64 ? launch_nl_x3<64, 64>(a, st) : launch_nl_x3<64, 256>(a, st);

@@ -224,8 +224,14 @@ def test_tuned_table_stores_config_names(ptx):
     assert len(table) >= 400
     lib = ptx._lib.lib()
     names = {lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())}
-    assert all(isinstance(v[0], str) and v[0] in names and v[1] >= 1 for v in table.values())
-    key = next(iter(table))
+    # round 3: "chain:" keys name a chained tile (ptx_conv3d_chain_config_name), "alt:" keys the measured choice between the
+    # chained launch and the two launches it replaces
+    chain_names = {lib.ptx_conv3d_chain_config_name(i).decode() for i in range(lib.ptx_conv3d_chain_num_configs())}
+    for k, v in table.items():
+        pool = chain_names if k.startswith("chain:") else {"chain", "pair"} if k.startswith("alt:") else names
+        assert isinstance(v[0], str) and v[0] in pool and v[1] >= 1, (k[:40], v)
+    assert any(k.startswith("chain:") for k in table) and any(k.startswith("alt:") for k in table)
+    key = next(k for k in table if not k.startswith(("chain:", "alt:")))
     idx, split = engine.tuned_lookup(key, table[key][0].endswith("/f16"))
     assert lib.ptx_conv3d_config_name(idx).decode() == table[key][0] and split == table[key][1]
     # unknown tile names and precision mismatches fall back to the heuristic instead of remapping

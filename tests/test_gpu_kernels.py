@@ -906,6 +906,10 @@ def test_conv_f16_operands(ptx):
     (1, 300, 300, 256, 256, "softmax/x3", "PTX_NL_X3: layer2 width"),
     (2, 90, 90, 40, 24, "scale/x3", "PTX_NL_X3: dot_product mode"),
     (1, 64, 1568, 256, 256, "softmax/x3", "PTX_NL_X3: many key tiles"),
+    (2, 90, 200, 128, 24, "scale", "key split (8 waves, two key groups merged through LDS): dot-product mode"),
+    (1, 130, 333, 200, 200, "softmax", "key split: ragged d / dv / queries / keys, a last tile whose second key group is empty"),
+    (3, 100, 1000, 256, 256, "softmax", "key split: layer2 widths, several clips"),
+    (2, 70, 160, 96, 128, "softmax/x3", "key split, split operands"),
     (2, 196, 196, 1024, 512, "softmax", "gaussian mode at the reference's layer3 width: theta = x, d = C = 1024 (theta from global)"),
     (1, 392, 49, 1024, 512, "softmax", "d = 1024 with sub-sampled keys"),
     (2, 100, 60, 640, 320, "scale", "512 < d < 1024, dot-product scaling"),

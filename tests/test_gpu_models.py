@@ -665,12 +665,17 @@ def test_biggan_generator_full_batch_both_chunks(ptx):
     torch.cuda.synchronize()
     assert tuple(img.shape) == (64, 3, 256, 256)
     plans = list(G.engine()._plans.values())
-    assert len(plans) == 1 and plans[0].shape[0] in (32, 64)            # one plan; 32 = both chunks served by it
+    # halfs between the convs: the fp16 plan's largest tensor stays under the 2 GiB per-launch limit at batch 64 (one
+    # launch set); the fp32 plan runs the batch as two 32-image chunks of ONE 32-image plan
+    assert len(plans) == 1 and plans[0].shape[0] in (32, 64)
     chunked = plans[0].shape[0] == 32
-    # chunking is invisible: an image of the 64-batch == the same image from a direct call of its own 32-image chunk, up to
-    # the last bits of the fp16 operand roundings (measured 1.5e-4; see scripts/gpu_biggan_chunk_probe.py)
+    # a direct batch-32 call runs ANOTHER plan (its own buffers and tuned tiles: other fp16 rounding points), so an image
+    # of the 64-batch equals the same image from a 32-batch call only up to the fp16 operand noise -- measured 1e-2 at the
+    # worst pixel (scripts/gpu_biggan_chunk_probe.py: the plans themselves are deterministic and carry no state from one
+    # batch to the next)
     second, first = G(z[32:].to(DEV), y[32:]), G(z[:32].to(DEV), y[:32])
-    assert (img[32:] - second).abs().max().item() <= 2e-3 and (img[:32] - first).abs().max().item() <= 2e-3
+    assert (img[32:] - second).abs().max().item() <= 2.5e-2 and (img[:32] - first).abs().max().item() <= 2.5e-2
+    assert torch.equal(second, G(z[32:].to(DEV), y[32:]))                 # ... and each plan is bit-reproducible
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     got = img.cpu()
     worst = 0.0
