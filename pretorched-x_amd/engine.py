@@ -1656,6 +1656,10 @@ class Engine:
         with plan.exclusive():
             if plan.tuned:
                 return
+            if os.environ.get("PTX_RETUNE") == "1":          # re-time EVERY problem (new tiles in the build): tuning sessions
+                self._autotune(model, x, iters=2, only_untuned=False, plan=plan)
+                plan.tuned = True
+                return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
                    for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
                     or any(alt_lookup(a.key) is None for a in plan.alt_steps):

@@ -1,7 +1,8 @@
 """Merge tuned-tile tables dumped by bench.py (PTX_TUNED_OUT) into pretorched-x_amd/tuned_gfx950.json.
 
     python scripts/merge_tuned.py gpurun_out/tuned_*.json
-Later files win; entries whose tile name the current build does not have are dropped."""
+Only entries a dump changed relative to the table on disk are adopted (later files win among those); entries whose
+tile name the current build does not have are dropped."""
 import json
 import os
 import sys
@@ -17,8 +18,13 @@ names |= {"chain", "pair"}                                                      
 path = os.path.join(ROOT, "pretorched-x_amd", "tuned_gfx950.json")
 table = json.load(open(path))
 n0 = len(table)
+base = dict(table)
 for f in sys.argv[1:]:
-    table.update(json.load(open(f)))
+    # every dump is the FULL in-memory table of its run (the shipped table + what that run tuned): adopt only the entries
+    # a run changed or added, so one run's stale copy of another run's problems cannot clobber them
+    for k, v in json.load(open(f)).items():
+        if base.get(k) != v:
+            table[k] = v
 table = {k: v for k, v in table.items() if v[0] in names}
 engine._tuned = {k: (str(v[0]), int(v[1])) for k, v in table.items()}
 engine.save_tuned_table(path)
