@@ -320,19 +320,30 @@ def main():
                         if k.startswith(name + "_kernel") and isinstance(v, dict) and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
                             return hit(v)
                     return None, None
-                tile, waves, mt = name.split("/")[:3]
-                stage = name.split("/")[3] if name.count("/") >= 3 else ""
+                parts = name.split("/")                   # "64x64x32/2x2/m32/dma[N][/chain][/re]"
+                tile, waves, mt = parts[:3]
+                rest = parts[3:]
+                stage = next((t for t in rest if t.startswith("dma")), "")
                 want = [int(v) for v in tile.split("x")] + [int(v) for v in waves.split("x")] + [int(mt[1:])]
                 want_dma = stage.startswith("dma")
                 want_nstage = int(stage[3:]) if len(stage) > 3 else 2
+                want_chain, want_re = "chain" in rest, "re" in rest
+
+                def flag(a):
+                    return a in ("t", "true", "1")
                 for k, v in tj.items():
-                    m = re.match(r"conv_igemm<([^>(]*)", k)         # names are cut at 60 characters by summarize_prof.py
+                    m = re.match(r"conv_igemm<([^>(]*)", k)         # summarize_prof.py: no blanks, t / f booleans, <= 60 characters
                     if not m or not isinstance(v, dict) or v.get("WRITE_SIZE_KiB") is None or v.get("FETCH_SIZE_KiB") is None:
                         continue
                     targs = [a.strip() for a in m.group(1).split(",")]
-                    if len(targs) < 10 or (len(targs) > 10 and targs[10].startswith("t")):     # fp32-operand tiles only
+                    if len(targs) < 10:
                         continue
-                    if [int(a) for a in targs[:6]] == want and (targs[8] == "true") == want_dma and int(targs[9]) == want_nstage:
+                    if (len(targs) > 10 and flag(targs[10])) or (len(targs) > 11 and flag(targs[11])):     # fp32-operand tiles only
+                        continue
+                    chain = len(targs) > 13 and flag(targs[13])
+                    repi = len(targs) > 14 and flag(targs[14])
+                    if ([int(a) for a in targs[:6]] == want and flag(targs[8]) == want_dma and int(targs[9]) == want_nstage
+                            and chain == want_chain and repi == want_re):
                         return hit(v)
             except Exception:
                 pass

@@ -1797,6 +1797,9 @@ class Engine:
 
     def _autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False, plan=None):
         lib = _lib.lib()
+        # timed launches per candidate: 2 keeps a first-use tune under a second per network; tuning sessions that feed the
+        # shipped table ask for more (PTX_TUNE_ITERS) -- many candidates differ by 1-2 %, the noise of a 2-launch average
+        iters = max(iters, int(os.environ.get("PTX_TUNE_ITERS", "0")))
         with torch.cuda.device(x.device):
             if plan is None:
                 plan = self.plan_for(model, _dense16(x))

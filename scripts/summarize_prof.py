@@ -12,7 +12,14 @@ root = sys.argv[1]
 
 
 def short(name):
-    return name.replace("void ptx::", "").replace("ptx::", "").replace("(ptx::ConvArgs)", "").replace("conv_igemm_kernel", "conv_igemm")[:60]
+    """Kernel name in <= 60 characters WITHOUT losing template arguments: the conv template's argument list
+    <BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3, KWR, CHAIN, REPI> is written without blanks and with t / f for
+    the booleans (the chained / row-major-epilogue variants differ only in its last two entries)."""
+    name = name.replace("void ptx::", "").replace("ptx::", "").replace("(ptx::ConvArgs)", "").replace("(ConvArgs)", "")
+    name = name.replace("conv_igemm_kernel", "conv_igemm")
+    if name.startswith("conv_igemm<"):
+        name = name.replace(", ", ",").replace("true", "t").replace("false", "f")
+    return name[:60]
 
 
 for f in sorted(glob.glob(os.path.join(root, "trace*", "*.db"))):
