@@ -125,9 +125,21 @@ extern "C" int ptx_conv3d_chain_pick_config(const ptx_conv3d_desc* conv, const p
     const int64_t M = (int64_t)conv->N * conv->To * conv->Ho * conv->Wo;
     const int K = conv->kT * conv->kH * conv->kW * conv->Kc;
     if (n1 > 128) return -1;
-    if (n1 <= 32) return 7;
-    if (n1 <= 64) return M < 32768 ? 4 : (K <= 128 || conv->Kc % 32 ? 1 : 0);
-    return M < 32768 ? 6 : (K <= 256 || conv->Kc % 32 ? 8 : 5);
+    // defaults resolved BY NAME (inserting / reordering kChain entries cannot remap them); the engine's tuner refines them
+    auto named = [](const char* name) -> int {
+        for (int i = 0; i < kNumChain; ++i)
+            if (!strcmp(kChain[i].name, name)) return i;
+        fprintf(stderr, "libptx_amd: default chained tile \"%s\" is not compiled into this build\n", name);
+        abort();
+        return -1;
+    };
+    static const int t64x32 = named("64x32x32/2x2/m16/dma/chain"), t32x64 = named("32x64x32/2x2/m16/dma/chain"),
+                     t64x64x16 = named("64x64x16/2x2/m32/dma/chain"), t64x64x32 = named("64x64x32/2x2/m32/dma/chain"),
+                     t32x128 = named("32x128x32/2x2/m16/dma/chain"), t64x128x16 = named("64x128x16/2x2/m32/dma/chain"),
+                     t64x128x32 = named("64x128x32/2x2/m32/dma/chain");
+    if (n1 <= 32) return t64x32;
+    if (n1 <= 64) return M < 32768 ? t32x64 : (K <= 128 || conv->Kc % 32 ? t64x64x16 : t64x64x32);
+    return M < 32768 ? t32x128 : (K <= 256 || conv->Kc % 32 ? t64x128x16 : t64x128x32);
 }
 
 extern "C" int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail, const float* x, const float* w_packed,

@@ -646,6 +646,35 @@ def test_biggan_generator_fp16(ptx):
     assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))
 
 
+@pytest.mark.parametrize("arch,kw,shape", [("resnet3d50", dict(num_classes=17, pretrained=None), (3, 3, 8, 112, 112)),
+                                           ("r2plus1d50", dict(num_classes=17), (2, 3, 16, 112, 112)),
+                                           ("nonlocal_r2plus1d50", dict(num_classes=17), (2, 3, 16, 112, 112))])
+def test_chained_and_unchained_plans_agree(ptx, arch, kw, shape, monkeypatch):
+    """Chained launches (conv -> 1x1x1 conv in one kernel: bottleneck tails, (2+1)D pointwise pairs) against the
+    plan that runs every conv as its own launch, and against the CPU oracle: PTX_CHAIN_FORCE=1 / 0 pin the choice the tuner
+    otherwise makes per pair.  Same arithmetic on both sides (bit-identical per tile shape; the two plans may pick different
+    tiles, hence 1e-4 of the logits' scale instead of equality)."""
+    from pretorched_x_amd.engine import AltStep
+    x = synth_clips(shape[0], shape[2], shape[3], 31)
+    outs = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("PTX_CHAIN_FORCE", force)
+        recipe = dict(inner_bn_damp=0.9, nl_bn_damp=0.05) if "r2plus1d" in arch else {}
+        model, sd = _build(ptx, arch, kw, 77, **recipe)
+        outs[force] = model(x.to(DEV))
+        torch.cuda.synchronize()
+        plan = list(model.engine()._plans.values())[-1]
+        alts = [s for s in plan.steps if isinstance(s, AltStep)]
+        assert alts and all(a.use_chain == (force == "1") for a in alts), (arch, force, len(alts))
+        n_chain = sum(a.use_chain for a in alts)
+        assert len(plan.all_convs()) == len(plan.conv_steps) + getattr(plan, "stem_steps", 0) - n_chain, arch
+    want = OF.forward(oracle_cfg(arch, kw), sd, x)
+    _check(outs["1"], want, "%s chained vs oracle" % arch)
+    _check(outs["0"], want, "%s unchained vs oracle" % arch)
+    assert (outs["1"] - outs["0"]).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    assert torch.equal(outs["1"].argmax(1).cpu(), want.argmax(1))
+
+
 def test_biggan_generator_full_batch_both_chunks(ptx):
     """BASELINE config 5 at its own size: batch 64.  Engine.generate runs it as two 32-image chunks (the 256^2 stage of a
     64-image batch exceeds the 2 GiB per-launch limit); ALL 64 images -- both chunks -- are compared with the stand-in
