@@ -138,11 +138,11 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // fp32 LDS-DMA tiles with the row-major epilogue (".../re"): bias + residual + ReLU through 16-byte accesses
-template <int BM, int BN, int BK, int WM, int WN, int MT, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, int MT, int NSTAGE, bool X3 = false>
 static int launch_cfg_re(const ConvArgs& a, dim3 grid, hipStream_t st) {
     if ((a.kA % BK) || (a.kB % BK) || (a.dual && ((a.kA2 % BK) || (a.wcol2 % BK))))
-        return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, NSTAGE, false, false, 0, true>(a, grid, st);
-    return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, NSTAGE, false, false, 0, true>(a, grid, st);
+        return launch_one<BM, BN, BK, WM, WN, MT, true, false, true, NSTAGE, false, X3, 0, true>(a, grid, st);
+    return launch_one<BM, BN, BK, WM, WN, MT, false, false, true, NSTAGE, false, X3, 0, true>(a, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -309,6 +309,9 @@ struct ConvConfig {
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/re", launch_cfg_re<BM, BN, BK, WM, WN, MT, 2>, false, false, false, 0 }
 #define PTX_CFG_RE3(BM, BN, BK, WM, WN, MT) \
     { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma3/re", launch_cfg_re<BM, BN, BK, WM, WN, MT, 3>, false, false, false, 0 }
+#define PTX_CFG_X3RE(BM, BN, BK, WM, WN, MT, NS) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma" #NS "/re/x3", \
+      launch_cfg_re<BM, BN, BK, WM, WN, MT, NS, true>, false, false, true, 0 }
 #define PTX_CFG_DIRECT(BM, BN, BK, CO, P) \
     { BM, BN, BK, 4, 1, 0, #BM "x" #BN "x" #BK "/direct", launch_direct<CO, P>, true, false, false, 0 }
 #define PTX_CFG_F16(BM, BN, BK, WM, WN, MT) \
@@ -491,6 +494,17 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_RE(32, 128, 32, 2, 2, 16),        // 141
     PTX_CFG_RE(64, 32, 32, 2, 2, 16),         // 142
     PTX_CFG_RE(112, 64, 32, 1, 4, 16),        // 143
+    // ... and for the split-operand tiles, whose shorter matrix work leaves the pointwise convs even more epilogue-bound
+    // ("/dma2/re/x3" = 2-stage)
+    PTX_CFG_X3RE(128, 128, 32, 4, 2, 32, 2),  // 144
+    PTX_CFG_X3RE(128, 128, 32, 4, 2, 32, 3),  // 145
+    PTX_CFG_X3RE(128, 64, 32, 4, 2, 32, 3),   // 146
+    PTX_CFG_X3RE(64, 128, 32, 2, 2, 32, 3),   // 147
+    PTX_CFG_X3RE(64, 64, 32, 2, 2, 32, 2),    // 148
+    PTX_CFG_X3RE(64, 64, 64, 2, 2, 32, 2),    // 149
+    PTX_CFG_X3RE(32, 64, 64, 2, 2, 16, 3),    // 150
+    PTX_CFG_X3RE(32, 128, 64, 2, 2, 16, 2),   // 151
+    PTX_CFG_X3RE(128, 64, 32, 2, 2, 32, 2),   // 152
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -428,7 +428,7 @@ template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, 
           bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !X3 && !K22 && KWR == 0), "chained tail: fp32 2-stage LDS-DMA tiles");
-    static_assert(!REPI || (DMA && !F16 && !X3 && !K22 && KWR == 0), "row-major epilogue: fp32 LDS-DMA tiles");
+    static_assert(!REPI || (DMA && !F16 && !K22 && KWR == 0), "row-major epilogue: fp32-output LDS-DMA tiles (fp32 or split operands)");
     static_assert(KWR == 0 || (KWR == 3 && DMA && NSTAGE == 2 && !K22), "kw-reuse tiles: 3-wide filters, 2-stage LDS-DMA");
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
     static_assert(!X3 || (DMA && !F16 && !K22), "split operands: LDS-DMA tiles");
