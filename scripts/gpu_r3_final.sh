@@ -15,5 +15,6 @@ W=cfg2 TAG=_final STEPS=15 bash scripts/gpu_prof_pmc.sh > $O/final_prof_cfg2.log
 W=cfg2 TAG=_final_x3 STEPS=15 ENVS="PTX_PRECISION=x3" PASSES="1 3 4" bash scripts/gpu_prof_pmc.sh > $O/final_prof_cfg2_x3.log 2>&1; tail -2 $O/final_prof_cfg2_x3.log
 W=cfg3 TAG=_final STEPS=15 PASSES="1 3 4" bash scripts/gpu_prof_pmc.sh > $O/final_prof_cfg3.log 2>&1; tail -2 $O/final_prof_cfg3.log
 python scripts/pmc_traffic_json.py $O/prof_cfg2_final/summary.txt $O/final_pmc_traffic.json "$PTX_COMMIT" "python bench.py --workload cfg2 --steps 15 --warmup 2 --no-cpu-baseline --no-x3 --no-autotune"
+cp $O/final_pmc_traffic.json profiles/r03_pmc_traffic.json   # (on the box: the after-profile line below cites THIS commit's counters)
 # the bench line of the SAME build right after its profile (the stem row's average must agree with roofline.avg_launch_ms)
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-x3 --no-cpu-baseline --no-autotune > $O/final_bench_cfg2_after_prof.json 2>/dev/null; tail -1 $O/final_bench_cfg2_after_prof.json | cut -c1-200
