@@ -11,14 +11,15 @@
 //     M = floor(Cin Cout / (Cin + Cout)) mid channels with BN + ReLU between them (r2plus1d.py:68-88): 64 -> 51 -> 256,
 //     256 -> 51 -> 64 ...: two launches of 15-60 us at 30-60 TF each become one.
 // Limits: N1 (the first conv's output channels) <= the tile's BN (32 / 64 / 128: one N tile holds the whole intermediate
-// row); dense fp32 convs; the tail is 1x1x1 / unit stride with PTX_EPI_RELU | PTX_EPI_RES_ADD; no split-K.
+// row); dense fp32 convs, fp32 or split (PTX_F16X3_OPERANDS, both convs) operands; the tail is 1x1x1 / unit stride with
+// PTX_EPI_RELU | PTX_EPI_RES_ADD; no split-K.
 #include "conv_igemm_kernel.h"
 
 namespace ptx {
 
 typedef int (*chain_launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool REPI>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool REPI, bool X3>
 static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * BK * sizeof(float);
     // the parked intermediate tile aliases the two A stages when they are big enough (kernel: kAlias); the row-major
@@ -26,7 +27,7 @@ static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     constexpr bool alias = BM * BN <= 2 * BM * BK;
     constexpr size_t lds = lds_tiles + (alias ? 0 : (size_t)BM * BN * sizeof(float)) +
                            (REPI ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, false, 0, true, REPI>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, X3, 0, true, REPI>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -38,22 +39,29 @@ static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     return hip_check(hipGetLastError(), "conv_chain launch");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool REPI>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool REPI, bool X3 = false>
 static int launch_chain(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true, REPI>(a, grid, st);
-    return launch_chain_one<BM, BN, BK, WM, WN, MT, false, REPI>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true, REPI, X3>(a, grid, st);
+    return launch_chain_one<BM, BN, BK, WM, WN, MT, false, REPI, X3>(a, grid, st);
 }
 
 struct ChainConfig {
     int BM, BN, BK, WM, WN, MT;
     const char* name;
     chain_launch_fn launch;
+    bool x3;          // split fp32 operands (PTX_F16X3_OPERANDS) in both GEMMs
 };
 #define PTX_CHAIN_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT, false> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT, false>, false }
 // the tail's epilogue row-major through LDS: 16-byte residual loads / output stores (conv_igemm_kernel.h, REPI)
 #define PTX_CHAIN_CFG_RE(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re", launch_chain<BM, BN, BK, WM, WN, MT, true> }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re", launch_chain<BM, BN, BK, WM, WN, MT, true>, false }
+// split operands (x3): both GEMMs on v_mfma_f32_*_f16 with (hi, lo) half operands; the parked tile stays fp32 and is split
+// at fragment-read time exactly like an activation tile staged from HBM
+#define PTX_CHAIN_CFG_X3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/x3", launch_chain<BM, BN, BK, WM, WN, MT, false, true>, true }
+#define PTX_CHAIN_CFG_X3RE(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re/x3", launch_chain<BM, BN, BK, WM, WN, MT, true, true>, true }
 
 static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG(64, 64, 32, 2, 2, 32),     // 0  the 3x3x3 -> 1x1x1 bottleneck tail at 64 planes (same tile as the tuned conv2)
@@ -74,6 +82,16 @@ static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG_RE(32, 128, 32, 2, 2, 16), // 15
     PTX_CHAIN_CFG_RE(64, 32, 32, 2, 2, 16),  // 16
     PTX_CHAIN_CFG_RE(64, 128, 16, 2, 2, 32), // 17
+    PTX_CHAIN_CFG_X3(64, 64, 32, 2, 2, 32),
+    PTX_CHAIN_CFG_X3(128, 64, 32, 4, 2, 32),
+    PTX_CHAIN_CFG_X3(64, 128, 32, 2, 2, 32),
+    PTX_CHAIN_CFG_X3(32, 64, 64, 2, 2, 16),
+    PTX_CHAIN_CFG_X3(64, 64, 64, 2, 2, 32),
+    PTX_CHAIN_CFG_X3RE(64, 64, 32, 2, 2, 32),
+    PTX_CHAIN_CFG_X3RE(128, 64, 32, 4, 2, 32),
+    PTX_CHAIN_CFG_X3RE(64, 128, 32, 2, 2, 32),
+    PTX_CHAIN_CFG_X3RE(32, 64, 64, 2, 2, 16),
+    PTX_CHAIN_CFG_X3RE(64, 64, 64, 2, 2, 32),
 };
 constexpr int kNumChain = sizeof(kChain) / sizeof(kChain[0]);
 
@@ -82,10 +100,13 @@ static int validate_chain(const ptx_conv3d_desc* c, const ptx_conv3d_desc* t) {
     if (s != PTX_OK) return s;
     s = validate_desc(t);
     if (s != PTX_OK) return s;
-    if (c->flags & ~(uint32_t)PTX_EPI_RELU)
-        return fail(PTX_ERR_UNSUPPORTED, "conv3d_chain: the first conv takes PTX_EPI_RELU only (flags 0x%x)", c->flags);
-    if (t->flags & ~(uint32_t)(PTX_EPI_RELU | PTX_EPI_RES_ADD))
-        return fail(PTX_ERR_UNSUPPORTED, "conv3d_chain: the tail takes PTX_EPI_RELU | PTX_EPI_RES_ADD only (flags 0x%x)", t->flags);
+    if (c->flags & ~(uint32_t)(PTX_EPI_RELU | PTX_F16X3_OPERANDS))
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d_chain: the first conv takes PTX_EPI_RELU (| PTX_F16X3_OPERANDS) only (flags 0x%x)", c->flags);
+    if (t->flags & ~(uint32_t)(PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_F16X3_OPERANDS))
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d_chain: the tail takes PTX_EPI_RELU | PTX_EPI_RES_ADD (| PTX_F16X3_OPERANDS) only (flags 0x%x)",
+                    t->flags);
+    if ((c->flags ^ t->flags) & PTX_F16X3_OPERANDS)
+        return fail(PTX_ERR_INVALID, "conv3d_chain: both convs or neither take split operands (PTX_F16X3_OPERANDS)");
     if (c->groups > 1 || t->groups > 1) return fail(PTX_ERR_UNSUPPORTED, "conv3d_chain: dense convs only");
     if (t->kT * t->kH * t->kW != 1 || t->sT != 1 || t->sH != 1 || t->sW != 1 || t->pT || t->pH || t->pW)
         return fail(PTX_ERR_INVALID, "conv3d_chain: the tail must be a unit-stride 1x1x1 conv");
@@ -116,6 +137,7 @@ extern "C" int ptx_conv3d_chain_supported(const ptx_conv3d_desc* conv, const ptx
     const ChainConfig& c = kChain[config];
     const int n1 = (conv->Co + 3) / 4 * 4;
     if (n1 > c.BN) return 0;                         // the whole intermediate row lives in ONE N tile
+    if (c.x3 != ((conv->flags & PTX_F16X3_OPERANDS) != 0)) return 0;     // operand kind of the packed filters = the tile's
     return 1;
 }
 
@@ -125,6 +147,7 @@ extern "C" int ptx_conv3d_chain_pick_config(const ptx_conv3d_desc* conv, const p
     const int64_t M = (int64_t)conv->N * conv->To * conv->Ho * conv->Wo;
     const int K = conv->kT * conv->kH * conv->kW * conv->Kc;
     if (n1 > 128) return -1;
+    const bool x3 = (conv->flags & PTX_F16X3_OPERANDS) != 0;
     // defaults resolved BY NAME (inserting / reordering kChain entries cannot remap them); the engine's tuner refines them
     auto named = [](const char* name) -> int {
         for (int i = 0; i < kNumChain; ++i)
@@ -137,6 +160,9 @@ extern "C" int ptx_conv3d_chain_pick_config(const ptx_conv3d_desc* conv, const p
                      t64x64x16 = named("64x64x16/2x2/m32/dma/chain"), t64x64x32 = named("64x64x32/2x2/m32/dma/chain"),
                      t32x128 = named("32x128x32/2x2/m16/dma/chain"), t64x128x16 = named("64x128x16/2x2/m32/dma/chain"),
                      t64x128x32 = named("64x128x32/2x2/m32/dma/chain");
+    static const int x64x64 = named("64x64x32/2x2/m32/dma/chain/x3"),
+                     x128x64 = named("128x64x32/4x2/m32/dma/chain/x3"), x64x128 = named("64x128x32/2x2/m32/dma/chain/x3");
+    if (x3) return n1 <= 64 ? (M >= 65536 ? x128x64 : x64x64) : x64x128;   // (the 16x16x32 tiles need BK = 64 > a 32-wide N tile)
     if (n1 <= 32) return t64x32;
     if (n1 <= 64) return M < 32768 ? t32x64 : (K <= 128 || conv->Kc % 32 ? t64x64x16 : t64x64x32);
     return M < 32768 ? t32x128 : (K <= 256 || conv->Kc % 32 ? t64x128x16 : t64x128x32);
@@ -166,6 +192,7 @@ extern "C" int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3
     a.ldw = d->Kc; a.kB = d->Kc; a.w_rows = d->Co_pad; a.w_tap_stride = (long long)d->Co_pad * d->Kc;
     a.M = d->N * d->To * d->Ho * d->Wo;
     a.flags = d->flags & PTX_EPI_RELU;
+    a.x3 = (d->flags & PTX_F16X3_OPERANDS) ? 1 : 0;
     {
         const uint64_t xb = (uint64_t)d->N * d->Ti * d->Hi * d->Wi * d->ldx * 4ull;
         const uint64_t wb = (uint64_t)d->kT * d->kH * d->kW * d->Co_pad * d->Kc * 4ull;
@@ -193,7 +220,7 @@ extern "C" int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3
                         a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo) ? 1 : 0;
     a.w2 = w2_packed; a.bias2 = bias2;
     a.ldw2 = tail->Kc; a.kB2 = tail->Kc; a.w2_rows = tail->Co_pad; a.Co2 = tail->Co; a.ncol2 = (tail->Co + 3) / 4 * 4;
-    a.flags2 = tail->flags;
+    a.flags2 = tail->flags & (PTX_EPI_RELU | PTX_EPI_RES_ADD);
     if ((int64_t)a.m_tiles > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "conv3d_chain: grid too large");
     return c.launch(a, dim3((unsigned)a.m_tiles, 1, 1), (hipStream_t)stream);
 }

@@ -427,7 +427,8 @@ __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
           bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
-    static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !X3 && !K22 && KWR == 0), "chained tail: fp32 2-stage LDS-DMA tiles");
+    static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22 && KWR == 0), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
+    static_assert(!CHAIN || BN >= BK, "chained tail: the parked tile is cut into BN / BK k-chunks");
     static_assert(!REPI || (DMA && !F16 && !K22 && KWR == 0), "row-major epilogue: fp32-output LDS-DMA tiles (fp32 or split operands)");
     static_assert(KWR == 0 || (KWR == 3 && DMA && NSTAGE == 2 && !K22), "kw-reuse tiles: 3-wide filters, 2-stage LDS-DMA");
     static_assert(!F16 || !K22, "the K22 stem path is fp32 only");
@@ -1092,6 +1093,28 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         // the last stage: drain both before P and the B stages are written
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        auto fold_x3 = [&]() {      // split operands: acc += 2^-12 acc2 (exact scaling), as the unchained epilogue does
+            if constexpr (X3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = fmaf(acc2[i][j][r], 1.0f / 4096.0f, acc[i][j][r]);
+            }
+        };
+        auto clear_acc = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < MF::NACC; ++r) {
+                        acc[i][j][r] = 0.f;
+                        if constexpr (X3) acc2[i][j][r] = 0.f;
+                    }
+        };
+        fold_x3();
         {
             const bool relu1 = (p.flags & PTX_EPI_RELU) != 0;
 #pragma unroll
@@ -1152,6 +1175,22 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         post_barrier_offsets(offa, offb);
         load_b2(1, 1);
         auto read_frags2 = [&](int kc, int bufb, int ks, int slot) {
+            if constexpr (X3) {
+                // 8-channel blocks: two 16-byte slots per lane group (P: floats 8b .. 8b+7; filter: 8 hi | 8 lo halfs)
+                const int b2 = (ks * KG + lane / MT) * 2;
+                const int k0 = (b2 ^ frag_sw) * 4, k1 = ((b2 + 1) ^ frag_sw) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    fa[slot][i][0] = *reinterpret_cast<const f32x4*>(P + kc * (BM * BK) + offa + i * MT * LDK + k0);
+                    fa[slot][i][NF - 1] = *reinterpret_cast<const f32x4*>(P + kc * (BM * BK) + offa + i * MT * LDK + k1);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + k0);
+                    fb[slot][j][NF - 1] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + k1);
+                }
+                return;
+            }
             const int koff = ((ks * KG + lane / MT) ^ frag_sw) * 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1168,12 +1207,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         for (int s2 = 0; s2 < steps2; ++s2) {
             const int buf = s2 & 1;
             if (REPI && kc == 0) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
+                clear_acc();
                 if constexpr (REPI)
                     rowmajor_load_residual<MF, TM, TN, WTM, WTN, MT>(res4c, rsrc_r2, res2, m0 + wm * WTM, nc * BN + wn * WTN, p.M,
                                                                      p.ncol2, p.ldr, lane);
@@ -1186,7 +1220,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                        for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = 0.f;
+                        for (int r = 0; r < MF::NACC; ++r) {
+                            acc[i][j][r] = 0.f;
+                            if constexpr (X3) acc2[i][j][r] = 0.f;
+                        }
                         const int co = nc * BN + wn * WTN + j * MT + (lane % MT);
                         const int mrow = m0 + wm * WTM + i * MT;
 #pragma unroll
@@ -1208,6 +1245,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             post_barrier_offsets(offa, offb);
             load_b2(s2 + 2, buf);
             ++kc;
+            if (kc == kc2) fold_x3();
             if (REPI && kc == kc2) {
                 if constexpr (REPI)
                     rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT>(acc, res4c, Ep, p.bias2, rsrc_y2, relu2, m0 + wm * WTM,

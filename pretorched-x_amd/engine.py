@@ -522,8 +522,9 @@ class Plan:
         self.conv_steps = []
         self.chain_steps = []    # ChainStep launches (two convs each; tuned over their own tile table)
         self.alt_steps = []      # AltStep: chained launch | the two launches, chosen by measurement
-        # chained convs (conv -> 1x1x1 conv in one launch): fp32 plans; PTX_CHAIN=0 keeps every conv its own launch
-        self.chain = os.environ.get("PTX_CHAIN", "1") != "0" and getattr(engine, "precision", "fp32") == "fp32"
+        # chained convs (conv -> 1x1x1 conv in one launch): fp32 and split-operand plans; PTX_CHAIN=0 keeps every conv its
+        # own launch
+        self.chain = os.environ.get("PTX_CHAIN", "1") != "0"
         self.packs = []
         self.acts = []
         self._pack_cache = {}
@@ -707,16 +708,20 @@ class Plan:
     def conv_chain(self, x, pk, stride, padding, pk2, relu1=True, relu2=False, res=None, label="chain", y=None):
         """conv(x, pk) -> [ReLU] -> 1x1x1 conv (pk2) -> [+ res] -> [ReLU] as ONE launch (ptx_conv3d_chain_fwd): returns (output
         activation, ChainStep) -- the step is NOT appended to the plan; the caller also emits the two separate launches into
-        the same output and wraps both with Plan.alt() -- or None when the pair does not qualify.  Qualifies: fp32 plan, dense unfolded
-        filters, a pointwise tail whose K axis is the first conv's output, at most 128 intermediate channels (one N tile
+        the same output and wraps both with Plan.alt() -- or None when the pair does not qualify.  Qualifies: dense unfolded
+        filters of one operand kind (fp32, or split operands in an "x3" plan), a pointwise tail whose K axis is the first conv's output, at most 128 intermediate channels (one N tile
         holds the whole intermediate row), a same-shape residual (or none), and enough rows to fill the chip from M tiles
         alone (the tail's N slices run inside one workgroup: M >= PTX_CHAIN_MIN_M, default 8192)."""
         if not self.chain or isinstance(x, RawInput) or getattr(x, "f16", False):
             return None
         for p_ in (pk, pk2):
-            if getattr(p_, "x3", False) or getattr(p_, "f16", False) or getattr(p_, "groups", 1) > 1 or getattr(p_, "fold_kw", False) \
-                    or not isinstance(p_, Packed):
+            if getattr(p_, "f16", False) or getattr(p_, "groups", 1) > 1 or getattr(p_, "fold_kw", False) or not isinstance(p_, Packed):
                 return None
+        x3 = bool(getattr(pk, "x3", False))
+        if x3 != bool(getattr(pk2, "x3", False)):          # both GEMMs of a chained launch take the same operand kind
+            return None
+        rk = _r8 if x3 else _r4
+        fx3 = PTX_F16X3_OPERANDS if x3 else 0
         # 32 .. PTX_CHAIN_MAX_N1 intermediate channels: narrower convs (SlowFast's fast pathway: 8 / 16 planes) keep their
         # 16-wide / direct tiles -- a 32-wide chained tile would pad their work 2-4x
         if pk2.k_eff != (1, 1, 1) or pk2.Ci != pk.Co or pk.Co < 32 or _r4(pk.Co) > min(128, int(os.environ.get("PTX_CHAIN_MAX_N1", "128"))):
@@ -734,17 +739,17 @@ class Plan:
             return None
         d = ConvDesc()
         d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = x.N, x.T, x.H, x.W, x.C, x.ld
-        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, _r4(pk.Co)
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, pk.Co, rk(pk.Co)
         d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, sT, sH, sW, pT, pH, pW
         d.Kc, d.Co_pad, d.groups = pk.Kc, pk.Co_pad, 1
-        d.flags = PTX_EPI_RELU if relu1 else 0
+        d.flags = (PTX_EPI_RELU if relu1 else 0) | fx3
         ld_out = y.ld if y is not None else _r4(pk2.Co)
         d2 = ConvDesc()
-        d2.N, d2.Ti, d2.Hi, d2.Wi, d2.Ci, d2.ldx = x.N, To, Ho, Wo, pk.Co, _r4(pk.Co)
+        d2.N, d2.Ti, d2.Hi, d2.Wi, d2.Ci, d2.ldx = x.N, To, Ho, Wo, pk.Co, rk(pk.Co)
         d2.To, d2.Ho, d2.Wo, d2.Co, d2.ldy = To, Ho, Wo, pk2.Co, ld_out
         d2.kT = d2.kH = d2.kW = d2.sT = d2.sH = d2.sW = 1
         d2.Kc, d2.Co_pad, d2.groups = pk2.Kc, pk2.Co_pad, 1
-        d2.flags = (PTX_EPI_RELU if relu2 else 0) | (PTX_EPI_RES_ADD if res is not None else 0)
+        d2.flags = (PTX_EPI_RELU if relu2 else 0) | (PTX_EPI_RES_ADD if res is not None else 0) | fx3
         d2.ldr = res.ld if res is not None else 0
         key = chain_key(d, d2)
         cfg = chain_lookup(key)
@@ -1937,7 +1942,9 @@ class Engine:
                     e1.record()
                     e1.synchronize()
                     ms2.append(e0.elapsed_time(e1) / max(iters, 3))
-                a.use_chain = ms2[0] < ms2[1]
+                # the chained launch has to win by a margin: timed alone in a loop it looks ~2 % better than inside the
+                # forward (measured: config 2 x3, layer2 tails -- chosen at parity by the tuner, 1.2 % slower in the step)
+                a.use_chain = ms2[0] < 0.97 * ms2[1]
                 seen_a[a.key] = a.use_chain
                 alt_store(a.key, a.use_chain)
                 if log is not None:

@@ -503,8 +503,14 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     eng.precision = "x3"
     plan = eng.dry_plan(m, (2, 3, 16, 224, 224))
     # the stem leaves the implicit-GEMM list: ptx_conv_stem_x3_fwd reads 4-channel positions, no kW fold
-    # (split-operand plans keep one launch per conv: the chained tiles are fp32-MFMA tiles)
-    assert plan.x3 and not plan.chain_steps and len(plan.conv_steps) == len(base.conv_steps)
+    # the bottleneck tails of layer1 are chained here too, on the split-operand chained tiles
+    assert plan.x3 and len(plan.chain_steps) == len(base.chain_steps) == 2 and len(plan.conv_steps) == len(base.conv_steps)
+    for c in plan.chain_steps:
+        assert c.d.flags & c.d2.flags & L.PTX_F16X3_OPERANDS and c.d.Kc % 8 == 0 and c.d2.Kc % 8 == 0, c.label
+        assert lib.ptx_conv3d_chain_config_name(c.cfg).decode().endswith("/x3"), c.label
+        assert lib.ptx_conv3d_chain_supported(C.byref(c.d), C.byref(c.d2), c.cfg)
+    for c in base.chain_steps:
+        assert not lib.ptx_conv3d_chain_config_name(c.cfg).decode().endswith("/x3"), c.label
     assert plan.stem_steps == 1
     stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
     assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"

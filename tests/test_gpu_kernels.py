@@ -1444,11 +1444,12 @@ def test_conv_stem_f32_padded_pitch(ptx):
         assert err <= 2e-5, ((N, T, H, W, Co), err)
 
 
-def _pack_plain(ptx, w, bn, bias=None):
-    """BN-folded K-major packed filter + bias on the device (fp32, unfolded)."""
+def _pack_plain(ptx, w, bn, bias=None, x3=False):
+    """BN-folded K-major packed filter + bias on the device (unfolded; fp32, or (hi8 | lo8) half blocks for x3)."""
     L, lib = ptx._lib, _lib(ptx)
     Co, Ci, kT, kH, kW = w.shape
-    pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, (Ci + 7) // 8 * 8 if x3 else _r4(Ci), (Co + 127) // 128 * 128, 0)
+    pd.f16 = 2 if x3 else 0
     wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
     bp = torch.empty(pd.Co_pad, device=DEV)
     wd = w.contiguous().to(DEV)
@@ -1478,12 +1479,14 @@ CHAIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("kind", ["fp32", "x3"])
 @pytest.mark.parametrize("case", CHAIN_CASES, ids=[c[0] for c in CHAIN_CASES])
-def test_conv_chain(ptx, case):
+def test_conv_chain(ptx, case, kind):
     """ptx_conv3d_chain_fwd (conv -> BN -> ReLU -> 1x1x1 conv -> BN -> + residual -> ReLU in one launch, the intermediate
     tile in LDS) on EVERY chained tile that holds the intermediate row, against (a) the op sequence in torch fp32 on the
     CPU and (b) the two launches it replaces on the plain tiles of the same MFMA shape -- bit for bit (same k order:
-    VERDICT r2 #3 'bit-exactness test vs the unfused pair')."""
+    VERDICT r2 #3 'bit-exactness test vs the unfused pair').  kind "x3": both GEMMs on split operands."""
+    x3 = kind == "x3"
     L, lib = ptx._lib, _lib(ptx)
     _, N, T, H, W, Ci, N1, Co2, k, s_, p_, relu1, relu2, with_res = case
     x = rnd(N, Ci, T, H, W, seed=400 + Ci)
@@ -1494,33 +1497,36 @@ def test_conv_chain(ptx, case):
     To, Ho, Wo = mid.shape[2:]
     res = rnd(N, Co2, To, Ho, Wo, seed=405) if with_res else None
     want = ref_conv(mid, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res)
-    pd1, wp1, bp1 = _pack_plain(ptx, w1, bn1)
-    pd2, wp2, bp2 = _pack_plain(ptx, w2, bn2)
+    pd1, wp1, bp1 = _pack_plain(ptx, w1, bn1, x3=x3)
+    pd2, wp2, bp2 = _pack_plain(ptx, w2, bn2, x3=x3)
+    fx3 = L.PTX_F16X3_OPERANDS if x3 else 0
     xd = to_cl(x)
     rd = to_cl(res) if with_res else None
     d = L.ConvDesc()
     d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, xd.shape[-1]
     d.To, d.Ho, d.Wo, d.Co, d.ldy = To, Ho, Wo, N1, _r4(N1)
     d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = k[0], k[1], k[2], s_[0], s_[1], s_[2], p_[0], p_[1], p_[2]
-    d.Kc, d.Co_pad, d.flags = pd1.Kc, pd1.Co_pad, (L.PTX_EPI_RELU if relu1 else 0)
+    d.Kc, d.Co_pad, d.flags = pd1.Kc, pd1.Co_pad, (L.PTX_EPI_RELU if relu1 else 0) | fx3
     ldy = _r4(Co2) + 8                                   # a row stride wider than the written columns
     d2 = L.ConvDesc()
     d2.N, d2.Ti, d2.Hi, d2.Wi, d2.Ci, d2.ldx = N, To, Ho, Wo, N1, _r4(N1)
     d2.To, d2.Ho, d2.Wo, d2.Co, d2.ldy = To, Ho, Wo, Co2, ldy
     d2.kT = d2.kH = d2.kW = d2.sT = d2.sH = d2.sW = 1
     d2.Kc, d2.Co_pad = pd2.Kc, pd2.Co_pad
-    d2.flags = (L.PTX_EPI_RELU if relu2 else 0) | (L.PTX_EPI_RES_ADD if with_res else 0)
+    d2.flags = (L.PTX_EPI_RELU if relu2 else 0) | (L.PTX_EPI_RES_ADD if with_res else 0) | fx3
     d2.ldr = rd.shape[-1] if with_res else 0
     plain = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
     null = C.c_void_p(0)
-    ran = 0
+    ran = pairs = 0
     for cfg in range(lib.ptx_conv3d_chain_num_configs()):
         name = lib.ptx_conv3d_chain_config_name(cfg).decode()
-        core = name[:-3] if name.endswith("/re") else name           # ".../chain/re": the tail's epilogue row-major through LDS
+        tile_x3 = name.endswith("/x3")                               # ".../chain[/re]/x3": split-operand tiles
+        core = name[:-3] if tile_x3 else name
+        core = core[:-3] if core.endswith("/re") else core           # ".../chain/re": the tail's epilogue row-major through LDS
         assert core.endswith("/dma/chain")
         bn_tile = int(name.split("x")[1])
         ok = lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg)
-        assert bool(ok) == (_r4(N1) <= bn_tile), (name, N1)
+        assert bool(ok) == (_r4(N1) <= bn_tile and tile_x3 == x3), (name, N1)
         if not ok:
             yd = torch.zeros((N, To, Ho, Wo, ldy), device=DEV)
             assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
@@ -1534,12 +1540,13 @@ def test_conv_chain(ptx, case):
         close(got, want, 2e-5)
         assert bool((yd[..., Co2:_r4(Co2)] == 0).all()) and bool(torch.isnan(yd[..., _r4(Co2):]).all()), name   # pad cols zero, beyond untouched
         ran += 1
-        base = core[:-len("/chain")]
+        base = core[:-len("/chain")] + ("/x3" if x3 else "")
         if base in plain:                                # the two launches it replaces, same tile / MFMA shape: bit-identical
-            mid_g = hip_conv(ptx, x, w1, s_, p_, bn=bn1, relu=relu1, cfg=plain[base], split=1)
-            two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=plain[base], split=1)
+            mid_g = hip_conv(ptx, x, w1, s_, p_, bn=bn1, relu=relu1, cfg=plain[base], split=1, x3=x3)
+            two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=plain[base], split=1, x3=x3)
+            pairs += 1
             assert torch.equal(got, two), (name, (got - two).abs().max().item())
-    assert ran >= 1
+    assert ran >= 1 and pairs >= 1
     # config < 0: the library's own pick
     yd = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
     L.check(lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
@@ -1551,4 +1558,7 @@ def test_conv_chain(ptx, case):
     assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0
     d.flags &= ~L.PTX_EPI_RES_ADD
     d2.Wi += 1
+    assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0
+    d2.Wi -= 1
+    d2.flags ^= L.PTX_F16X3_OPERANDS                     # split operands on one conv only
     assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0
