@@ -172,6 +172,10 @@ int ptx_conv3d_dual_fwd(const ptx_conv3d_desc* desc, const float* x, const float
  *         PTX_EPI_RELU | PTX_EPI_RES_ADD (res: same shape as y, row stride ldr), ldy = row stride of y.
  * Arithmetic: both GEMMs on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 in the same k order as the unfused launches on tiles of
  * the same MFMA shape -- bit-identical to ptx_conv3d_fwd followed by ptx_conv3d_fwd.  config < 0: ptx_conv3d_chain_pick_config.
+ * Split operands: PTX_F16X3_OPERANDS on BOTH descriptors (both filters packed with ptx_pack_desc.f16 == 2, Kc % 8 == 0)
+ * runs both GEMMs as three fp16 MFMAs per product block on the ".../chain/x3" configurations -- the parked tile stays
+ * fp32 and is split at fragment-read time like an activation; bit-identical to the two x3 launches.  The flag on one
+ * descriptor only is PTX_ERR_INVALID; a configuration of the other operand kind is PTX_ERR_UNSUPPORTED.
  */
 int ptx_conv3d_chain_num_configs(void);
 const char* ptx_conv3d_chain_config_name(int config);

@@ -19,15 +19,18 @@ namespace ptx {
 
 typedef int (*chain_launch_fn)(const ConvArgs&, dim3, hipStream_t);
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool REPI, bool X3>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool REPI, bool X3, int KWR>
 static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    constexpr size_t lds_tiles = (size_t)2 * ((KWR ? (BM + BM / 4 + 15) / 16 * 16 : BM) + (KWR ? KWR : 1) * BN) * BK * sizeof(float);
     // the parked intermediate tile aliases the two A stages when they are big enough (kernel: kAlias); the row-major
-    // epilogue (REPI) adds one [MT][BN / WN + 4] parking block per wave behind everything else
+    // epilogue (REPI) adds one [MT][BN / WN + 4] parking block per wave behind everything else.  kw-reuse tiles: the parked
+    // tile takes the whole tile area, the tail's two [BN][BK] filter stages follow it.
     constexpr bool alias = BM * BN <= 2 * BM * BK;
-    constexpr size_t lds = lds_tiles + (alias ? 0 : (size_t)BM * BN * sizeof(float)) +
-                           (REPI ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, X3, 0, true, REPI>;
+    constexpr size_t lds_plain = lds_tiles + (alias ? 0 : (size_t)BM * BN * sizeof(float)) +
+                                 (REPI ? (size_t)WM * WN * MT * (BN / WN + 4) * sizeof(float) : 0);
+    constexpr size_t lds_kwr = ((size_t)BM * BN + 2 * BN * BK) * sizeof(float);
+    constexpr size_t lds = KWR ? (lds_kwr > lds_tiles ? lds_kwr : lds_tiles) : lds_plain;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, MT, KTAIL, false, true, 2, false, X3, KWR, true, REPI>;
     static bool attr_set[64] = {};   // per device; benign race (idempotent call)
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -39,10 +42,10 @@ static int launch_chain_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     return hip_check(hipGetLastError(), "conv_chain launch");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MT, bool REPI, bool X3 = false>
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool REPI, bool X3 = false, int KWR = 0>
 static int launch_chain(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true, REPI, X3>(a, grid, st);
-    return launch_chain_one<BM, BN, BK, WM, WN, MT, false, REPI, X3>(a, grid, st);
+    if ((a.kA % BK) || (a.kB % BK)) return launch_chain_one<BM, BN, BK, WM, WN, MT, true, REPI, X3, KWR>(a, grid, st);
+    return launch_chain_one<BM, BN, BK, WM, WN, MT, false, REPI, X3, KWR>(a, grid, st);
 }
 
 struct ChainConfig {
@@ -50,18 +53,23 @@ struct ChainConfig {
     const char* name;
     chain_launch_fn launch;
     bool x3;          // split fp32 operands (PTX_F16X3_OPERANDS) in both GEMMs
+    int kwr;          // kw-reuse loader of the first conv (3-wide stride-1 filters, BM a whole number of output rows)
 };
 #define PTX_CHAIN_CFG(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT, false>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain", launch_chain<BM, BN, BK, WM, WN, MT, false>, false, 0 }
 // the tail's epilogue row-major through LDS: 16-byte residual loads / output stores (conv_igemm_kernel.h, REPI)
 #define PTX_CHAIN_CFG_RE(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re", launch_chain<BM, BN, BK, WM, WN, MT, true>, false }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re", launch_chain<BM, BN, BK, WM, WN, MT, true>, false, 0 }
 // split operands (x3): both GEMMs on v_mfma_f32_*_f16 with (hi, lo) half operands; the parked tile stays fp32 and is split
 // at fragment-read time exactly like an activation tile staged from HBM
 #define PTX_CHAIN_CFG_X3(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/x3", launch_chain<BM, BN, BK, WM, WN, MT, false, true>, true }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/x3", launch_chain<BM, BN, BK, WM, WN, MT, false, true>, true, 0 }
 #define PTX_CHAIN_CFG_X3RE(BM, BN, BK, WM, WN, MT) \
-    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re/x3", launch_chain<BM, BN, BK, WM, WN, MT, true, true>, true }
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/chain/re/x3", launch_chain<BM, BN, BK, WM, WN, MT, true, true>, true, 0 }
+// ... with the kw-reuse loader for the first conv (a split-operand 3x3x3 conv2 is bound by its A traffic, not its MFMAs:
+// conv_igemm_kernel.h, KWR): the bottleneck tails of a split-operand plan
+#define PTX_CHAIN_CFG_KWRX3(BM, BN, BK, WM, WN, MT) \
+    { BM, BN, BK, WM, WN, MT, #BM "x" #BN "x" #BK "/" #WM "x" #WN "/m" #MT "/dma/kwr/chain/x3", launch_chain<BM, BN, BK, WM, WN, MT, false, true, 3>, true, 3 }
 
 static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG(64, 64, 32, 2, 2, 32),     // 0  the 3x3x3 -> 1x1x1 bottleneck tail at 64 planes (same tile as the tuned conv2)
@@ -92,6 +100,8 @@ static const ChainConfig kChain[] = {
     PTX_CHAIN_CFG_X3RE(64, 128, 32, 2, 2, 32),
     PTX_CHAIN_CFG_X3RE(32, 64, 64, 2, 2, 16),
     PTX_CHAIN_CFG_X3RE(64, 64, 64, 2, 2, 32),
+    PTX_CHAIN_CFG_KWRX3(224, 64, 16, 7, 1, 32),
+    PTX_CHAIN_CFG_KWRX3(224, 64, 32, 7, 1, 32),
 };
 constexpr int kNumChain = sizeof(kChain) / sizeof(kChain[0]);
 
@@ -138,6 +148,9 @@ extern "C" int ptx_conv3d_chain_supported(const ptx_conv3d_desc* conv, const ptx
     const int n1 = (conv->Co + 3) / 4 * 4;
     if (n1 > c.BN) return 0;                         // the whole intermediate row lives in ONE N tile
     if (c.x3 != ((conv->flags & PTX_F16X3_OPERANDS) != 0)) return 0;     // operand kind of the packed filters = the tile's
+    if (c.kwr && (conv->kW != c.kwr || conv->sW != 1 || conv->Wo < 8 || c.BM % conv->Wo ||
+                  conv->Wo != conv->Wi + 2 * conv->pW - conv->kW + 1))
+        return 0;                                    // kw-reuse: a 3-wide stride-1 filter, the M tile = whole output rows
     return 1;
 }
 
@@ -162,6 +175,8 @@ extern "C" int ptx_conv3d_chain_pick_config(const ptx_conv3d_desc* conv, const p
                      t64x128x32 = named("64x128x32/2x2/m32/dma/chain");
     static const int x64x64 = named("64x64x32/2x2/m32/dma/chain/x3"),
                      x128x64 = named("128x64x32/4x2/m32/dma/chain/x3"), x64x128 = named("64x128x32/2x2/m32/dma/chain/x3");
+    static const int xkwr = named("224x64x16/7x1/m32/dma/kwr/chain/x3");
+    if (x3 && n1 <= 64 && M >= 32768 && ptx_conv3d_chain_supported(conv, tail, xkwr)) return xkwr;     // 3-wide filters, whole-row tiles
     if (x3) return n1 <= 64 ? (M >= 65536 ? x128x64 : x64x64) : x64x128;   // (the 16x16x32 tiles need BK = 64 > a 32-wide N tile)
     if (n1 <= 32) return t64x32;
     if (n1 <= 64) return M < 32768 ? t32x64 : (K <= 128 || conv->Kc % 32 ? t64x64x16 : t64x64x32);
@@ -212,6 +227,7 @@ extern "C" int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3
     fastdiv_make((unsigned)a.Wo, a.dv_wo);
     fastdiv_make((unsigned)a.Ho, a.dv_ho);
     fastdiv_make((unsigned)a.To, a.dv_to);
+    if (c.kwr) fastdiv_make((unsigned)(a.Wo + c.kwr - 1), a.dv_hw);
     a.tiles_per_plane = 0;
     a.ncol = (a.Co + 3) / 4 * 4;
     a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);

@@ -427,7 +427,8 @@ __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
           bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
-    static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22 && KWR == 0), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
+    static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
+    static_assert(!(CHAIN && KWR && REPI), "kw-reuse chained tiles keep the column-wise tail epilogue");
     static_assert(!CHAIN || BN >= BK, "chained tail: the parked tile is cut into BN / BK k-chunks");
     static_assert(!REPI || (DMA && !F16 && !K22 && KWR == 0), "row-major epilogue: fp32-output LDS-DMA tiles (fp32 or split operands)");
     static_assert(KWR == 0 || (KWR == 3 && DMA && NSTAGE == 2 && !K22), "kw-reuse tiles: 3-wide filters, 2-stage LDS-DMA");
@@ -1087,8 +1088,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         // XOR-swizzled by row exactly like a DMA-staged A tile, so the fragment reads are the main loop's.  It aliases
         // the (now idle) A stages when they are big enough, else it sits behind the tile buffers.
         constexpr int KC_MAX = BN / BK;                               // k-chunks of the tail's K axis (K = N1 <= BN)
-        constexpr bool kAlias = BM * BN <= NSTAGE * ASTG;
+        // kw-reuse tiles: their stages (a halo'd A image + three filter tiles) are bigger than P, so P takes the WHOLE tile
+        // area and the tail's own filter stages (one [BN][BK] tile each) sit right behind it
+        static_assert(!KWR || BM * BN <= NSTAGE * (ASTG + BSTG), "kw-reuse chained tile: P must fit the idle stages");
+        constexpr bool kAlias = KWR ? true : BM * BN <= NSTAGE * ASTG;
         float* P = kAlias ? smem : smem + NSTAGE * (ASTG + BSTG);
+        float* Bt = KWR ? smem + BM * BN : Bs;                        // the tail's filter stages
+        constexpr int BTS = KWR ? BN * LDK : BSTG;                    // ... and their stride
         // the main loop leaves its trailing (all-OOB, zero-writing) DMAs in flight and other waves may still be reading
         // the last stage: drain both before P and the B stages are written
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1162,7 +1168,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 off = ok ? off : kOOB;
                 if ((B_F4 % NT == 0) || (wave_u * 64 + NT * i < B_F4))
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rsrc_w2, (lds_ptr_t)(Bs + dbuf * BSTG + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
+                        rsrc_w2, (lds_ptr_t)(Bt + dbuf * BTS + (wave_u * 64 + NT * i) * 4), 16, off, 0, 0, 0);
             }
         };
         const bool res2 = (p.flags2 & PTX_EPI_RES_ADD) != 0, relu2 = (p.flags2 & PTX_EPI_RELU) != 0;
@@ -1171,7 +1177,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
         load_b2(0, 0);
         step_barrier();                                               // P complete, tile 0 landed
-        int offa = frag_off_a, offb = frag_off_b;
+        // (kw-reuse main loops address A rows through a_lrow: the parked tile is indexed by the plain tile row again)
+        int offa = KWR ? (wm * WTM + (lane % MT)) * LDK : frag_off_a, offb = frag_off_b;
         post_barrier_offsets(offa, offb);
         load_b2(1, 1);
         auto read_frags2 = [&](int kc, int bufb, int ks, int slot) {
@@ -1186,8 +1193,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + k0);
-                    fb[slot][j][NF - 1] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + k1);
+                    fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bt + bufb * BTS + offb + j * MT * LDK + k0);
+                    fb[slot][j][NF - 1] = *reinterpret_cast<const f32x4*>(Bt + bufb * BTS + offb + j * MT * LDK + k1);
                 }
                 return;
             }
@@ -1197,7 +1204,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 fa[slot][i][0] = *reinterpret_cast<const f32x4*>(P + kc * (BM * BK) + offa + i * MT * LDK + koff);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bs + bufb * BSTG + offb + j * MT * LDK + koff);
+                fb[slot][j][0] = *reinterpret_cast<const f32x4*>(Bt + bufb * BTS + offb + j * MT * LDK + koff);
         };
         // REPI: the tail's epilogue runs row-major through a per-wave LDS slice behind P and the tile stages
         using RE2 = RowEpi<WTN, MT>;

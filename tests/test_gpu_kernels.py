@@ -1476,6 +1476,8 @@ CHAIN_CASES = [
     ("mid 102 (128-wide N tile): 512 -> 102 -> 512 + residual", 1, 2, 10, 9, 512, 102, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, True, True),
     ("layer2 tail 3x3x3 stride 2 -> 1x1x1, 128 planes", 1, 4, 12, 12, 128, 128, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1), True, True, False),
     ("(1,3,3) conv -> ragged tail 144 -> 100 -> 36, no inner ReLU", 1, 3, 10, 10, 144, 100, 36, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True, False),
+    # 28-wide rows: the kw-reuse chained tiles (224 rows = 8 whole output rows; 9 rows per frame: tiles straddle frames)
+    ("kw-reuse tail 3x3x3 -> 1x1x1 + residual, Wo 28", 1, 3, 9, 28, 64, 64, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True, True),
 ]
 
 
@@ -1523,10 +1525,12 @@ def test_conv_chain(ptx, case, kind):
         tile_x3 = name.endswith("/x3")                               # ".../chain[/re]/x3": split-operand tiles
         core = name[:-3] if tile_x3 else name
         core = core[:-3] if core.endswith("/re") else core           # ".../chain/re": the tail's epilogue row-major through LDS
-        assert core.endswith("/dma/chain")
-        bn_tile = int(name.split("x")[1])
+        assert core.endswith(("/dma/chain", "/dma/kwr/chain"))
+        bm_tile, bn_tile = int(name.split("x")[0]), int(name.split("x")[1])
+        # ".../kwr/chain": the first conv through the kw-reuse loader -- 3-wide stride-1 filters, tiles of whole output rows
+        kwr_ok = "/kwr/" not in name or (k[2] == 3 and s_[2] == 1 and Wo >= 8 and bm_tile % Wo == 0 and Wo == W + 2 * p_[2] - 2)
         ok = lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(d2), cfg)
-        assert bool(ok) == (_r4(N1) <= bn_tile and tile_x3 == x3), (name, N1)
+        assert bool(ok) == (_r4(N1) <= bn_tile and tile_x3 == x3 and kwr_ok), (name, N1)
         if not ok:
             yd = torch.zeros((N, To, Ho, Wo, ldy), device=DEV)
             assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2),
@@ -1543,7 +1547,9 @@ def test_conv_chain(ptx, case, kind):
         base = core[:-len("/chain")] + ("/x3" if x3 else "")
         if base in plain:                                # the two launches it replaces, same tile / MFMA shape: bit-identical
             mid_g = hip_conv(ptx, x, w1, s_, p_, bn=bn1, relu=relu1, cfg=plain[base], split=1, x3=x3)
-            two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=plain[base], split=1, x3=x3)
+            # (a kw-reuse tile does not take the pointwise tail: any 32x32x16 split-operand tile sums k in the same order)
+            tail_cfg = plain["64x64x32/2x2/m32/dma/x3"] if "/kwr/" in name else plain[base]
+            two = hip_conv(ptx, mid_g, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=relu2, res=res, cfg=tail_cfg, split=1, x3=x3)
             pairs += 1
             assert torch.equal(got, two), (name, (got - two).abs().max().item())
     assert ran >= 1 and pairs >= 1
