@@ -507,8 +507,8 @@ def main():
                                   "avg_launch_ms": round(dv["ms"] / dv["launches"], 4)},
                      "roofline_net": {"achieved": round(tf3, 2), "peak": round(peak3, 1), "frac": round(tf3 / peak3, 4),
                                       "vs_fp32_mfma_peak": round(tf3 / PEAK_F32_MFMA_TF, 4),
-                                      "conv_ms_sum": round(sum(r[4] for r in rows3 if r[1] in ("conv", "stem")), 3),
-                                      "non_conv_ms": round(sum(r[4] for r in rows3 if r[1] not in ("conv", "stem")), 3)},
+                                      "conv_ms_sum": round(sum(r[4] for r in rows3 if r[1] in ("conv", "stem", "chain")), 3),
+                                      "non_conv_ms": round(sum(r[4] for r in rows3 if r[1] not in ("conv", "stem", "chain")), 3)},
                      "parity": None}
             if parity is not None:
                 got3 = out3.cpu()[idx]
