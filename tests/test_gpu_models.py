@@ -649,7 +649,8 @@ def test_biggan_generator_fp16(ptx):
 @pytest.mark.parametrize("arch,kw,shape", [("resnet3d50", dict(num_classes=17, pretrained=None), (3, 3, 8, 112, 112)),
                                            ("r2plus1d50", dict(num_classes=17), (2, 3, 16, 112, 112)),
                                            ("nonlocal_r2plus1d50", dict(num_classes=17), (2, 3, 16, 112, 112))])
-def test_chained_and_unchained_plans_agree(ptx, arch, kw, shape, monkeypatch):
+@pytest.mark.parametrize("precision", ["fp32", "x3"])
+def test_chained_and_unchained_plans_agree(ptx, arch, kw, shape, precision, monkeypatch):
     """Chained launches (conv -> 1x1x1 conv in one kernel: bottleneck tails, (2+1)D pointwise pairs) against the
     plan that runs every conv as its own launch, and against the CPU oracle: PTX_CHAIN_FORCE=1 / 0 pin the choice the tuner
     otherwise makes per pair.  Same arithmetic on both sides (bit-identical per tile shape; the two plans may pick different
@@ -661,11 +662,13 @@ def test_chained_and_unchained_plans_agree(ptx, arch, kw, shape, monkeypatch):
         monkeypatch.setenv("PTX_CHAIN_FORCE", force)
         recipe = dict(inner_bn_damp=0.9, nl_bn_damp=0.05) if "r2plus1d" in arch else {}
         model, sd = _build(ptx, arch, kw, 77, **recipe)
+        model.engine().precision = precision          # "x3": the chained launches run on the split-operand chained tiles
         outs[force] = model(x.to(DEV))
         torch.cuda.synchronize()
         plan = list(model.engine()._plans.values())[-1]
         alts = [s for s in plan.steps if isinstance(s, AltStep)]
         assert alts and all(a.use_chain == (force == "1") for a in alts), (arch, force, len(alts))
+        assert all(a.chain.kernel.endswith("/x3") == (precision == "x3") for a in alts), arch
         n_chain = sum(a.use_chain for a in alts)
         assert len(plan.all_convs()) == len(plan.conv_steps) + getattr(plan, "stem_steps", 0) - n_chain, arch
     want = OF.forward(oracle_cfg(arch, kw), sd, x)
