@@ -198,9 +198,55 @@ __device__ __forceinline__ void fused_value(const ConvArgs& p, float acc, int m,
 // 4-byte stores: config-5's 1x1 convs, which are all epilogue, ran at 1.6-2.1 TB/s.)
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
+// How many of a row block's passes get their skip operand early: 16 bytes per lane and pass stay live across the k-loop, and
+// the 8-wave 128x128 tile has ten registers to spare below the 128 that keep two workgroups on a CU.
+constexpr int kSkipEarlyPasses = 2;
+// The skip operand of a fused generator stage, requested BEFORE the k-loop (half residuals only: one 16-byte load per lane
+// and pass).  A block's last conv is a short-K pointwise GEMM (K = 64 .. 512 channels): issued in the epilogue, the skip's
+// HBM round trip came after the operand tiles' one -- two dependent latencies per workgroup on a kernel that is nothing but
+// memory traffic (2.6-3.0 TB/s on the upsampled skips); here both are in flight together.  Same (i, pass) order and the
+// same address arithmetic as fused_stage_epilogue, which consumes `rq`.
+template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+__device__ __forceinline__ void fused_stage_skip_prefetch(const ConvArgs& p, f32x4* rq /* [TM][NPE] */, int m0, int n0, int wm, int wn,
+                                                          int lane) {
+    constexpr unsigned kOOB = 0x80000000u;
+    constexpr int LPR = WTN / 8, RPP = 64 / LPR, NP = (MT + RPP - 1) / RPP;
+    constexpr int NPE = NP < kSkipEarlyPasses ? NP : kSkipEarlyPasses;
+    const bool res_gather = (p.flags & PTX_EPI_RES_PADA) != 0, res_up = (p.flags & PTX_EPI_RES_UP) != 0;
+    const int res_lim = res_gather ? (res_up ? p.Co : p.res_C) : p.ncol;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.r_bytes, 0x00020000);
+    const int co8 = n0 + wn * WTN + (lane % LPR) * 8;
+    const bool c_lo = co8 < p.ncol;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow = m0 + wm * WTM + i * MT;
+#pragma unroll
+        for (int ps = 0; ps < NPE; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int m = mrow + row;
+            const bool ok0 = row < MT && m < p.M && c_lo;
+            unsigned pos = (unsigned)m;
+            if (res_gather) {
+                const unsigned t = fastdiv((unsigned)m, p.dv_wo);
+                const int wo = m - (int)t * p.Wo;
+                const unsigned t2 = fastdiv(t, p.dv_ho);
+                const int ho = (int)t - (int)t2 * p.Ho;
+                const int n = (int)fastdiv(t2, p.dv_to);
+                const int to = (int)t2 - n * p.To;
+                const int rt = res_up ? to >> p.res_sT : to * p.res_sT, rh = res_up ? ho >> p.res_sH : ho * p.res_sH,
+                          rw = res_up ? wo >> p.res_sW : wo * p.res_sW;
+                pos = (unsigned)(((n * p.res_T + rt) * p.res_H + rh) * p.res_W + rw);
+            }
+            const unsigned e = pos * (unsigned)p.ldr + (unsigned)co8;
+            const bool q0 = ok0 && co8 < res_lim;
+            rq[i * NPE + ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, q0 ? e * 2u : kOOB, 0, 0));
+        }
+    }
+}
+
 template <class MF, int TM, int TN, int WTM, int WTN, int MT>
 __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename MF::acc_t (&acc)[TM][TN], int m0, int n0,
-                                                     int wm, int wn, int lane, float* smem, int wave) {
+                                                     int wm, int wn, int lane, float* smem, int wave, const f32x4* rq, bool have_rq) {
     constexpr int NACC = MF::NACC;
     constexpr unsigned kOOB = 0x80000000u;
     constexpr int LDT = WTN + 4;                 // staged row stride (floats): 16-byte aligned rows, rows 4 banks apart
@@ -275,7 +321,9 @@ __device__ __forceinline__ void fused_stage_epilogue(const ConvArgs& p, typename
                 const unsigned e = pos * (unsigned)p.ldr + (unsigned)co8;
                 const bool q0 = ok0 && co8 < res_lim, q1 = ok1 && co8 + 4 < res_lim;
                 if (r16) {               // 8 halfs = one 16-byte load (channels beyond res_lim inside it are masked below)
-                    const half8_t h = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_res, q0 ? e * 2u : kOOB, 0, 0));
+                    const half8_t h = (have_rq && ps < kSkipEarlyPasses)
+                                          ? __builtin_bit_cast(half8_t, rq[i * (NP < kSkipEarlyPasses ? NP : kSkipEarlyPasses) + ps])   // requested before the k-loop
+                                              : __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_res, q0 ? e * 2u : kOOB, 0, 0));
                     k0 = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                     k1 = q1 ? f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
@@ -816,6 +864,17 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             for (int j = 0; j < TN; ++j) load_residual(i, j);
     }
 
+    // fused generator stages (fp16 tiles): the half skip operand, requested now so that its round trip overlaps the
+    // operand tiles' (fused_stage_skip_prefetch)
+    constexpr int kSkipNP0 = F16 ? (MT + 64 / (WTN / 8) - 1) / (64 / (WTN / 8)) : 1;
+    constexpr int kSkipNP = kSkipNP0 < kSkipEarlyPasses ? kSkipNP0 : kSkipEarlyPasses;
+    f32x4 skip_rq[F16 ? TM * kSkipNP : 1];
+    bool skip_early = false;
+    if constexpr (F16) {
+        skip_early = fused_epi && (p.flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) != 0 && (p.flags & PTX_RES_F16) != 0;
+        if (skip_early) fused_stage_skip_prefetch<MF, TM, TN, WTM, WTN, MT>(p, skip_rq, m0, n0, wm, wn, lane);
+    }
+
     // fragment registers, rotated across sub-steps.  The slot sequence must close on itself at the
     // step boundary with compile-time indices: 2 slots for an even sub-step count, KSUB for odd.
     static_assert(KW_T * KSUB >= 2, "at least two sub-steps per k-step");
@@ -1298,7 +1357,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     }
     if constexpr (F16) {
         if (fused_epi) {          // generator stage: per-sample affine / halfs out / dual output / half skip / tanh
-            fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane, smem, wave_u);
+            fused_stage_epilogue<MF, TM, TN, WTM, WTN, MT>(p, acc, m0, n0, wm, wn, lane, smem, wave_u, skip_rq, skip_early);
             return;
         }
     }
