@@ -817,6 +817,11 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     a.M = d->N * d->To * d->Ho * d->Wo;
     a.flags = d->flags;
     {
+        static int skip_early = -1;          // PTX_SKIP_EARLY=0: the fused stages fetch their skip operand in the epilogue (A/B)
+        if (skip_early < 0) { const char* e = getenv("PTX_SKIP_EARLY"); skip_early = (e && atoi(e) == 0) ? 0 : 1; }
+        if (!skip_early) a.flags |= kNoSkipEarly;
+    }
+    {
         const int up = (d->flags & PTX_PRO_UP2) ? 2 : 1;       // the stored input is (Hi/2, Wi/2) behind an upsampling loader
         const uint64_t xb = (uint64_t)d->N * d->Ti * (d->Hi / up) * (d->Wi / up) * d->ldx * 4ull;
         const uint64_t wb = (uint64_t)d->kT * d->kH * d->kW * d->Co_pad * d->Kc * 4ull;

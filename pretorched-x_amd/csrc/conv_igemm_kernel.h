@@ -77,6 +77,8 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const unsigned (&dv)[2])
 }
 
 constexpr unsigned kFusedEpiFlags = PTX_EPI_OUT_F16 | PTX_EPI_AFFINE | PTX_EPI_DUAL_RAW | PTX_RES_F16 | PTX_EPI_TANH;
+// ConvArgs::flags only (never in a descriptor): PTX_SKIP_EARLY=0 in the environment -- A/B switch of fused_stage_skip_prefetch
+constexpr unsigned kNoSkipEarly = 0x40000000u;
 
 // Step barrier.  hipcc may schedule LDS reads of the NEXT buffer above a plain __syncthreads() when it
 // sees no aliasing store in this thread (observed on the LDS-DMA variant, whose only LDS writers are
@@ -871,7 +873,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     f32x4 skip_rq[F16 ? TM * kSkipNP : 1];
     bool skip_early = false;
     if constexpr (F16) {
-        skip_early = fused_epi && (p.flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) != 0 && (p.flags & PTX_RES_F16) != 0;
+        skip_early = fused_epi && (p.flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) != 0 && (p.flags & PTX_RES_F16) != 0 &&
+                     !(p.flags & kNoSkipEarly);
         if (skip_early) fused_stage_skip_prefetch<MF, TM, TN, WTM, WTN, MT>(p, skip_rq, m0, n0, wm, wn, lane);
     }
 
