@@ -31,6 +31,7 @@ CLIPS_PER_GPU, FRAMES, SIZE, CLASSES = 8, 16, 224, 339
 GFLOP_PER_CLIP = 79.692           # 2 x 318.768 GMAC / 8 clips, padding taps counted
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+SUSTAINED_F16_MFMA_TF = 1600.0     # measured: scripts/micro/mfma_f16_peak.hip, random operands (profiles/r03_mfma_f16_peak.txt)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md HBM3E peak
 def _newest_traffic_file():
     """Newest committed PMC traffic table (profiles/rNN_pmc_traffic.json), replayed in roofline.traffic."""
@@ -504,7 +505,12 @@ def main():
                                   "achieved": round(dv["flop"] / dv["ms"] / 1e9, 2), "peak": round(peak3, 1),
                                   "unit": "TFLOP/s (algorithmic fp32-equivalent; peak = 2500 dense f16 / 3 MFMAs per product)",
                                   "frac": round(dv["flop"] / dv["ms"] / 1e9 / peak3, 4), "launches_per_step": dv["launches"],
-                                  "avg_launch_ms": round(dv["ms"] / dv["launches"], 4)},
+                                  "avg_launch_ms": round(dv["ms"] / dv["launches"], 4),
+                                  # what a register-only loop of 32x32x16 f16 MFMAs sustains on RANDOM operands (clock / power):
+                                  # 1.57-1.65 of the 2.5 PFLOP/s (profiles/r03_mfma_f16_peak.txt); informational, `frac` stays
+                                  # against the nominal dense peak
+                                  "peak_sustained_random_operands": round(SUSTAINED_F16_MFMA_TF / 3.0, 1),
+                                  "frac_of_sustained": round(dv["flop"] / dv["ms"] / 1e9 / (SUSTAINED_F16_MFMA_TF / 3.0), 4)},
                      "roofline_net": {"achieved": round(tf3, 2), "peak": round(peak3, 1), "frac": round(tf3 / peak3, 4),
                                       "vs_fp32_mfma_peak": round(tf3 / PEAK_F32_MFMA_TF, 4),
                                       "conv_ms_sum": round(sum(r[4] for r in rows3 if r[1] in ("conv", "stem", "chain")), 3),
