@@ -174,10 +174,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PTX_BENCH_BACKEND=gloo: a functional check of the N > 1 branches on a box with FEWER GPUs than ranks (ranks share
+    # devices round-robin, collectives go through gloo) -- never a scaling figure; the line says so in `config.parallelism`
+    backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local)
@@ -531,7 +539,10 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
             "config": {"workload": workload_label,
                        "clips_per_gpu": units_per_gpu, "global_batch": total_units,
-                       "parallelism": "clip-parallel x%d, one all-gather of logits" % world},
+                       "parallelism": "clip-parallel x%d, one all-gather of logits" % world +
+                                      ("" if backend == "nccl" or world == 1 else
+                                       " -- FUNCTIONAL CHECK over %s, ranks sharing %d device(s): not a scaling figure" % (
+                                           backend, torch.cuda.device_count()))},
             "roofline": roofline, "roofline_longest_launch": roofline_longest, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
             "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
             "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
