@@ -819,3 +819,32 @@ def test_x3_config2_full_size_parity(ptx):
     assert err <= 2e-4, err            # fp32-class: the fp32-MFMA path measures 1.5e-5 here
     assert torch.equal(out.cpu().argmax(1), ref.argmax(1))
     print("cfg2 x3 max|dlogits| = %.3e (max|logit| %.2f)" % (err, ref.abs().max().item()))
+
+
+def test_rccl_single_rank_collectives(ptx):
+    """RCCL itself on the box: a 1-rank "nccl" process group (the only size a 1-GPU box can form) runs the collectives of
+    the clip-parallel path on device tensors -- all_gather_into_tensor, the all_reduce self-check of
+    parallel.verify_gather and the tuned-table broadcast -- in a fresh process (process groups are per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, importlib, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ptx = importlib.import_module("pretorched_x_amd")
+from pretorched_x_amd.parallel import verify_gather, broadcast_tuned_table
+x = torch.randn(8, 339, device="cuda")
+out = x.new_empty((8, 339))
+dist.all_gather_into_tensor(out, x)
+assert torch.equal(out, x)
+v = verify_gather(x, out)
+assert v == {"gather_order_ok": True, "replicas_identical": True, "ranks": 1, "rows": 8}, v
+assert broadcast_tuned_table(src=0) > 0
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
