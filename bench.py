@@ -155,6 +155,28 @@ def timed_steps(run, total_units, steps, warmup, dev, sync):
     return elapsed, out, verify
 
 
+def self_launch(n):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`.
+    Fails loudly when the node has fewer than n GPUs (PTX_BENCH_BACKEND=gloo -- the functional check in which ranks share
+    devices -- is exempt)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if os.environ.get("PTX_BENCH_BACKEND", "nccl") == "nccl" and have < n:
+        raise SystemExit("bench.py --gpus %d: this node has %d visible GPU(s); one rank per GPU is required "
+                         "(PTX_BENCH_BACKEND=gloo runs a functional check with ranks sharing devices)" % (n, have))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +192,11 @@ def main():
                          "clips, cfg4: 16) sharded over the ranks -- at 8 GPUs the headline batch leaves 1 clip per GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU, RCCL) by re-executing under
+        # torch.distributed.run -- the same command line the driver uses.  The N = 1 path never gets here.
+        self_launch(args.gpus)
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +204,27 @@ def main():
     # PTX_BENCH_BACKEND=gloo: a functional check of the N > 1 branches on a box with FEWER GPUs than ranks (ranks share
     # devices round-robin, collectives go through gloo) -- never a scaling figure; the line says so in `config.parallelism`
     backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
+    if os.environ.get("PTX_BENCH_LAUNCH_CHECK") == "1":
+        # launcher check (runs without GPUs, tests/test_parallel_gloo.py): the ranks `--gpus N` started rendezvous over gloo,
+        # report who they are, rank 0 prints the line's launch-related fields, nothing is measured
+        if args.gpus != world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = [None] * world
+        me = {"rank": rank, "local_rank": local, "pid": os.getpid()}
+        if world > 1:
+            dist.all_gather_object(seen, me)
+            dist.barrier()
+        else:
+            seen = [me]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": {
+                "world_size": dist.get_world_size() if world > 1 else 1, "distinct_pids": len({r["pid"] for r in seen}),
+                "local_ranks": sorted(r["local_rank"] for r in seen)}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
@@ -186,8 +234,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -252,6 +300,9 @@ def main():
         ranks_seen = {"world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(),
                       "distinct_devices": len({r["device"] for r in seen}), "ranks": seen,
                       "tuned_entries_broadcast": tuned_entries}
+        if backend == "nccl" and ranks_seen["distinct_devices"] != world:
+            raise SystemExit("bench.py: %d ranks on %d distinct GPUs -- one rank per GPU is the contract" % (
+                world, ranks_seen["distinct_devices"]))
 
     ms_per_step = 1e3 * elapsed / args.steps
     clips_per_s = total_units * args.steps / elapsed
@@ -547,6 +598,8 @@ def main():
             "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
             "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
             "commit": os.environ.get("PTX_COMMIT"),
+            # which sources the loaded libptx_amd.so was compiled from, and whether that is this tree (build.py stamps it)
+            "binary": {"version": ptx._lib.lib().ptx_version().decode(), "source_sha256_matches_tree": ptx._lib.binary_source_hash() == ptx._lib.source_hash()},
             "distributed_check": verify, "ranks_seen": ranks_seen,
         }
     if rank == 0 and os.environ.get("PTX_TUNED_OUT"):      # tile choices of this run (both legs), for tuned_gfx950.json

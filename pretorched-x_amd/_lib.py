@@ -183,6 +183,21 @@ def lib():
     return _lib
 
 
+def source_hash():
+    """sha256 of the library's sources as they are in THIS tree (csrc/build.py:source_hash -- the same function build.py
+    compiles into ptx_version()).  Equal to `binary_source_hash()` iff the loaded .so was built from this tree."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ptx_build", os.path.join(_HERE, "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
+def binary_source_hash():
+    """The source hash the loaded libptx_amd.so carries (the part of ptx_version() after "src:")."""
+    return lib().ptx_version().decode().rsplit("src:", 1)[-1]
+
+
 def check(status, what=""):
     if status != 0:
         msg = lib().ptx_last_error().decode(errors="replace")

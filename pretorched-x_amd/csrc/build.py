@@ -7,6 +7,7 @@ Objects and the shared library are written next to this file's parent package
 snapshot to the GPU box.  `--report` adds -Rpass-analysis=kernel-resource-usage.
 """
 import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
@@ -24,6 +25,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 EXTRA_FLAGS = {"nonlocal_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+def source_hash():
+    """sha256 over every source the library is compiled from (csrc/*.hip, csrc/*.h, include/ptx_amd.h; sorted by file
+    name, each as name + NUL + bytes).  Compiled into ptx_version() so a test run can prove WHICH source the loaded
+    binary was built from (the .so travels prebuilt to the GPU box; VERDICT r3 #10)."""
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(HERE) if f.endswith((".hip", ".h")))
+    for path in [os.path.join(HERE, f) for f in files] + [os.path.join(HERE, "..", "..", "include", "ptx_amd.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+VERSION_SOURCE = "pack_layout.hip"       # defines ptx_version(): compiled with -DPTX_SOURCE_SHA256
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -34,13 +51,23 @@ def _stale(target, deps):
 def _compile(src, report):
     obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    extra, stamp, sha = [], obj + ".srchash", None
+    if src == VERSION_SOURCE:            # the object that carries the hash is rebuilt whenever ANY source changed
+        sha = source_hash()
+        extra = ['-DPTX_SOURCE_SHA256="%s"' % sha]
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if have != sha and os.path.exists(obj):
+            os.remove(obj)
     if not _stale(obj, deps):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + (["-Rpass-analysis=kernel-resource-usage"] if report else []) + \
           ["-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stdout))
+    if sha is not None:
+        with open(stamp, "w") as f:
+            f.write(sha + "\n")
     return obj, r.stdout
 
 

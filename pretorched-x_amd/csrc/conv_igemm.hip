@@ -585,7 +585,21 @@ extern "C" const char* ptx_conv3d_config_name(int config) {
 
 extern "C" int ptx_conv3d_config_supported(const ptx_conv3d_desc* d, int config) {
     if (validate_desc(d) != PTX_OK || config < 0 || config >= kNumConfigs) return 0;
-    return 1;   // K / M / N tails are all guarded inside the kernel
+    // the refusals of launch_conv, decided from the descriptor alone -- so a stale tuned-table entry is dropped when a plan
+    // is COMPILED and never reaches a launch (K / M / N tails are all guarded inside the kernel)
+    const ConvConfig& c = kConfigs[config];
+    if (((d->flags & PTX_F16_OPERANDS) != 0) != (c.f16 != 0)) return 0;          // operand kind <-> tile kind
+    if (((d->flags & PTX_F16X3_OPERANDS) != 0) != (c.x3 != 0)) return 0;
+    const int groups = d->groups > 1 ? d->groups : 1;
+    const bool dual = d->x2_C > 0;
+    if (c.kwr) {                                                                  // kw-reuse tiles: whole output rows of a
+        // dense stride-1 filter of THAT width (desc.Wi is the extent the filter slides over, upsampled or not)
+        if (d->kW != c.kwr || d->sW != 1 || dual || groups > 1 || d->Wo < 8 || c.BM % d->Wo ||
+            d->Wo != d->Wi + 2 * d->pW - d->kW + 1)
+            return 0;
+    }
+    if (groups > 1 && !c.direct && ((d->Co / groups) % c.BN || dual)) return 0;  // an MFMA tile stays inside one group
+    return 1;
 }
 
 extern "C" int ptx_conv3d_pick_config(const ptx_conv3d_desc* d, int* split_k) {

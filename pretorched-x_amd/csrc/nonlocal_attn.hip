@@ -233,9 +233,12 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const bool moved = m_new > m_run;
-            const float alpha = __expf(m_run - m_new);         // exp(-inf) = 0 on the first tile
+            // a wave (key group) that has seen no valid key yet keeps m = -inf: exp(-inf - (-inf)) would be NaN, so the
+            // reference point of the exponentials is 0 until a key arrives (alpha = p = 0)
+            const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(m_run - m_ref);         // exp(-inf) = 0 on the first tile
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = __expf(s[r] - m_new);
+            for (int r = 0; r < 4; ++r) pr[r] = __expf(s[r] - m_ref);
             l_run = l_run * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
             m_run = m_new;
             if (__any(moved)) {               // O rows are queries 4*gq + r: fetch their alpha from lane (4*gq + r)
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
         if constexpr (SOFTMAX) {
             const float M = fmaxf(m_run, m1);             // finite: group 0 always owns at least one valid key
             a0 = __expf(m_run - M);
-            a1 = __expf(m1 - M);                          // exp(-inf) = 0 when group 1 saw no key
+            a1 = __expf(m1 - M);                          // exp(-inf) = 0 when group 1 saw no key (its O and l are 0)
             l_run = l_run * a0 + l1 * a1;
         }
 #pragma unroll
@@ -454,9 +457,12 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     if (d->d > 512) return launch_nl_tg<1024, 128>(a, st);
     // key split (two wave groups over the key tiles): when the plain grid is below two workgroups per CU -- i.e. one wave
     // per SIMD -- and there are enough keys to split.  PTX_NL_KSPLIT=0 / 1 forces it off / on (A/B runs).
+    // The choice depends on PER-SAMPLE extents only (never on the batch): a clip's logits must not change bits with the
+    // batch size or a rank's shard size (the reference is batch-independent, nonlocalnet.py:143-166).  At large
+    // grids the two variants measure the same (8 waves per CU either way), so the key split is simply the kernel for
+    // 64 < d <= 256 and Nk >= 128.
     static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
-    const int64_t wgs = (int64_t)a.q_tiles * a.batch * cdiv(a.dv, d->dv <= 128 ? 128 : 256);
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && wgs < 2 * kNumCU && a.Nk >= 128);
+    const bool ksplit = ks_env != 0 && a.Nk >= 128;
     if (ksplit && d->d > 64 && d->d <= 256) {
         if (d->mode & PTX_NL_X3) return d->dv <= 128 ? launch_nl_ks_x3<256, 128>(a, st) : launch_nl_ks_x3<256, 256>(a, st);
         return d->dv <= 128 ? launch_nl_ks<256, 128>(a, st) : launch_nl_ks<256, 256>(a, st);

@@ -302,7 +302,12 @@ __global__ void __launch_bounds__(256) checksum_f32_kernel(const long long* __re
 
 using namespace ptx;
 
-extern "C" const char* ptx_version(void) { return "ptx_amd 0.1.0 (gfx950, fp32 MFMA)"; }
+// PTX_SOURCE_SHA256: sha256 of csrc/*.hip, csrc/*.h and include/ptx_amd.h, computed by build.py (source_hash) and passed on
+// this file's command line -- `ptx_version()` names the source the loaded binary was compiled from
+#ifndef PTX_SOURCE_SHA256
+#define PTX_SOURCE_SHA256 "unstamped"
+#endif
+extern "C" const char* ptx_version(void) { return "ptx_amd 0.4.0 (gfx950, fp32 MFMA) src:" PTX_SOURCE_SHA256; }
 extern "C" const char* ptx_last_error(void) { return last_error_buf(); }
 
 extern "C" size_t ptx_packed_weight_elems(const ptx_pack_desc* d) {

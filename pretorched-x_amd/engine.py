@@ -1234,7 +1234,10 @@ class Plan:
                 # the bottleneck's tail conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu (resnet3D.py:129-142)
                 # as one chained launch: conv2's output tile never leaves the workgroup
                 k2, s2, p2 = _geom(blk.conv2)
-                tail = self.conv_chain(o, self.pack(blk.conv2, blk.bn2), s2, p2, self.pack(blk.conv3, blk.bn3), relu1=True,
+                # conv_chain composes conv2's geometry with a UNIT-stride, unpadded pointwise tail: anything else keeps
+                # the two launches (the reference's bottlenecks qualify, resnet3D.py:117-119; a user-edited block may not)
+                plain_tail = _geom(blk.conv3) == ((1, 1, 1), (1, 1, 1), (0, 0, 0)) and not getattr(blk.conv3, "tf_same", False)
+                tail = None if not plain_tail else self.conv_chain(o, self.pack(blk.conv2, blk.bn2), s2, p2, self.pack(blk.conv3, blk.bn3), relu1=True,
                                        relu2=True, res=res, label=name + ".conv2+conv3", y=out)
             first = len(self.steps)
             o2 = self.conv_bn(o, blk.conv2, blk.bn2, relu=True, label=name + ".conv2")
@@ -1960,25 +1963,22 @@ class Engine:
         return plan
 
     def profile_convs(self, model, x, iters=5, plan=None):
-        """Per-conv-launch timing with HIP events on the current stream (for bench.py's roofline).  `plan`:
-        an already compiled (and run) plan, for models whose input is not one NCDHW tensor."""
-        rows = []
+        """Per-conv-launch timing with HIP events on the current stream: the launches the forward RUNS (`plan.all_convs()`:
+        the active side of every chain-or-pair decision, chained launches and direct stems included), as rows of
+        (label, MACs, ms, tile / kernel name, split-K).  `plan`: an already compiled (and run) plan, for models whose input
+        is not one NCDHW tensor."""
         with torch.cuda.device(x.device):
             if plan is None:
                 self._validate(model, x, model.arch.dims)
                 plan = self.plan_for(model, _dense16(x))
                 plan.bind(model)
                 plan.run_features(_dense16(x))
-            for stp in plan.conv_steps:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                stp(_stream())
-                e0.record()
-                for _ in range(iters):
-                    stp(_stream())
-                e1.record()
-                e1.synchronize()
-                rows.append((stp.label, stp.macs, e0.elapsed_time(e1) / iters,
-                             _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp.split))
+            live = set(id(s) for s in plan.all_convs())
+            rows = []
+            for r in self.profile_steps(plan, iters):
+                if r[1] in ("conv", "stem", "chain"):
+                    rows.append((r[0], r[3], r[4], r[5], r[6].split if r[1] == "conv" else 1))
+            assert len(rows) == len(live)
         return rows
 
 

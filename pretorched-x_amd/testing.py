@@ -46,7 +46,7 @@ def _is_closing_bn(prefix, keys):
 
 
 def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=NL_BN_DAMP, inner_bn_damp=1.0,
-                     unit_bn_damp=1.0, conv_fan="out", closing_conv_damp=1.0):
+                     unit_bn_damp=1.0, conv_fan="out", closing_conv_damp=1.0, nl_embed_damp=1.0):
     """template: mapping key -> tensor (only shape/dtype are used). Returns an OrderedDict of
     fresh CPU fp32 tensors with the same keys/shapes.
 
@@ -57,9 +57,22 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
     of an I3D Unit3D (`*.bn` next to `*.conv3d`).  `conv_fan`: 'out' = the reference's kaiming-normal
     fan_out (resnet3D.py:198); 'in' = fan_in, for Inception stacks whose 1x1x1 reductions (192 -> 16)
     would otherwise amplify 2*Cin/Cout per layer; `closing_conv_damp` scales the filters
-    that close a BigGAN-deep residual branch (`conv4`, attention `o`), which has no BN after them.  Fixtures record the values they were generated with."""
+    that close a BigGAN-deep residual branch (`conv4`, attention `o`), which has no BN after them;
+    `nl_embed_damp` scales the non-local block's theta / phi embeddings (weights and biases): the softmax input
+    theta^T phi grows with the SQUARE of the activation scale, and with kaiming filters it reaches 1e2 ... 1e4 in a
+    random-weight network -- a hard arg-max whose winner flips under fp32 rounding (round 4: the reference's own CPU
+    forward then differs from its fp64 self by 1e-2 relative).  damp^2 brings the affinities back to the O(1-30) range of
+    a trained network, so the NL branch can be tested at FULL strength (`nl_bn_damp` = 1).  Fixtures record the values
+    they were generated with."""
     keys = set(template.keys())
     out = OrderedDict()
+
+    def embed_damp(key):
+        # a float, or {key prefix: factor} (activations grow with depth, and the affinities with their square)
+        if isinstance(nl_embed_damp, dict):
+            return next((float(v) for k, v in nl_embed_damp.items() if key.startswith(k)), 1.0)
+        return float(nl_embed_damp)
+
     for key, ref in template.items():
         shape = tuple(ref.shape)
         g = _gen(seed, key)
@@ -95,6 +108,8 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
             out[key] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
             if prefix.endswith(".conv4") or prefix.endswith(".o"):      # closes a BigGAN residual / attention branch
                 out[key] = out[key] * closing_conv_damp
+            if ".nonlocalblock." in key and (prefix.endswith(".theta") or prefix.endswith(".phi") or prefix.endswith(".phi.0")):
+                out[key] = out[key] * embed_damp(key)
         elif leaf == "weight" and shape == (1, 3) and prefix.endswith(".linear") and (prefix[:-7] + ".weight") in keys:
             # MultiViewConv's view-mixing Linear(3, 1) (multiview.py:50): positive weights with sum of squares ~ 1, so the
             # three-view sum keeps the signal scale of a plain conv (default Linear init would shrink it 0.58x per layer)
@@ -104,6 +119,8 @@ def synth_state_dict(template, seed=1234, last_bn_damp=LAST_BN_DAMP, nl_bn_damp=
             out[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound
         elif leaf == "bias":                                # conv / linear bias
             out[key] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+            if ".nonlocalblock." in key and (prefix.endswith(".theta") or prefix.endswith(".phi") or prefix.endswith(".phi.0")):
+                out[key] = out[key] * embed_damp(key)
         else:
             raise KeyError("synth_state_dict: unclassified key %r" % key)
     return out

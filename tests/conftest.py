@@ -76,11 +76,14 @@ GOLDEN_CASES = {
     "nonlocal_r2plus1d50_cfg3": ("nonlocal_r2plus1d50", dict(num_classes=339)),
     "r2plus1d50_cfg3": ("r2plus1d50", dict(num_classes=400)),
     "nonlocalresnet3d50_cfg3": ("nonlocalresnet3d50", dict(pretrained=None)),
+    "nonlocal_r2plus1d50_cfg3_fullnl": ("nonlocal_r2plus1d50", dict(num_classes=339)),
+    "nonlocalresnet3d50_16x224_fullnl": ("nonlocalresnet3d50", dict(pretrained=None)),
 }
 TRN_CASES = ("trn_htrn_small", "trn_mstrn_small", "trn_trn_b1")
 SLOWFAST_CASES = ("slowfast50_sf_small", "slowfast50_s_small", "slowfast50_f_small", "slowfast18_sf_small",
                   "slowfast50_sf_full")
-FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3")
+FULL_SIZE = ("resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3", "r2plus1d50_cfg3", "nonlocalresnet3d50_cfg3",
+             "nonlocal_r2plus1d50_cfg3_fullnl", "nonlocalresnet3d50_16x224_fullnl")
 
 
 def oracle_cfg(arch, kw):

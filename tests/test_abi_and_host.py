@@ -20,6 +20,10 @@ def test_header_and_bindings_agree(ptx):
     for name in declared:
         assert hasattr(lib, name)
     assert b"gfx950" in lib.ptx_version()
+    # the binary names the sources it was compiled from (sha256 over csrc/*.hip, csrc/*.h, include/ptx_amd.h, computed by
+    # build.py): what a test run loads is what this tree's source compiles to
+    from pretorched_x_amd import _lib as L
+    assert len(L.binary_source_hash()) == 64 and L.binary_source_hash() == L.source_hash()
 
 
 def test_struct_layouts_match_header(ptx):
@@ -541,9 +545,35 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx, d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, 1, 8, 8, 20, 20, 1, 8, 8, 8, 8
     d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
     d.Kc, d.Co_pad, d.flags = 20, 128, L.PTX_F16X3_OPERANDS        # Kc % 8 != 0
-    assert lib.ptx_conv3d_config_supported(C.byref(d), 0) == 0
+    x3_tile = engine._config_index("64x64x32/2x2/m32/dma/x3")
+    assert lib.ptx_conv3d_config_supported(C.byref(d), x3_tile) == 0
     d.Kc = 24
-    assert lib.ptx_conv3d_config_supported(C.byref(d), 0) == 1
+    assert lib.ptx_conv3d_config_supported(C.byref(d), x3_tile) == 1
+    # ... and the gate mirrors what a LAUNCH would refuse, so stale tuned-table entries are dropped at plan-build time:
+    # an fp32 tile for a split-operand problem, a kw-reuse tile for a problem that is not whole 3-wide stride-1 rows
+    assert lib.ptx_conv3d_config_supported(C.byref(d), engine._config_index("64x64x32/2x2/m32/dma")) == 0
+    kwr = [i for i in range(lib.ptx_conv3d_num_configs()) if "/kwr" in lib.ptx_conv3d_config_name(i).decode()
+           and lib.ptx_conv3d_config_name(i).decode().endswith("/x3")]
+    assert kwr and all(lib.ptx_conv3d_config_supported(C.byref(d), i) == 0 for i in kwr)      # a 1x1 conv
+    d3 = L.ConvDesc()
+    d3.N, d3.Ti, d3.Hi, d3.Wi, d3.Ci, d3.ldx, d3.To, d3.Ho, d3.Wo, d3.Co, d3.ldy = 1, 1, 56, 56, 64, 64, 1, 56, 56, 64, 64
+    d3.kT, d3.kH, d3.kW, d3.sT, d3.sH, d3.sW, d3.pT, d3.pH, d3.pW = 1, 3, 3, 1, 1, 1, 0, 1, 1
+    d3.Kc, d3.Co_pad, d3.flags = 64, 128, L.PTX_F16X3_OPERANDS
+    ok = [lib.ptx_conv3d_config_name(i).decode() for i in kwr if lib.ptx_conv3d_config_supported(C.byref(d3), i)]
+    assert ok and all(int(n.split("x")[0]) % 56 == 0 for n in ok), ok                          # whole 56-wide rows only
+    d3.sW, d3.Wo = 2, 28
+    assert not any(lib.ptx_conv3d_config_supported(C.byref(d3), i) for i in kwr)              # strided: never
+    # a plan compiled against a table that holds such an entry falls back to the library's default tile, silently and at
+    # BUILD time (no warning, no mid-forward workspace growth)
+    m2 = ptx.resnet3d18(num_classes=4, pretrained=None)
+    m2.engine().precision = "x3"
+    p0 = m2.engine().dry_plan(m2, (1, 3, 4, 32, 32))
+    victim = next(s_ for s_ in p0.conv_steps if s_.d.kW == 3 and s_.d.sW == 2)
+    import json as _json
+    engine.tuned_merge({_json.dumps(victim.d.key()): (lib.ptx_conv3d_config_name(kwr[0]).decode(), 1)})
+    p1 = m2.engine().dry_plan(m2, (1, 3, 4, 32, 32))
+    hit = next(s_ for s_ in p1.conv_steps if s_.d.key() == victim.d.key())
+    assert not hit.from_table and "/kwr" not in lib.ptx_conv3d_config_name(hit.cfg).decode()
     sk = C.c_int(0)
     assert lib.ptx_conv3d_config_name(lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))).decode().endswith("/x3")
     pd = L.PackDesc(8, 20, 1, 1, 1, 20, 128, 0)

@@ -848,3 +848,59 @@ print("rccl-ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("case", ["nonlocal_r2plus1d50_cfg3_fullnl", "nonlocalresnet3d50_16x224_fullnl"])
+def test_nl_batch_size_and_stream_equivalence(ptx, case):
+    """the reference is batch-independent by construction (per-sample softmax, eval-mode BN:
+    nonlocalnet.py:143-166, :397-420) -- so must every execution shape of the HIP engine be.  The NL + (2+1)D composite at
+    config 3's size (N = 1568 / 196 keys) and NonLocalResNet3D-50 at the reference's 16 x 224 x 224 input (N = 3136 / 392),
+    NL branch at FULL strength (W.1 gamma undamped; the fixture's theta / phi embeddings are scaled so the softmax input
+    stays in the O(1-60) range of a trained network -- tests/golden/make_golden.py RECIPES says why): one B-clip plan, two
+    B/2-clip forwards sequentially on one model, B single-clip forwards, and two model instances on two HIP streams
+    running concurrently, each against the REAL reference's logits (golden) and the CPU oracle (2 clips, same run).
+    Bar: 3e-5 of the logits' scale (the network's fp32 noise floor on the CPU is 6e-7 ... 9e-7 of it, recorded in the
+    fixture) and identical argmax."""
+    arch, kw = GOLDEN_CASES[case]
+    blob = load_golden(case)
+    rec = golden_recipe(blob)
+    model, sd = _build(ptx, arch, kw, **rec)
+    x = golden_input(blob)
+    xd = x.to(DEV)
+    ref = torch.from_numpy(blob["logits"])
+    B, h = x.shape[0], x.shape[0] // 2
+    bar = 3e-5 * ref.abs().max().item()
+    assert bar < TOL
+    outs = {"B=%d" % B: model(xd)}
+    outs["%d+%d sequential" % (h, h)] = torch.cat([model(xd[:h].contiguous()), model(xd[h:].contiguous())], 0)
+    if B > 2:
+        outs["1 x %d" % B] = torch.cat([model(xd[i:i + 1].contiguous()) for i in range(B)], 0)
+    halves = [_build(ptx, arch, kw, **rec)[0] for _ in range(2)]
+    parts = [xd[:h], xd[h:]]
+    for m_, xi in zip(halves, parts):
+        m_(xi)                                            # compile + tune on the default stream
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    cur = torch.cuda.current_stream()
+    for rep in range(3):                                  # concurrent: both plans' launches interleave on the device
+        res = []
+        for m_, xi, st in zip(halves, parts, streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                res.append(m_(xi))
+        for st in streams:
+            cur.wait_stream(st)
+    torch.cuda.synchronize()
+    outs["%d+%d two instances, two streams" % (h, h)] = torch.cat(res, 0)
+    worst = 0.0
+    for name, o in outs.items():
+        e = _check(o, ref, "%s %s vs golden" % (case, name), bar)
+        worst = max(worst, e)
+        assert torch.equal(o.cpu().argmax(1), ref.argmax(1)), name
+    first = outs["B=%d" % B]
+    for name, o in outs.items():
+        assert (o - first).abs().max().item() <= bar, "%s: %s differs from the one-plan forward" % (case, name)
+    want = OF.forward(oracle_cfg(arch, kw), sd, x[:2])
+    _check(first[:2], want, case + " vs oracle (2 clips)", bar)
+    print("%s: worst max|dlogits| over %d execution shapes = %.3e (bar %.2e, max|logit| %.2f, fixture's fp32 noise floor %.1e)" % (
+        case, len(outs), worst, bar, ref.abs().max().item(), float(blob["fp32_noise_floor"])))
