@@ -869,8 +869,7 @@ def test_nl_batch_size_and_stream_equivalence(ptx, case):
     xd = x.to(DEV)
     ref = torch.from_numpy(blob["logits"])
     B, h = x.shape[0], x.shape[0] // 2
-    bar = 3e-5 * ref.abs().max().item()
-    assert bar < TOL
+    bar = min(TOL, 3e-5 * ref.abs().max().item())
     outs = {"B=%d" % B: model(xd)}
     outs["%d+%d sequential" % (h, h)] = torch.cat([model(xd[:h].contiguous()), model(xd[h:].contiguous())], 0)
     if B > 2:
