@@ -370,6 +370,194 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
     }
 }
 
+// DS ("d split"): short sequences (Nq <= 512: the layer3 blocks of the video nets, N = 196 / 392 at C = 1024).  There the
+// kernel above is a handful of long serial chains -- config 3's layer3: batch x 4 query tiles x 2 dv chunks = 64 workgroups,
+// each 13 key tiles x 192 dependent-ish MFMAs = 55 us for 0.6 GFLOP (11 TFLOP/s).  What is scarce is not arithmetic but
+// chain length, so the work of ONE 16-query group is spread over the NW waves of a workgroup along the CHANNEL axes:
+//   * wave w computes the partial S^T tile over its d slice [w D/NW, (w+1) D/NW)  (D / (16 NW) fragment reads x 4 MFMAs),
+//   * the partial tiles (4 floats per lane) meet in LDS, every wave adds them in the same order -> identical S, identical
+//     online-softmax state in every wave (recomputed redundantly: 4 exps per lane),
+//   * wave w multiplies P into ITS dv slice [w DV/NW, ...) of the output: no S recompute across dv chunks any more.
+// Per tile and wave: D/(4 NW) + DV/(4 NW) MFMAs instead of D/4 + DV/4 -- an 8-fold shorter chain at D = DV = 512 -- for two
+// barriers per tile.  A workgroup streams every key / value row of its clip through LDS (N x (D + DV) x 4 B = 0.8 MB at
+// N = 196): L2-resident and irrelevant at these lengths, prohibitive at N = 1568, hence the Nq bound.
+template <int D, int DV, bool SOFTMAX, int NW>
+__global__ void __launch_bounds__(64 * NW) nl_attention_ds_kernel(const NlArgs p) {
+    constexpr int DW = D / NW, VW = DV / NW;         // this wave's slice of d / dv
+    constexpr int QJ = DW / 16, CB = VW / 64;
+    constexpr int F4R = D / 4;
+    constexpr int NKP = 16 * D / 256, NVP = 16 * DV / 256;        // 1-KiB DMA pieces of a 16-key tile
+    static_assert(DW % 16 == 0 && VW % 64 == 0 && F4R >= 16, "slice extents");
+    constexpr unsigned kOOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                                // [2][16][D]   (16-byte slots XOR-swizzled by row)
+    float* Vs = smem + 2 * 16 * D;                   // [2][16][DV]
+    float* Xs = Vs + 2 * 16 * DV;                    // [2][NW][64 lanes][4]: the waves' partial S^T tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, p.q_tiles * p.batch);   // q_tiles counts 16-query groups here
+    const int b = tile / p.q_tiles, qg = tile - b * p.q_tiles;
+    const int n = lane & 15, gq = lane >> 4;
+    const int q = qg * 16 + n;
+
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.theta + (size_t)b * p.bs_t), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.phi + (size_t)b * p.bs_p), 0, p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.g + (size_t)b * p.bs_g), 0, p.g_bytes, 0x00020000);
+
+    f32x4 qf[QJ];                                    // theta[q][this wave's d slice]
+#pragma unroll
+    for (int j = 0; j < QJ; ++j) {
+        const int col = DW * wave + 16 * j + 4 * gq;
+        const unsigned off = ((unsigned)q * (unsigned)p.ld_t + (unsigned)col) * 4u;
+        qf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, (q < p.Nq && col < p.d) ? off : kOOB, 0, 0));
+    }
+    constexpr int KPW = (NKP + NW - 1) / NW, VPW = (NVP + NW - 1) / NW;
+    unsigned koff[KPW], voff[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int f = (wave + NW * i) * 256 + lane * 4;
+        const int row = f / D, slot = (f % D) / 4;
+        const int col = (slot ^ (row & 15)) * 4;
+        koff[i] = col < p.d ? ((unsigned)row * (unsigned)p.ld_p + (unsigned)col) * 4u : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int f = (wave + NW * i) * 256 + lane * 4;
+        const int row = f / DV, col = f % DV;
+        voff[i] = col < p.dv ? ((unsigned)row * (unsigned)p.ld_g + (unsigned)col) * 4u : kOOB;
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const unsigned kbase = (unsigned)t * 16u * (unsigned)p.ld_p * 4u, vbase = (unsigned)t * 16u * (unsigned)p.ld_g * 4u;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+            if (wave + NW * i < NKP)
+                dma16(rs_p, Ks + buf * 16 * D + (wave + NW * i) * 256, koff[i] == kOOB ? kOOB : koff[i] + kbase);
+#pragma unroll
+        for (int i = 0; i < VPW; ++i)
+            if (wave + NW * i < NVP)
+                dma16(rs_g, Vs + buf * 16 * DV + (wave + NW * i) * 256, voff[i] == kOOB ? kOOB : voff[i] + vbase);
+    };
+
+    f32x4 O[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) O[cb][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float inv_nk = 1.0f / (float)p.Nk;
+    const int n_tiles = (p.Nk + 15) / 16;
+    issue_tile(0, 0);
+    const int k_row_off = n * D, v_row_off = 4 * gq * DV + VW * wave + n * 4;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        int ko = k_row_off, vo = v_row_off;
+        tile_barrier(ko, vo);                        // tile t landed; buffer buf^1 and X[buf^1] are free
+        if (t + 1 < n_tiles) issue_tile(t + 1, buf ^ 1);
+        const float* Kb = Ks + buf * 16 * D + ko;
+        const float* Vb = Vs + buf * 16 * DV + vo;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + (((DW * wave) / 4 + 4 * j + gq) ^ n) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (j & 1) s1 = mfma16(kf[e], qf[j][e], s1);
+                else       s0 = mfma16(kf[e], qf[j][e], s0);
+            }
+        }
+        // partial S^T tiles meet in LDS; every wave adds them in wave order (bit-identical S everywhere)
+        float* Xb = Xs + buf * NW * 256;
+        *reinterpret_cast<f32x4*>(Xb + wave * 256 + lane * 4) = s0 + s1;
+        __syncthreads();
+        f32x4 s = *reinterpret_cast<const f32x4*>(Xb + lane * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(Xb + w * 256 + lane * 4);
+
+        float pr[4];
+        if constexpr (SOFTMAX) {
+            const int key0 = t * 16 + 4 * gq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = (key0 + r < p.Nk) ? s[r] : -INFINITY;
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);        // finite from tile 0 on: every 16-key tile of a wave holds a valid key
+            const bool moved = m_new > m_run;
+            const float alpha = __expf(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = __expf(s[r] - m_new);
+            l_run = l_run * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+            m_run = m_new;
+            if (__any(moved)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = __shfl(alpha, 4 * gq + r, 64);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) O[cb][e][r] *= a;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = (p.relu ? fmaxf(s[r], 0.f) : s[r]) * inv_nk;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vb + r * DV + cb * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[cb][e] = mfma16(pr[r], vf[e], O[cb][e]);
+            }
+        }
+    }
+    float inv = 1.f;
+    if constexpr (SOFTMAX) {
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        inv = 1.0f / l_run;
+    }
+    float* yb = p.y + (size_t)b * p.bs_y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float iv = SOFTMAX ? __shfl(inv, 4 * gq + r, 64) : 1.f;
+        const int qo = qg * 16 + 4 * gq + r;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int ch = VW * wave + cb * 64 + 4 * n;
+            if (qo < p.Nq && ch < p.dv) {
+                const f32x4 o = {O[cb][0][r] * iv, O[cb][1][r] * iv, O[cb][2][r] * iv, O[cb][3][r] * iv};
+                *reinterpret_cast<f32x4*>(yb + (size_t)qo * p.ld_y + ch) = o;
+            }
+        }
+    }
+}
+
+template <int D, int DV, int NW>
+static int launch_nl_ds(NlArgs a, hipStream_t st) {
+    constexpr size_t lds = ((size_t)2 * 16 * (D + DV) + (size_t)2 * NW * 256) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    a.q_tiles = cdiv(a.Nq, 16);                      // one 16-query group per workgroup
+    const dim3 grid((unsigned)(a.q_tiles * a.batch));
+    auto launch = [&](auto kernel) -> int {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        PTX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), lds, st, a);
+        return hip_check(hipGetLastError(), "nonlocal attention (d-split) launch");
+    };
+    return a.scale_only ? launch(nl_attention_ds_kernel<D, DV, false, NW>) : launch(nl_attention_ds_kernel<D, DV, true, NW>);
+}
+
 template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false, int KS = 1>
 static int launch_nl_mode(const NlArgs& a, hipStream_t st) {
     constexpr size_t lds_t = (size_t)2 * 16 * KS * (D + DV) * sizeof(float);
@@ -454,6 +642,14 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     }
     // d > 512 ('gaussian' mode at C = 1024): theta fragments come from global memory; fp32 MFMAs whatever the plan's
     // precision (the split-operand mode is fp32-accurate by contract, so the exact kernel is a valid stand-in)
+    // short sequences: the d-split kernel (one 16-query group per workgroup, the channel axes spread over its waves).  Chosen
+    // from PER-SAMPLE extents only, like everything below: a clip's bits must not depend on the batch it arrives in.
+    // Exact fp32 MFMAs also under a split-operand plan (fp32-accurate by contract, as for d > 512).  PTX_NL_DS=0: off (A/B).
+    static const int ds_env = getenv("PTX_NL_DS") ? atoi(getenv("PTX_NL_DS")) : 1;
+    if (ds_env && d->Nq <= 512 && d->d > 64 && d->d <= 512 && d->dv <= 512) {
+        if (d->d <= 256 && d->dv <= 256) return launch_nl_ds<256, 256, 4>(a, st);
+        return launch_nl_ds<512, 512, 8>(a, st);
+    }
     if (d->d > 512) return launch_nl_tg<1024, 128>(a, st);
     // key split (two wave groups over the key tiles): when the plain grid is below two workgroups per CU -- i.e. one wave
     // per SIMD -- and there are enough keys to split.  PTX_NL_KSPLIT=0 / 1 forces it off / on (A/B runs).

@@ -121,22 +121,37 @@ __global__ void __launch_bounds__(256) maxpool3d_slide_kernel(ptx_pool3d_desc d,
 // generic one 27) -- the stride-1 SAME pools of the Inception branches are L1/L2-request bound, not HBM bound.
 template <int HSEG, int WSEG, int S, int NB>
 __global__ void __launch_bounds__(256) maxpool3d_tile_kernel(ptx_pool3d_desc d, const float* __restrict__ x,
-                                                             float* __restrict__ y, unsigned total) {
+                                                             float* __restrict__ y, unsigned total, int xcd_local) {
     constexpr int NR = (HSEG - 1) * S + 3, NC = (WSEG - 1) * S + 3;
     constexpr int RB = NB == 0 ? 1 : (NR + NB - 1) / NB;       // halo rows whose loads are issued together
     const int f4r = (d.C + 3) / 4;
     const int ldy = d.ldy ? d.ldy : d.ld;
     const int wsegs = (d.Wo + WSEG - 1) / WSEG, hsegs = (d.Ho + HSEG - 1) / HSEG;
     const bool pad_zero = (d.flags & PTX_POOL_PAD_ZERO) != 0;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    // xcd_local: workgroup b runs on XCD b % 8 -- give every XCD a CONTIGUOUS chunk of the (n, to, hs, ws) list, so the halo
+    // rows / frames two neighbouring patches share (1.27x spatially, 1.5x temporally for the 3x3x3 / 2 pool) are re-read
+    // from that XCD's own L2 instead of missing in eight of them (round 4)
+    const unsigned blk = (xcd_local & 1) ? (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x) : blockIdx.x;
+    for (unsigned i = blk * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int q = (int)(i % (unsigned)f4r);
         unsigned r = i / (unsigned)f4r;
-        const int ws = (int)(r % (unsigned)wsegs);
-        r /= (unsigned)wsegs;
-        const int hs = (int)(r % (unsigned)hsegs);
-        r /= (unsigned)hsegs;
-        const int to = (int)(r % (unsigned)d.To);
-        const int n = (int)(r / (unsigned)d.To);
+        int ws, hs, to;
+        if (xcd_local & 2) {              // frames innermost: the output frames of one patch sit in one workgroup, so the
+            to = (int)(r % (unsigned)d.To);   // input frames two of them share are re-read from L1 / L2 at once (a kT-frame
+            r /= (unsigned)d.To;              // window of big frames does not survive in a 4 MiB L2 until the next `to`)
+            ws = (int)(r % (unsigned)wsegs);
+            r /= (unsigned)wsegs;
+            hs = (int)(r % (unsigned)hsegs);
+            r /= (unsigned)hsegs;
+        } else {
+            ws = (int)(r % (unsigned)wsegs);
+            r /= (unsigned)wsegs;
+            hs = (int)(r % (unsigned)hsegs);
+            r /= (unsigned)hsegs;
+            to = (int)(r % (unsigned)d.To);
+            r /= (unsigned)d.To;
+        }
+        const int n = (int)r;
         const int t_lo = max(0, to * d.sT - d.pT), t_hi = min(d.Ti, to * d.sT - d.pT + d.kT);
         const bool t_clipped = (t_hi - t_lo) != d.kT;
         const int ho0 = hs * HSEG, wo0 = ws * WSEG;
@@ -662,10 +677,25 @@ extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float
         if (total < (1ull << 31)) {
             const dim3 g(grid_for(total)), b(256);
             const unsigned n = (unsigned)total;
-            if (big && d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 1, 0>), g, b, 0, st, *d, x, y, n);
-            else if (big) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 2, 0>), g, b, 0, st, *d, x, y, n);
-            else if (d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 1, 1>), g, b, 0, st, *d, x, y, n);
-            else hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 2, 1>), g, b, 0, st, *d, x, y, n);
+            // bit 0: XCD-local chunks; bit 1: frames innermost.  Measured per geometry (round 4, scripts/gpu_pool_bench.py,
+            // profiles/r04_pool_order_ab.txt): XCD-local chunks pay when the kT-frame window of a 3-D pool fits the 4 MiB L2 --
+            // config 3's stem pool 56 -> 41 us (5.7 TB/s), I3D's stride-2 Mixed_4 pool 30 -> 21 us, its small stride-1 SAME
+            // pools at 2 clips per GPU 13-18 -> 9-11 us -- and cost elsewhere: config 2's 112 x 112 frames (9.6 MB window:
+            // 112 -> 116 us), every kT = 1 pool (the 2-D stems: 44 -> 47 us), stride-1 pools at batch 8 (113 -> 174 us: eight
+            // XCDs marching through eight clips in lock-step).  Frames-innermost alone or combined never won on the stem pools.
+            // PTX_POOL_XCD=0..3 forces a mode.
+            static const int xl_env = getenv("PTX_POOL_XCD") ? atoi(getenv("PTX_POOL_XCD")) : -1;
+            const size_t window = (size_t)d->kT * d->Hi * d->Wi * d->ld * 4;
+            int xl = 0;
+            if (d->kT > 1 && d->To > 1) {
+                if (d->sW == 2) xl = window <= (6u << 20) ? 1 : 0;
+                else xl = (window <= (3u << 20) && d->N <= 4) ? 1 : 0;
+            }
+            if (xl_env >= 0) xl = xl_env;
+            if (big && d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 1, 0>), g, b, 0, st, *d, x, y, n, xl);
+            else if (big) hipLaunchKernelGGL((maxpool3d_tile_kernel<4, 4, 2, 0>), g, b, 0, st, *d, x, y, n, xl);
+            else if (d->sW == 1) hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 1, 1>), g, b, 0, st, *d, x, y, n, xl);
+            else hipLaunchKernelGGL((maxpool3d_tile_kernel<2, 2, 2, 1>), g, b, 0, st, *d, x, y, n, xl);
             return hip_check(hipGetLastError(), "maxpool3d launch");
         }
     }

@@ -906,16 +906,24 @@ def test_conv_f16_operands(ptx):
     (1, 300, 300, 256, 256, "softmax/x3", "PTX_NL_X3: layer2 width"),
     (2, 90, 90, 40, 24, "scale/x3", "PTX_NL_X3: dot_product mode"),
     (1, 64, 1568, 256, 256, "softmax/x3", "PTX_NL_X3: many key tiles"),
-    (2, 90, 200, 128, 24, "scale", "key split (8 waves, two key groups merged through LDS): dot-product mode"),
-    (1, 130, 333, 200, 200, "softmax", "key split: ragged d / dv / queries / keys, a last tile whose second key group is empty"),
-    (3, 100, 1000, 256, 256, "softmax", "key split: layer2 widths, several clips"),
-    (2, 70, 160, 96, 128, "softmax/x3", "key split, split operands"),
+    (2, 530, 200, 128, 24, "scale", "key split (8 waves, two key groups merged through LDS): dot-product mode"),
+    (1, 530, 333, 200, 200, "softmax", "key split: ragged d / dv / queries / keys, a last tile whose second key group is empty"),
+    (3, 600, 1000, 256, 256, "softmax", "key split: layer2 widths, several clips"),
+    (2, 520, 160, 96, 128, "softmax/x3", "key split, split operands"),
     (2, 196, 196, 1024, 512, "softmax", "gaussian mode at the reference's layer3 width: theta = x, d = C = 1024 (theta from global)"),
     (1, 392, 49, 1024, 512, "softmax", "d = 1024 with sub-sampled keys"),
     (2, 100, 60, 640, 320, "scale", "512 < d < 1024, dot-product scaling"),
     (2, 90, 70, 4, 24, "relu", "concatenation mode: relu(a_i + b_j) / N as a 2-term dot product on 4-float rows"),
     (1, 200, 200, 4, 256, "relu/x3", "concatenation mode, split operands"),
     (2, 196, 196, 1024, 512, "softmax/x3", "d > 512 under an x3 plan: the exact fp32 kernel stands in"),
+    # round 4: Nq <= 512 with 64 < d <= 512 runs the d-split kernel (16-query workgroups, channel axes spread over the waves);
+    # the cases above with such extents exercise it too (config 3's layer3: 196 x 196 x 512 x 512)
+    (1, 576, 1568, 256, 256, "softmax", "the 64-query kernel on many key tiles (Nq > 512 keeps it off the d-split kernel)"),
+    (2, 50, 25, 200, 136, "softmax", "d-split <256,256,4>: ragged d / dv / queries / keys"),
+    (2, 196, 98, 512, 512, "scale", "d-split <512,512,8>: dot-product mode, sub-sampled keys"),
+    (1, 392, 392, 512, 512, "softmax", "d-split: layer3 of NonLocalResNet3D-50 at the reference's 16 x 224 x 224 input"),
+    (3, 17, 300, 320, 400, "softmax", "d-split <512,512,8> with padded slices, one ragged query group per clip"),
+    (2, 100, 60, 72, 264, "relu", "d-split, relu(S) / N weights"),
 ])
 def test_fused_nonlocal_attention(ptx, case):
     """ptx_nonlocal_fwd against the reference's op sequence (nonlocalnet.py:143-166 / :192-211): matmul ->
