@@ -464,6 +464,33 @@ int ptx_softmax_rows(float* x, int64_t rows, int32_t cols, int32_t ld, int32_t s
 int ptx_transpose_last2(const float* x, float* y, int32_t batch, int32_t R, int32_t Cc, int32_t ldx,
                         int32_t ldy, ptx_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * fp16 kernels of the generator stage designed for the fp16 matrix cores (gen_stage_f16.hip; BASELINE config 5).
+ * BigGAN-deep has no source in the reference snapshot: the layer definitions follow Brock et al. 2019,
+ * appendix B (BigGAN-deep generator); parity of everything below is UNPINNED.
+ *
+ * ptx_rgb_conv3x3_f16_fwd -- the generator's output layer in one launch:
+ *     y[n][h][w][co] = tanh( bias[co] + sum_{kh,kw,c} relu(x[n][h+kh-1][w+kw-1][c] * scale[n][c] + shift[n][c]) * w[co][c][kh][kw] )
+ * i.e. BN (folded to a per-sample affine by ptx_cbn_fold) -> ReLU -> conv3x3(C -> 3, zero padding of the ACTIVATED
+ * map) -> tanh (PTX_EPI_TANH in flags; 0 = no tanh).  x: halfs [N][H][W][ldx], the RAW output of the last GBlock;
+ * y: fp32 [N][H][W][ldy] (3 live columns; with ldy >= 4 a zero 4th column is written: one 16-byte store per pixel).
+ * The nine taps sit in the N axis of ONE GEMM over the input positions (K = C, N = 27 -> 32), the shifted partial sums
+ * are combined through LDS: the input is read once, no activated copy of it exists.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_rgb_conv_desc {
+    int32_t N, H, W, C;      /* C = 32, 64 or 128                                      */
+    int32_t ldx;             /* channel stride of x in halfs (multiple of 8, >= C)     */
+    int32_t ldy;             /* row stride of y in floats (3, or a multiple of 4)      */
+    int32_t ld_affine;       /* row stride of scale / shift in floats (multiple of 4)  */
+    uint32_t flags;          /* PTX_EPI_TANH or 0                                      */
+} ptx_rgb_conv_desc;
+int ptx_rgb_conv3x3_f16_supported(const ptx_rgb_conv_desc* desc);
+size_t ptx_rgb_conv_weight_elems(int32_t C);                 /* halfs of the packed filter */
+/* w [3][C][3][3] fp32 (torch Conv2d layout) -> the kernel's B-fragment order, halfs */
+int ptx_pack_rgb_conv_weight(const float* w, int32_t C, void* w_packed, ptx_stream_t stream);
+int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* desc, const void* x, const float* scale, const float* shift,
+                            const void* w_packed, const float* bias /* [3] or NULL */, float* y, ptx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

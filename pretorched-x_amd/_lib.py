@@ -96,6 +96,12 @@ class NonlocalDesc(C.Structure):
 
 PTX_NL_SOFTMAX, PTX_NL_SCALE, PTX_NL_F16, PTX_NL_X3, PTX_NL_RELU = 0, 1, 2, 4, 8
 
+
+class RgbConvDesc(C.Structure):
+    """ptx_rgb_conv_desc: the generator's output layer BN -> ReLU -> conv3x3(C -> 3) -> tanh in one launch."""
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "ldx", "ldy", "ld_affine")] + [("flags", C.c_uint32)]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
@@ -152,6 +158,10 @@ SIGNATURES = {
     "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),
     "ptx_softmax_rows": (C.c_int, [_P, _L, _I, _I, _I, _P]),
     "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ptx_rgb_conv3x3_f16_supported": (C.c_int, [C.POINTER(RgbConvDesc)]),
+    "ptx_rgb_conv_weight_elems": (_Z, [_I]),
+    "ptx_pack_rgb_conv_weight": (C.c_int, [_P, _I, _P, _P]),
+    "ptx_rgb_conv3x3_f16_fwd": (C.c_int, [C.POINTER(RgbConvDesc), _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -352,6 +352,14 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         t = self.conv(t, pk(blk.conv3), one, (0, 1, 1), relu=True, affine=tab(blk.bn4), out_f16=True, label=name + ".conv3")
         skip = dict(res=xr) if (not up and blk.in_channels == blk.out_channels) else \
             dict(res=xr, res_kind="up", res_stride=(0, int(up), int(up)))
+        if nxt is None and _rgb_conv_ok(self, blk.conv4.out_channels):
+            # last block, image conv on its own kernel (round 4): the output layer's BN + ReLU runs on that kernel's A
+            # fragments, so this conv stores the RAW sum only -- no activated copy of the last feature map exists
+            xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)
+            xa = None
+            self.feat = _rgb_conv(self, xr, model.output_layer[2], _ptr(oscale), _ptr(oshift), obn.channels)
+            self.pooled = None
+            return
         if nxt is None:                          # last block: the output layer's BN + ReLU in the epilogue
             xa = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=(_ptr(oscale), _ptr(oshift), obn.channels),
                            out_f16=True, label=name + ".conv4", **skip)
@@ -367,6 +375,45 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
     self.feat = self.conv(xa, self.pack(model.output_layer[2], None, f16=True), one, (0, 1, 1), tanh=True,
                           label="output_layer.2")
     self.pooled = None
+
+def _rgb_conv_ok(self, channels):
+    """The generator's image conv has its own kernel for C in {32, 64, 128} (ptx_rgb_conv3x3_f16_fwd); PTX_RGB_CONV=0 keeps
+    the implicit-GEMM tile (A/B runs)."""
+    import os
+    return os.environ.get("PTX_RGB_CONV", "1") != "0" and channels in (32, 64, 128)
+
+
+def _rgb_conv(self, x, conv, scale_ptr, shift_ptr, ld_aff):
+    """BN -> ReLU -> conv3x3(C -> 3) -> tanh as ONE launch on the raw half feature map x (gen_stage_f16.hip)."""
+    from ._lib import RgbConvDesc, PTX_EPI_TANH
+    from .engine import PtxError, _tag
+    lib = self.lib
+    d = RgbConvDesc(x.N, x.H, x.W, x.C, x.ld, 4, ld_aff, PTX_EPI_TANH)
+    if not x.f16 or conv.out_channels != 3 or tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1) \
+            or not lib.ptx_rgb_conv3x3_f16_supported(C.byref(d)):
+        raise PtxError("output layer: not the 3x3, 3-channel image conv the fused kernel covers")
+    y = self.act(x.N, 1, x.H, x.W, 3)
+    wp = torch.empty(int(lib.ptx_rgb_conv_weight_elems(x.C)), device=self.dev, dtype=torch.float16)
+    bias = torch.zeros(4, device=self.dev, dtype=torch.float32)
+    self.keepalive += [d, wp, bias]
+    ref = self.ref(conv)
+
+    def refresh():
+        cv = self.get(ref)
+        w = cv.weight.detach().contiguous()
+        check(lib.ptx_pack_rgb_conv_weight(_ptr(w), x.C, C.c_void_p(wp.data_ptr()), _stream()), "ptx_pack_rgb_conv_weight")
+        bias.zero_()
+        if cv.bias is not None:
+            bias[:3].copy_(cv.bias.detach())
+    if torch.device(self.dev).type != "meta":
+        self.refreshers.append(refresh)
+    xp, yp, wpp, bp = C.c_void_p(x.t.data_ptr()), _ptr(y.t), C.c_void_p(wp.data_ptr()), _ptr(bias)
+
+    def step(st):
+        check(lib.ptx_rgb_conv3x3_f16_fwd(C.byref(d), xp, scale_ptr, shift_ptr, wpp, bp, yp, st), "ptx_rgb_conv3x3_f16_fwd")
+    self.steps.append(_tag(step, "rgb_conv3x3", 2 * x.N * x.H * x.W * x.C + 16 * x.N * x.H * x.W))
+    return y
+
 
 def biggan_attention(self, x, att, name):
     """layers.Attention: theta^T phi over 2x2-max-pooled keys, softmax, values g, output conv * gamma + x."""

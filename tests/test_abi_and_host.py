@@ -48,6 +48,8 @@ def test_struct_layouts_match_header(ptx):
     assert fields_of("ptx_pack_desc") == [f for f, _ in L.PackDesc._fields_]
     assert fields_of("ptx_pool3d_desc") == [f for f, _ in L.PoolDesc._fields_]
     assert fields_of("ptx_norm_desc") == [f for f, _ in L.NormDesc._fields_]
+    assert fields_of("ptx_rgb_conv_desc") == [f for f, _ in L.RgbConvDesc._fields_]
+    assert C.sizeof(L.RgbConvDesc) == 4 * len(L.RgbConvDesc._fields_)
     assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
     assert C.sizeof(L.PoolDesc) == 4 * len(L.PoolDesc._fields_)
     assert C.sizeof(L.NormDesc) == 4 * 10

@@ -1576,3 +1576,38 @@ def test_conv_chain(ptx, case, kind):
     d2.Wi -= 1
     d2.flags ^= L.PTX_F16X3_OPERANDS                     # split operands on one conv only
     assert lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(d2), _p(xd), _p(wp1), _p(bp1), _p(wp2), _p(bp2), null, _p(yd), -1, _st()) != 0
+
+
+@pytest.mark.parametrize("N,H,W,Cc", [(2, 64, 64, 128), (3, 37, 70, 64), (1, 8, 32, 32), (2, 256, 256, 128)])
+def test_rgb_conv3x3_f16(ptx, N, H, W, Cc):
+    """ptx_rgb_conv3x3_f16_fwd (the generator's output layer, BN -> ReLU -> conv3x3(C -> 3) -> tanh in one launch: taps in
+    the N axis of one GEMM over the input positions, shifted partial sums combined through LDS) against the op sequence in
+    torch fp32 on the same half-rounded operands: per-sample affine + ReLU (rounded to half, as the fragment math does),
+    zero padding of the ACTIVATED map, conv2d, tanh.  Ragged tiles, every compiled channel count, config 5's own extent."""
+    L, lib = ptx._lib, _lib(ptx)
+    g_ = torch.Generator().manual_seed(7 + H + Cc)
+    ldx, lda = Cc + 8, Cc + 4
+    x = (torch.randn(N, H, W, ldx, generator=g_) * 1.5).half()
+    scale = torch.rand(N, lda, generator=g_) + 0.5
+    shift = torch.randn(N, lda, generator=g_) * 0.3
+    w = torch.randn(3, Cc, 3, 3, generator=g_) * (1.0 / (9 * Cc)) ** 0.5
+    b = torch.randn(3, generator=g_) * 0.1
+    act = F.relu((x[..., :Cc].float() * scale[:, None, None, :Cc].half().float() + shift[:, None, None, :Cc].half().float()).half().float())
+    want = torch.tanh(F.conv2d(act.permute(0, 3, 1, 2), w.half().float(), b, padding=1)).permute(0, 2, 3, 1)
+    xd, sd, hd, wd = x.to(DEV), scale.to(DEV), shift.to(DEV), w.to(DEV)
+    bd = torch.zeros(4, device=DEV)
+    bd[:3] = b.to(DEV)
+    wp = torch.empty(int(lib.ptx_rgb_conv_weight_elems(Cc)), device=DEV, dtype=torch.float16)
+    L.check(lib.ptx_pack_rgb_conv_weight(_p(wd), Cc, C.c_void_p(wp.data_ptr()), _st()), "pack")
+    y = torch.full((N, H, W, 4), float("nan"), device=DEV)
+    d = L.RgbConvDesc(N, H, W, Cc, ldx, 4, lda, L.PTX_EPI_TANH)
+    assert lib.ptx_rgb_conv3x3_f16_supported(C.byref(d))
+    L.check(lib.ptx_rgb_conv3x3_f16_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), _p(sd), _p(hd), C.c_void_p(wp.data_ptr()), _p(bd), _p(y),
+                                        _st()), "rgb conv")
+    torch.cuda.synchronize()
+    got = y.cpu()
+    assert (got[..., 3] == 0).all()
+    err = (got[..., :3] - want).abs().max().item()
+    assert err <= 4e-3, (N, H, W, Cc, err)              # half-rounded affine tables + one fp16 rounding per activation
+    d.C = 48
+    assert not lib.ptx_rgb_conv3x3_f16_supported(C.byref(d))
