@@ -491,6 +491,18 @@ int ptx_pack_rgb_conv_weight(const float* w, int32_t C, void* w_packed, ptx_stre
 int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* desc, const void* x, const float* scale, const float* shift,
                             const void* w_packed, const float* bias /* [3] or NULL */, float* y, ptx_stream_t stream);
 
+/* ptx_conv3x3_f16_fwd -- the 3x3 convs of a GBlock (conv2 / conv3 of BigGAN-deep's bottleneck, 64 / 128 / 256 channels in
+ * and out: the 32^2 ... 256^2 stages) from ONE staged input patch per 8 x 32 output tile:
+ *     y = half( relu?( (conv3x3(up2?(x)) + bias) * scale[n] + shift[n] ) )
+ * Same descriptor, operands and flag semantics as ptx_conv3d_fused_fwd restricted to what ptx_conv3x3_f16_supported
+ * accepts: PTX_F16_OPERANDS | PTX_EPI_OUT_F16 [| PTX_PRO_UP2] [| PTX_EPI_AFFINE] [| PTX_EPI_RELU], kT = 1, 3 x 3, unit
+ * stride, pad 1, Ci == Co (64, 128 or 256 channels), at least 32 columns, no residual; w_packed / bias from
+ * ptx_pack_conv_weight (f16 = 1).
+ * ext may be NULL without PTX_EPI_AFFINE.  No workspace, no tile configuration. */
+int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* desc);
+int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, void* y,
+                        const ptx_conv_fused_ext* ext, ptx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

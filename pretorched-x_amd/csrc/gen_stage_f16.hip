@@ -4,6 +4,7 @@
 // SURVEY.md F2 -- parity of everything here is UNPINNED and the tolerance is the builder's).
 //
 //   ptx_rgb_conv3x3_f16_fwd   the output layer  BN -> ReLU -> conv3x3(ch -> 3) -> tanh  in one launch
+//   ptx_conv3x3_f16_fwd       a GBlock's 3x3 convs (64 / 128 channels, the 128^2 / 256^2 stages) from one staged input patch
 //
 // ---- the image conv ----------------------------------------------------------------------------------------------------
 // 3 output channels waste 13/16 of the narrowest MFMA tile, and as an implicit GEMM the layer re-stages its input nine
@@ -141,6 +142,213 @@ __global__ void __launch_bounds__(256) pack_rgb_conv_kernel(const float* __restr
     }
 }
 
+
+// ---- the 3x3 convs of a GBlock (C -> C channels, C = 64 / 128; [nearest 2x] -> conv -> + bias -> cBN affine -> ReLU -> halfs) -------
+// On the generic tiles a 3x3 conv over 64 channels is 18 k-steps of 2 (f16) MFMAs per wave, each behind a barrier and its own
+// round of staging address math: 0.53 ms at 256 x 256 x 64 images where HBM needs 0.18 and the matrix cores 0.12-0.19.  Here a
+// workgroup (4 waves) owns 8 x 32 output positions x ALL output channels and stages the halo'd INPUT PATCH once -- 10 x 34
+// positions x 64 channels = 42.5 KB by LDS-DMA, 16-byte slots XOR-swizzled by position so the fragment reads are conflict
+// free; with PTX_PRO_UP2 every patch position is fetched from its source pixel (h / 2, w / 2): the upsampled map never exists
+// -- and serves all nine taps from it.  Only the filter streams: one [C][64] tile per tap (8 / 16 KB) through a 3- / 2-slot
+// ring, requested one or two taps ahead.  Per tap a wave issues 16 (C = 64) or 32 (C = 128, per 64-channel input chunk)
+// v_mfma_f32_32x32x16_f16 between barriers, fed by as many ds_read_b128.  The product is computed TRANSPOSED (filter rows as
+// the A operand): a lane then owns 4 consecutive output channels of one position, so the epilogue -- affine tables from LDS,
+// ReLU, 4 halfs per ds_write_b64 into a position-major tile, 16-byte row-major copy-out -- stores whole 128 / 256-byte pixels.
+// 59.5 KB (C = 64) / 75.5 KB (C = 128) of LDS: two workgroups per CU cover each other's patch load and epilogue.
+struct C3Args {
+    const _Float16* x;      // [N][Hs][Ws][ldx] halfs (Hs = H / 2 under PTX_PRO_UP2)
+    const _Float16* w;      // ptx_pack_conv_weight(f16 = 1): [9][Co_pad][Kc] halfs
+    const float* bias;      // [C] or NULL
+    const float* scale;     // [N][ld_aff] or NULL (no affine)
+    const float* shift;
+    _Float16* y;            // [N][H][W][ldy] halfs
+    int N, H, W, Hs, Ws, ldx, ldy, ld_aff, Kc, tap_stride, tiles_h, tiles_w;
+    unsigned x_bytes, w_bytes, flags;
+};
+
+constexpr int kC3TH = 8, kC3TW = 32, kC3PW = kC3TW + 2, kC3Pos = (kC3TH + 2) * kC3PW;      // 340 patch positions
+constexpr int kC3PatchPieces = (kC3Pos * 8 + 255) / 256 * 256;                              // 16-byte pieces, padded to whole rounds
+constexpr int kC3PatchBytes = kC3PatchPieces * 16;                                          // 45056
+
+// NCH: 64-channel input chunks (Ci = 64 NCH); CT: 32-channel output tiles of ONE workgroup (Co_wg = 32 CT: 64 or 128 --
+// wider outputs are cut along blockIdx.y, each part re-staging the patch: C = 256 runs as <4, 4> x 2)
+template <int NCH, int CT, bool UP2>
+__global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
+    constexpr int C = 32 * CT;                     // output channels of this workgroup
+    constexpr int NBUF = CT == 2 ? 3 : 2;          // filter ring
+    constexpr int BT_BYTES = C * 128;              // one (tap, chunk) filter tile: C rows x 64 halfs
+    constexpr int BT_IT = C * 8 / 256;             // its 16-byte pieces per thread
+    constexpr int PA_IT = kC3PatchPieces / 256;    // patch pieces per thread (11)
+    constexpr int TP = C + 8;                      // pitch (halfs) of the output tile in LDS: conflict-free ds_write_b64
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Pa = smem;                               // the patch chunk, later the output tile
+    char* Bt = smem + kC3PatchBytes;               // [NBUF][BT_BYTES]
+    float* Sc = reinterpret_cast<float*>(smem + kC3PatchBytes + NBUF * BT_BYTES);     // [C] scale, [C] shift' = bias * scale + shift
+    float* Sh = Sc + C;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, kg = lane >> 5;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t % p.tiles_w;
+    t /= p.tiles_w;
+    const int th = t % p.tiles_h, n = t / p.tiles_h;
+    const int h0 = th * kC3TH, w0 = tw * kC3TW;
+    const int co_base = blockIdx.y * C;            // first output channel of this workgroup
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- DMA sources (byte offsets), fixed for the tile: piece q = wave * 64 + 256 i + lane lands at Pa + 16 q ----
+    unsigned pa_src[PA_IT];
+#pragma unroll
+    for (int i = 0; i < PA_IT; ++i) {
+        const int q = tid + 256 * i;
+        const int pos = q >> 3, ps = q & 7;
+        const int slot = ps ^ ((pos >> 1) & 7);                       // logical 8-channel slot this physical slot holds
+        const int pr = pos / kC3PW, pc = pos - pr * kC3PW;
+        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+        const bool ok = pos < kC3Pos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        const int sh_ = UP2 ? (h >> 1) : h, sw_ = UP2 ? (w >> 1) : w;
+        pa_src[i] = ok ? (unsigned)((((n * p.Hs + sh_) * p.Ws + sw_) * p.ldx + slot * 8) * 2) : kOOB;
+    }
+    unsigned bt_src[4];      // (sized by its maximum: a template-dependent extent indexed inside the voffset operand of the LDS-DMA
+                             //  builtin makes hipcc's host pass drop the kernel's stub -- DESIGN.md 3.8)
+    static_assert(BT_IT <= 4, "filter tile pieces per thread");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= BT_IT) break;
+        const int q = tid + 256 * i;
+        const int co = q >> 3, ps = q & 7;
+        bt_src[i] = (unsigned)(((co_base + co) * p.Kc + (ps ^ ((co >> 1) & 7)) * 8) * 2);
+    }
+    auto issue_patch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < PA_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Pa + (wave * 64 + 256 * i) * 16), 16,
+                                                     pa_src[i] == kOOB ? kOOB : pa_src[i] + (unsigned)chunk * 128u, 0, 0, 0);
+    };
+    auto issue_filter = [&](int s) {                                  // step s = chunk * 9 + tap
+        const int chunk = s / 9, tap = s - chunk * 9, buf = s % NBUF;
+        const unsigned base = (unsigned)(tap * p.tap_stride) * 2u + (unsigned)chunk * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < BT_IT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bt + buf * BT_BYTES + (wave * 64 + 256 * i) * 16), 16,
+                                                         bt_src[i] + base, 0, 0, 0);
+    };
+    constexpr int NS = 9 * NCH;
+    issue_patch(0);
+    issue_filter(0);
+    if (NBUF == 3) issue_filter(1);
+    // affine tables of this sample -> LDS (shift' = bias * scale + shift: one fma per output in the epilogue)
+    if (tid < C / 4) {
+        const int c4 = tid * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) {
+            sc = *reinterpret_cast<const f32x4*>(p.scale + (size_t)n * p.ld_aff + co_base + c4);
+            sf = *reinterpret_cast<const f32x4*>(p.shift + (size_t)n * p.ld_aff + co_base + c4);
+        }
+        if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + co_base + c4);
+        *reinterpret_cast<f32x4*>(Sc + c4) = sc;
+        *reinterpret_cast<f32x4*>(Sh + c4) = f32x4{bs[0] * sc[0] + sf[0], bs[1] * sc[1] + sf[1], bs[2] * sc[2] + sf[2], bs[3] * sc[3] + sf[3]};
+    }
+
+    f32x16 acc[CT][2];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+    // fragment addresses: filter row co = 32 a + l32 (tap independent), patch position of output (row 2 wave + i, column l32)
+    int b_off[CT], b_sw[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) {
+        const int co = 32 * a + l32;
+        b_off[a] = co * 128;
+        b_sw[a] = (co >> 1) & 7;
+    }
+    const int p_base = (2 * wave) * kC3PW + l32;
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = chunk * 9 + tap;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // filter tile s (and at tap 0 the patch chunk) landed; slot (s - 1) % NBUF is free
+            if (s + NBUF - 1 < NS) issue_filter(s + NBUF - 1);
+            const char* Bb = Bt + (s % NBUF) * BT_BYTES;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            int a_off[2], a_sw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pos = p_base + (i + kh) * kC3PW + kw;
+                a_off[i] = pos * 128;
+                a_sw[i] = (pos >> 1) & 7;
+            }
+            asm volatile("; LDS reads stay below the barrier" : "+v"(a_off[0]), "+v"(a_off[1])::"memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = 2 * j + kg;
+                h8 xa[2], wb[CT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xa[i] = *reinterpret_cast<const h8*>(Pa + a_off[i] + ((slot ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int a = 0; a < CT; ++a) wb[a] = *reinterpret_cast<const h8*>(Bb + b_off[a] + ((slot ^ b_sw[a]) << 4));
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[a], xa[i], acc[a][i], 0, 0, 0);   // C^T[co][position]
+            }
+        }
+        if (chunk + 1 < NCH) {
+            __syncthreads();                       // every wave is done with this patch chunk
+            issue_patch(chunk + 1);                // exposed; the CU's other workgroup covers it
+        }
+    }
+
+    // ---- epilogue: lane = position (2 wave + i, l32); element r of acc[a][i] = channel 32 a + 8 (r >> 2) + 4 kg + (r & 3) ----
+    __syncthreads();                               // all fragment reads done: the patch area becomes the output tile
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+    _Float16* T = reinterpret_cast<_Float16*>(Pa);
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = 32 * a + 8 * g + 4 * kg;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(Sc + co), sf = *reinterpret_cast<const f32x4*>(Sh + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][i][4 * g + e] * sc[e] + sf[e];
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    o[e] = (_Float16)v;
+                }
+                *reinterpret_cast<h4*>(T + ((2 * wave + i) * 32 + l32) * TP + co) = o;
+            }
+        }
+    __syncthreads();
+    constexpr int SL = C / 8;                      // 16-byte pieces per pixel
+    const size_t y_img = (size_t)n * p.H * p.W * p.ldy;      // element offset of this image
+#pragma unroll
+    for (int it = 0; it < SL; ++it) {
+        const int q = tid + 256 * it;
+        const int pos = q / SL, sl = q - pos * SL;
+        const int h = h0 + (pos >> 5), w = w0 + (pos & 31);
+        if (h < p.H && w < p.W) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + pos * TP + sl * 8);
+            *reinterpret_cast<f32x4*>(p.y + y_img + ((size_t)h * p.W + w) * p.ldy + co_base + sl * 8) = v;
+        }
+    }
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -188,4 +396,67 @@ extern "C" int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* d, const void* x
     else if (d->C == 64) hipLaunchKernelGGL(rgb_conv3x3_f16_kernel<4>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(rgb_conv3x3_f16_kernel<2>, grid, dim3(256), 0, st, a);
     return hip_check(hipGetLastError(), "rgb_conv3x3_f16 launch");
+}
+
+extern "C" int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* d) {
+    if (!d) return 0;
+    const unsigned need = PTX_F16_OPERANDS | PTX_EPI_OUT_F16;
+    const unsigned may = need | PTX_PRO_UP2 | PTX_EPI_AFFINE | PTX_EPI_RELU;
+    if ((d->flags & need) != need || (d->flags & ~may)) return 0;
+    const int C = 2 * d->Ci;                                   // fp16 descriptors count 32-bit words (channel pairs)
+    if ((C != 64 && C != 128 && C != 256) || d->Co != C || d->groups > 1) return 0;
+    if (d->Wi < kC3TW) return 0;                                // 8 x 32 tiles: at 16 columns half of every tile is padding (measured:
+                                                                // 0.033 vs 0.028 ms for the generic tile at 16 x 16 x 256)
+    if (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 0 || d->pH != 1 || d->pW != 1) return 0;
+    if (d->Ti != 1 || d->To != 1 || d->Ho != d->Hi || d->Wo != d->Wi || d->N <= 0 || d->Hi <= 0 || d->Wi <= 0) return 0;
+    if ((d->flags & PTX_PRO_UP2) && ((d->Hi | d->Wi) & 1)) return 0;
+    if (2 * d->ldx < C || (2 * d->ldx) % 8 || d->ldy < C || d->ldy % 8 || 2 * d->Kc < C || (2 * d->Kc) % 8 || d->Co_pad < C) return 0;
+    const int Hs = (d->flags & PTX_PRO_UP2) ? d->Hi / 2 : d->Hi, Ws = (d->flags & PTX_PRO_UP2) ? d->Wi / 2 : d->Wi;
+    if ((uint64_t)d->N * Hs * Ws * d->ldx * 4ull >= 0x80000000ull) return 0;
+    if ((uint64_t)9 * d->Co_pad * d->Kc * 4ull >= 0x80000000ull) return 0;
+    return (int64_t)d->N * cdiv(d->Hi, kC3TH) * cdiv(d->Wi, kC3TW) <= 0x7fffffffLL;
+}
+
+template <int NCH, int CT, bool UP2>
+static int launch_c3(const C3Args& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = kC3PatchBytes + (size_t)(CT == 2 ? 3 : 2) * (32 * CT) * 128 + 2 * (32 * CT) * sizeof(float);
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16_kernel<NCH, CT, UP2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_f16_kernel<NCH, CT, UP2>), grid, dim3(256), lds, st, a);
+    return hip_check(hipGetLastError(), "conv3x3_f16 launch");
+}
+
+extern "C" int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                                   const ptx_conv_fused_ext* ext, ptx_stream_t stream) {
+    if (!d || !x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv3x3_f16: null pointer");
+    if (!ptx_conv3x3_f16_supported(d))
+        return fail(PTX_ERR_UNSUPPORTED, "conv3x3_f16: a unit-stride 3x3 conv with pad 1 over halfs, Ci == Co in {64, 128, 256}, at least 32 columns, halfs out, "
+                    "flags within F16_OPERANDS | OUT_F16 | PRO_UP2 | EPI_AFFINE | EPI_RELU");
+    if ((d->flags & PTX_EPI_AFFINE) && (!ext || !ext->scale || !ext->shift || ext->ld_affine < d->Co || ext->ld_affine % 4))
+        return fail(PTX_ERR_INVALID, "conv3x3_f16: PTX_EPI_AFFINE needs scale / shift tables with a row stride that is a multiple of 4");
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)bias) & 15) return fail(PTX_ERR_INVALID, "conv3x3_f16: misaligned pointer");
+    const bool up2 = (d->flags & PTX_PRO_UP2) != 0;
+    C3Args a{};
+    a.x = static_cast<const _Float16*>(x); a.w = static_cast<const _Float16*>(w_packed); a.bias = bias;
+    a.scale = (d->flags & PTX_EPI_AFFINE) ? ext->scale : nullptr;
+    a.shift = (d->flags & PTX_EPI_AFFINE) ? ext->shift : nullptr;
+    a.ld_aff = (d->flags & PTX_EPI_AFFINE) ? ext->ld_affine : 0;
+    a.y = static_cast<_Float16*>(y);
+    a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Hs = up2 ? d->Hi / 2 : d->Hi; a.Ws = up2 ? d->Wi / 2 : d->Wi;
+    a.ldx = 2 * d->ldx; a.ldy = d->ldy; a.Kc = 2 * d->Kc; a.tap_stride = d->Co_pad * a.Kc;
+    a.tiles_h = cdiv(d->Hi, kC3TH); a.tiles_w = cdiv(d->Wi, kC3TW);
+    a.x_bytes = (unsigned)((uint64_t)d->N * a.Hs * a.Ws * a.ldx * 2ull);
+    a.w_bytes = (unsigned)((uint64_t)9 * d->Co_pad * a.Kc * 2ull);
+    a.flags = d->flags;
+    const dim3 grid((unsigned)(d->N * a.tiles_h * a.tiles_w), (unsigned)(d->Co <= 128 ? 1 : d->Co / 128));
+    const hipStream_t st = (hipStream_t)stream;
+    if (d->Co == 64) return up2 ? launch_c3<1, 2, true>(a, grid, st) : launch_c3<1, 2, false>(a, grid, st);
+    if (d->Co == 128) return up2 ? launch_c3<2, 4, true>(a, grid, st) : launch_c3<2, 4, false>(a, grid, st);
+    return up2 ? launch_c3<4, 4, true>(a, grid, st) : launch_c3<4, 4, false>(a, grid, st);
 }

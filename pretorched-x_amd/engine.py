@@ -482,6 +482,17 @@ class StemStep:
         check(_lib.lib().ptx_conv_stem_x3_fwd(C.byref(self.d), self.x, self.w, self.b, self.y, st), self.label)
 
 
+class PatchConvStep:
+    """One ptx_conv3x3_f16_fwd launch: a generator-stage 3x3 conv (64 / 128 channels, halfs) served from one staged input
+    patch per tile (gen_stage_f16.hip) instead of the implicit-GEMM tiles."""
+    __slots__ = ("d", "x", "w", "b", "y", "ext", "label", "macs", "hbm_bytes")
+    kernel = "conv3x3_f16"
+
+    def __call__(self, st):
+        check(_lib.lib().ptx_conv3x3_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.y,
+                                             C.byref(self.ext) if self.ext is not None else None, st), self.label)
+
+
 class StemF32Step:
     """One ptx_conv_stem_f32_fwd launch: the RGB stem on the fp32 matrix cores, read straight from the caller's NCDHW
     tensor (bound per run: plan.in_ptr) -- no fold, no layout pass."""
@@ -686,6 +697,15 @@ class Plan:
             d.x2_sT, d.x2_sH, d.x2_sW = _t3(x2_stride)
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
+        if (fused and res is None and not raw and not tanh and x2 is None and os.environ.get("PTX_CONV3X3_F16", "1") != "0"
+                and self.lib.ptx_conv3x3_f16_supported(C.byref(d))):
+            # a GBlock's 3x3 conv at 64 / 128 channels: its own fp16 kernel (one staged patch per tile, no tile table)
+            ps = PatchConvStep()
+            ps.d, ps.x, ps.w, ps.b, ps.y, ps.ext, ps.label = d, st.x, st.w, st.b, st.y, ext, label
+            ps.macs, ps.hbm_bytes = st.macs, 0
+            self.steps.append(ps)
+            self.patch_steps = getattr(self, "patch_steps", 0) + 1
+            return y
         key = json.dumps(d.key())
         tuned = tuned_lookup(key, _flags_kind(flags))
         if tuned is not None and not self.lib.ptx_conv3d_config_supported(C.byref(d), tuned[0]):
@@ -1317,7 +1337,7 @@ class Plan:
         out = []
         for s in self.steps:
             for t in (s.active() if isinstance(s, AltStep) else [s]):
-                if isinstance(t, (ConvStep, ChainStep, StemStep, StemF32Step)):
+                if isinstance(t, (ConvStep, ChainStep, StemStep, StemF32Step, PatchConvStep)):
                     out.append(t)
         return out
 
@@ -2000,7 +2020,7 @@ class Engine:
             ms = e0.elapsed_time(e1) / iters
             if isinstance(stp, ConvStep):
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp))
-            elif isinstance(stp, (StemStep, StemF32Step)):      # the direct stems are convs too, with their own kernels
+            elif isinstance(stp, (StemStep, StemF32Step, PatchConvStep)):      # direct (patch) kernels are convs too
                 rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
             elif isinstance(stp, ChainStep):                    # two convs in one launch, its own tile table
                 rows.append((stp.label, "chain", 0, stp.macs, ms, stp.kernel))

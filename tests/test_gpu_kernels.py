@@ -1611,3 +1611,71 @@ def test_rgb_conv3x3_f16(ptx, N, H, W, Cc):
     assert err <= 4e-3, (N, H, W, Cc, err)              # half-rounded affine tables + one fp16 rounding per activation
     d.C = 48
     assert not lib.ptx_rgb_conv3x3_f16_supported(C.byref(d))
+
+
+@pytest.mark.parametrize("N,H,W,Cc,up2,affine,relu", [
+    (2, 32, 64, 64, False, True, True),      # whole tiles
+    (2, 16, 32, 64, True, True, True),       # upsampling loader: the filter slides over 32 x 64
+    (1, 19, 45, 64, False, True, False),     # ragged tiles, no ReLU
+    (2, 32, 32, 128, False, True, True),     # two 64-channel input chunks
+    (1, 12, 20, 128, True, False, True),     # C = 128 + upsampling, no affine (bias only), ragged
+    (3, 8, 32, 64, False, False, False),     # one tile per image, plain conv + bias
+    (2, 32, 32, 256, False, True, True),     # 256 channels: four input chunks, output channels cut over blockIdx.y
+    (1, 8, 16, 256, True, True, True),       # ... with the upsampling loader (16 x 32 output)
+    (1, 19, 45, 64, True, True, True),       # ragged + upsampled
+])
+def test_conv3x3_f16_patch_kernel(ptx, N, H, W, Cc, up2, affine, relu):
+    """ptx_conv3x3_f16_fwd (a GBlock's 3x3 conv from one staged input patch per 8 x 32 tile, gen_stage_f16.hip) against the op
+    sequence in torch fp32 on the same half-rounded operands: [nearest x2] -> conv3x3 + bias -> per-sample affine -> ReLU ->
+    halfs.  Also bit-compared in spirit with the implicit-GEMM fused stage it replaces (same operands, same packed filter):
+    both must sit within the half-output rounding of the torch result."""
+    L, lib = ptx._lib, _lib(ptx)
+    x = rnd(N, Cc, 1, H, W, seed=400 + Cc + H).half().float()
+    w = rnd(Cc, Cc, 1, 3, 3, seed=401, scale=(Cc * 9) ** -0.5).half().float()
+    bias = rnd(Cc, seed=402)
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    xin = F.interpolate(x[:, :, 0], scale_factor=2, mode="nearest").unsqueeze(2) if up2 else x
+    v = F.conv3d(xin, w, bias, 1, (0, 1, 1))
+    ld_aff = Cc + 4
+    sc = torch.rand(N, ld_aff, generator=torch.Generator().manual_seed(405)) + 0.5
+    sh = rnd(N, ld_aff, seed=406, scale=0.3)
+    if affine:
+        v = v * sc[:, :Cc, None, None, None] + sh[:, :Cc, None, None, None]
+    v = F.relu(v) if relu else v
+    want = v[:, :, 0].permute(0, 2, 3, 1)
+    ldh = Cc + 8
+    xh = torch.zeros(N, 1, H, W, ldh, dtype=torch.float16)
+    xh[..., :Cc] = x.permute(0, 2, 3, 4, 1).half()
+    xd = xh.to(DEV)
+    pd = L.PackDesc(Cc, Cc, 1, 3, 3, ldh, (Cc + 127) // 128 * 128, 0, 0, 0, 0, 0, 0, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV, dtype=torch.float16)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd, bd, scd, shd = w.to(DEV), bias.to(DEV), sc.to(DEV), sh.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0),
+                                     C.c_void_p(wp.data_ptr()), _p(bp), _st()), "pack f16")
+    ldy = Cc + 16
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, Ho, Wo, Cc // 2, ldh // 2
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, Ho, Wo, Cc, ldy
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 1, 3, 3, 1, 1, 1, 0, 1, 1
+    d.Kc, d.Co_pad, d.groups = ldh // 2, pd.Co_pad, 1
+    d.flags = (L.PTX_F16_OPERANDS | L.PTX_EPI_OUT_F16 | (L.PTX_PRO_UP2 if up2 else 0) | (L.PTX_EPI_AFFINE if affine else 0) |
+               (L.PTX_EPI_RELU if relu else 0))
+    assert lib.ptx_conv3x3_f16_supported(C.byref(d))
+    ext = L.ConvFusedExt()
+    ext.scale, ext.shift, ext.ld_affine = scd.data_ptr(), shd.data_ptr(), ld_aff
+    yd = torch.full((N, 1, Ho, Wo, ldy), float("nan"), device=DEV, dtype=torch.float16)
+    L.check(lib.ptx_conv3x3_f16_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
+                                    C.c_void_p(yd.data_ptr()), C.byref(ext) if affine else None, _st()), "conv3x3_f16")
+    torch.cuda.synchronize()
+    got = yd.cpu().float()[:, 0]
+    assert torch.isnan(got[..., Cc:]).all()                 # columns beyond Co are left untouched
+    err = (got[..., :Cc] - want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, want.abs().max().item()), (N, H, W, Cc, up2, err)
+    # what it refuses: strides, other widths, residuals
+    d.sW = 2
+    assert not lib.ptx_conv3x3_f16_supported(C.byref(d))
+    d.sW, d.Ci = 1, 48
+    assert not lib.ptx_conv3x3_f16_supported(C.byref(d))
+    d.Ci, d.flags = Cc // 2, d.flags | L.PTX_EPI_RES_ADD
+    assert not lib.ptx_conv3x3_f16_supported(C.byref(d))
