@@ -499,6 +499,16 @@ int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* desc, const void* x, const 
  * stride, pad 1, Ci == Co (64, 128 or 256 channels), at least 32 columns, no residual; w_packed / bias from
  * ptx_pack_conv_weight (f16 = 1).
  * ext may be NULL without PTX_EPI_AFFINE.  No workspace, no tile configuration. */
+/* ptx_conv1x1_skip_f16_fwd -- the closing 1x1 conv of a GBlock (conv4 of BigGAN-deep's bottleneck: C/4 -> C' channels) with
+ * everything the next block reads produced in its epilogue:
+ *     v = conv1x1(x) + bias + skip;   y_raw = half(v)  [PTX_EPI_DUAL_RAW];   y = half(relu?(v * scale[n] + shift[n]))  [PTX_EPI_AFFINE]
+ * (without PTX_EPI_AFFINE: y = half(relu?(v))).  skip = res halfs (PTX_RES_F16): same shape (PTX_EPI_RES_ADD) or nearest-
+ * upsampled by 2^res_sH and channel-truncated (PTX_EPI_RES_PADA | PTX_EPI_RES_UP, res_sH == res_sW in 0..1, res_sT = 0).
+ * Same descriptor / ext conventions as ptx_conv3d_fused_fwd; accepted: 64 / 128 / 256 input channels, Co a multiple of
+ * 128, at least 32 columns, halfs in and out. */
+int ptx_conv1x1_skip_f16_supported(const ptx_conv3d_desc* desc);
+int ptx_conv1x1_skip_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, const void* res,
+                             void* y, const ptx_conv_fused_ext* ext, ptx_stream_t stream);
 int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* desc);
 int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, void* y,
                         const ptx_conv_fused_ext* ext, ptx_stream_t stream);

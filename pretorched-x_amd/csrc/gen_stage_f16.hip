@@ -4,7 +4,8 @@
 // SURVEY.md F2 -- parity of everything here is UNPINNED and the tolerance is the builder's).
 //
 //   ptx_rgb_conv3x3_f16_fwd   the output layer  BN -> ReLU -> conv3x3(ch -> 3) -> tanh  in one launch
-//   ptx_conv3x3_f16_fwd       a GBlock's 3x3 convs (64 / 128 channels, the 128^2 / 256^2 stages) from one staged input patch
+//   ptx_conv3x3_f16_fwd       a GBlock's 3x3 convs (64 / 128 / 256 channels) from one staged input patch
+//   ptx_conv1x1_skip_f16_fwd  a GBlock's closing 1x1 conv: + skip (upsampled, channel-truncated) and BOTH outputs the next block reads
 //
 // ---- the image conv ----------------------------------------------------------------------------------------------------
 // 3 output channels waste 13/16 of the narrowest MFMA tile, and as an implicit GEMM the layer re-stages its input nine
@@ -349,6 +350,217 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
     }
 }
 
+
+// ---- the closing 1x1 conv of a GBlock (conv4: C/4 -> C' channels, + skip, two outputs) ----------------------------------------
+//     v     = conv1x1(t) + bias + up?(x_block[:, :C'])          (the block's output; x_block halfs, nearest 2x when the block upsamples)
+//     y_raw = half(v)                                            (the next block's skip operand)              [PTX_EPI_DUAL_RAW]
+//     y     = half(relu(v * scale[n] + shift[n]))                (the next block's cBN1 + ReLU, folded)       [PTX_EPI_AFFINE]
+// K is 64 ... 256 channels: one to four k-steps per output tile, after which the generic tile spends its time in a 16-row-at-a-
+// time epilogue -- 0.69 ms at 256 x 256 x 128 where the bytes (0.54 GB in + 0.27 GB skip + 1.07 GB out) need 0.34.  Same skeleton
+// as the 3x3 kernel with one tap and no halo: 8 x 32 positions x 128 output channels per workgroup (wider outputs over
+// blockIdx.y), the input tile and the [128][64] filter tile by LDS-DMA, transposed product.  The epilogue keeps fp32 until the
+// single rounding: half of the tile at a time is parked as floats (128 positions x 132), then every thread handles 16-byte
+// pieces of whole pixels -- skip read, raw store, affine + ReLU, activated store, all coalesced.
+struct C1Args {
+    const _Float16* x;      // [N][H][W][ldx] halfs
+    const _Float16* w;      // [Co_pad][Kc] halfs (ptx_pack_conv_weight, f16 = 1)
+    const float* bias;
+    const _Float16* res;    // skip operand [N][rH][rW][ldr] halfs, read at (h >> ush, w >> ush), or NULL
+    const float* scale;     // [N][ld_aff] or NULL
+    const float* shift;
+    _Float16* y;            // main output [N][H][W][ldy]
+    _Float16* y_raw;        // PTX_EPI_DUAL_RAW: pre-affine output [N][H][W][ld_raw]
+    int N, H, W, ldx, ldy, ld_raw, ld_aff, Kc, rH, rW, ldr, ush, tiles_h, tiles_w;
+    unsigned x_bytes, w_bytes, r_bytes, y_bytes, raw_bytes, flags;
+};
+
+constexpr int kC1TP = 132;                                      // pitch (floats) of the parked half tile
+constexpr int kC1Lds = 128 * kC1TP * 4 + 3 * 128 * 4;           // parked tile (overlays the operand tiles) + bias / scale / shift
+
+template <int NCH>
+__global__ void __launch_bounds__(256, 2) conv1x1_skip_f16_kernel(const C1Args p) {
+    constexpr int CO = 128, CT = 4;
+    constexpr int A_BYTES = 256 * 128, BT_BYTES = CO * 128;
+    static_assert(A_BYTES + 2 * BT_BYTES <= 128 * kC1TP * 4, "operand tiles under the parked tile");
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Pa = smem;                               // [256 positions][64 halfs], swizzled
+    char* Bt = smem + A_BYTES;                     // [2][128][64 halfs]
+    float* Tb = reinterpret_cast<float*>(smem + 128 * kC1TP * 4);     // bias | scale | shift of this workgroup's 128 channels
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, kg = lane >> 5;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t % p.tiles_w;
+    t /= p.tiles_w;
+    const int th = t % p.tiles_h, n = t / p.tiles_h;
+    const int h0 = th * kC3TH, w0 = tw * kC3TW;
+    const int co_base = blockIdx.y * CO;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    unsigned pa_src[8], bt_src[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i;
+        const int pos = q >> 3, ps = q & 7;
+        const int h = h0 + (pos >> 5), w = w0 + (pos & 31);
+        const bool ok = h < p.H && w < p.W;
+        pa_src[i] = ok ? (unsigned)((((n * p.H + h) * p.W + w) * p.ldx + (ps ^ ((pos >> 1) & 7)) * 8) * 2) : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        const int co = q >> 3, ps = q & 7;
+        bt_src[i] = (unsigned)(((co_base + co) * p.Kc + (ps ^ ((co >> 1) & 7)) * 8) * 2);
+    }
+    auto issue_a = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Pa + (wave * 64 + 256 * i) * 16), 16,
+                                                     pa_src[i] == kOOB ? kOOB : pa_src[i] + (unsigned)chunk * 128u, 0, 0, 0);
+    };
+    auto issue_b = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bt + (chunk & 1) * BT_BYTES + (wave * 64 + 256 * i) * 16), 16,
+                                                     bt_src[i] + (unsigned)chunk * 128u, 0, 0, 0);
+    };
+    issue_a(0);
+    issue_b(0);
+    // the epilogue's per-thread pieces: 16 bytes = 8 channels of one pixel; half hp of the tile holds pieces (pl, sl) = (q >> 4, q & 15),
+    // q = tid + 256 it.  Their pixel offsets are fixed for the tile, and the SKIP operand of half 0 is requested now -- its round
+    // trip hides under the operand DMA and the MFMAs instead of sitting in the epilogue (a load inside the copy-out loop was
+    // ~1 us of exposed latency per piece: the first version of this kernel ran at 3.2 TB/s)
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.res ? p.res : p.x), 0, p.res ? p.r_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.y_raw ? p.y_raw : p.y, 0, p.y_raw ? p.raw_bytes : 0u, 0x00020000);
+    auto skip_off = [&](int hp, int it) -> unsigned {
+        const int q = tid + 256 * it;
+        const int pl = q >> 4, sl = q & 15;
+        const int h = h0 + 4 * hp + (pl >> 5), w = w0 + (pl & 31);
+        return (h < p.H && w < p.W) ? (unsigned)((((n * p.rH + (h >> p.ush)) * p.rW + (w >> p.ush)) * p.ldr + co_base + sl * 8) * 2) : kOOB;
+    };
+    f32x4 rq0[8], rq1[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rq0[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, skip_off(0, it), 0, 0);
+    if (tid < 3 * CO / 4) {                        // bias | scale | shift -> LDS
+        const int which = tid / (CO / 4), c4 = (tid - which * (CO / 4)) * 4;
+        f32x4 v = which == 1 ? f32x4{1.f, 1.f, 1.f, 1.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (which == 0 && p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co_base + c4);
+        if (which == 1 && p.scale) v = *reinterpret_cast<const f32x4*>(p.scale + (size_t)n * p.ld_aff + co_base + c4);
+        if (which == 2 && p.shift) v = *reinterpret_cast<const f32x4*>(p.shift + (size_t)n * p.ld_aff + co_base + c4);
+        *reinterpret_cast<f32x4*>(Tb + which * CO + c4) = v;
+    }
+    f32x16 acc[CT][2];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+    int b_off[CT], b_sw[CT], a_off[2], a_sw[2];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) {
+        const int co = 32 * a + l32;
+        b_off[a] = co * 128;
+        b_sw[a] = (co >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pos = (2 * wave + i) * 32 + l32;
+        a_off[i] = pos * 128;
+        a_sw[i] = (pos >> 1) & 7;
+    }
+#pragma unroll 1
+    for (int s = 0; s < NCH; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // input chunk s and filter tile s landed
+        if (s + 1 < NCH) issue_b(s + 1);
+        const char* Bb = Bt + (s & 1) * BT_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = 2 * j + kg;
+            h8 xa[2], wb[CT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[i] = *reinterpret_cast<const h8*>(Pa + a_off[i] + ((slot ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int a = 0; a < CT; ++a) wb[a] = *reinterpret_cast<const h8*>(Bb + b_off[a] + ((slot ^ b_sw[a]) << 4));
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[a], xa[i], acc[a][i], 0, 0, 0);
+        }
+        if (s + 1 < NCH) {
+            __syncthreads();                       // every wave is done with this input chunk
+            issue_a(s + 1);
+        }
+    }
+    // ---- epilogue, half a tile (4 output rows = two waves' accumulators) at a time ----
+    const bool affine = (p.flags & PTX_EPI_AFFINE) != 0, dual = (p.flags & PTX_EPI_DUAL_RAW) != 0, relu = (p.flags & PTX_EPI_RELU) != 0;
+    float* T = reinterpret_cast<float*>(smem);
+    auto park = [&](int hp) {
+        if ((wave >> 1) == hp) {
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int pl = ((2 * wave + i) - 4 * hp) * 32 + l32;
+                        *reinterpret_cast<f32x4*>(T + pl * kC1TP + 32 * a + 8 * g + 4 * kg) =
+                            f32x4{acc[a][i][4 * g], acc[a][i][4 * g + 1], acc[a][i][4 * g + 2], acc[a][i][4 * g + 3]};
+                    }
+        }
+    };
+    auto copy_out = [&](int hp, const f32x4 (&rq)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = tid + 256 * it;
+            const int pl = q >> 4, sl = q & 15;
+            const int h = h0 + 4 * hp + (pl >> 5), w = w0 + (pl & 31);
+            const bool ok = h < p.H && w < p.W;
+            const unsigned px = (unsigned)((n * p.H + h) * p.W + w);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + pl * kC1TP + sl * 8), v1 = *reinterpret_cast<const f32x4*>(T + pl * kC1TP + sl * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tb + sl * 8), b1 = *reinterpret_cast<const f32x4*>(Tb + sl * 8 + 4);
+            const h8 r = __builtin_bit_cast(h8, rq[it]);           // zeros without a skip operand (empty descriptor)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? v0[e] + b0[e] : v1[e - 4] + b1[e - 4]) + (float)r[e];
+            if (dual || !affine) {
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)((!affine && relu) ? fmaxf(v[e], 0.f) : v[e]);
+                if (dual) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f32x4, o), rs_q, ok ? (px * (unsigned)p.ld_raw + co_base + sl * 8) * 2u : kOOB, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f32x4, o), rs_y, ok ? (px * (unsigned)p.ldy + co_base + sl * 8) * 2u : kOOB, 0, 0);
+            }
+            if (affine) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(Tb + CO + sl * 8), s1 = *reinterpret_cast<const f32x4*>(Tb + CO + sl * 8 + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(Tb + 2 * CO + sl * 8), t1 = *reinterpret_cast<const f32x4*>(Tb + 2 * CO + sl * 8 + 4);
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float u = v[e] * (e < 4 ? s0[e] : s1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+                    o[e] = (_Float16)(relu ? fmaxf(u, 0.f) : u);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f32x4, o), rs_y, ok ? (px * (unsigned)p.ldy + co_base + sl * 8) * 2u : kOOB, 0, 0);
+            }
+        }
+    };
+    __syncthreads();                               // the operand tiles are no longer read
+    park(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rq1[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, skip_off(1, it), 0, 0);     // half 1's skip: under half 0's copy-out
+    __syncthreads();
+    copy_out(0, rq0);
+    __syncthreads();                               // half 0 has been read
+    park(1);
+    __syncthreads();
+    copy_out(1, rq1);
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -459,4 +671,86 @@ extern "C" int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* d, const void* x, cons
     if (d->Co == 64) return up2 ? launch_c3<1, 2, true>(a, grid, st) : launch_c3<1, 2, false>(a, grid, st);
     if (d->Co == 128) return up2 ? launch_c3<2, 4, true>(a, grid, st) : launch_c3<2, 4, false>(a, grid, st);
     return up2 ? launch_c3<4, 4, true>(a, grid, st) : launch_c3<4, 4, false>(a, grid, st);
+}
+
+extern "C" int ptx_conv1x1_skip_f16_supported(const ptx_conv3d_desc* d) {
+    if (!d) return 0;
+    const unsigned need = PTX_F16_OPERANDS | PTX_EPI_OUT_F16;
+    const unsigned may = need | PTX_EPI_AFFINE | PTX_EPI_RELU | PTX_EPI_DUAL_RAW | PTX_RES_F16 | PTX_EPI_RES_ADD | PTX_EPI_RES_PADA | PTX_EPI_RES_UP;
+    if ((d->flags & need) != need || (d->flags & ~may)) return 0;
+    const int K = 2 * d->Ci;
+    if ((K != 64 && K != 128 && K != 256) || d->Co < 128 || d->Co % 128 || d->groups > 1) return 0;
+    if (d->kT != 1 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT || d->pH || d->pW) return 0;
+    if (d->Ti != 1 || d->To != 1 || d->Ho != d->Hi || d->Wo != d->Wi || d->N <= 0 || d->Hi <= 0 || d->Wi < kC3TW) return 0;
+    if (2 * d->ldx < K || (2 * d->ldx) % 8 || d->ldy < d->Co || d->ldy % 8 || 2 * d->Kc < K || (2 * d->Kc) % 8 || d->Co_pad < d->Co) return 0;
+    const bool has_res = (d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) != 0;
+    if (has_res) {
+        if (!(d->flags & PTX_RES_F16) || d->ldr % 8) return 0;                     // halfs only (fp32 skips keep the generic tiles)
+        if ((d->flags & PTX_EPI_RES_ADD) && (d->flags & PTX_EPI_RES_PADA)) return 0;
+        if (d->flags & PTX_EPI_RES_PADA) {
+            if (!(d->flags & PTX_EPI_RES_UP) || d->res_sT != 0 || d->res_sH != d->res_sW || d->res_sH < 0 || d->res_sH > 1) return 0;
+            if (d->res_C < d->Co || d->ldr < d->res_C || d->res_T != 1 || ((d->Hi - 1) >> d->res_sH) >= d->res_H || ((d->Wi - 1) >> d->res_sW) >= d->res_W) return 0;
+        } else if (d->ldr < d->Co) return 0;
+    } else if (d->flags & (PTX_RES_F16 | PTX_EPI_RES_UP)) return 0;
+    if ((d->flags & PTX_EPI_DUAL_RAW) && !(d->flags & PTX_EPI_AFFINE)) return 0;
+    if ((uint64_t)d->N * d->Hi * d->Wi * d->ldy * 2ull >= 0x80000000ull) return 0;                 // 32-bit buffer offsets on every operand
+    if (has_res && (uint64_t)d->N * ((d->flags & PTX_EPI_RES_PADA) ? (uint64_t)d->res_H * d->res_W : (uint64_t)d->Hi * d->Wi) * d->ldr * 2ull >= 0x80000000ull) return 0;
+    if ((uint64_t)d->N * d->Hi * d->Wi * d->ldx * 4ull >= 0x80000000ull || (uint64_t)d->Co_pad * d->Kc * 4ull >= 0x80000000ull) return 0;
+    return (int64_t)d->N * cdiv(d->Hi, kC3TH) * cdiv(d->Wi, kC3TW) <= 0x7fffffffLL;
+}
+
+template <int NCH>
+static int launch_c1(const C1Args& a, dim3 grid, hipStream_t st) {
+    static_assert(kC1Lds <= 80 * 1024, "two workgroups per CU");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_skip_f16_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, kC1Lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_skip_f16_kernel<NCH>), grid, dim3(256), kC1Lds, st, a);
+    return hip_check(hipGetLastError(), "conv1x1_skip_f16 launch");
+}
+
+extern "C" int ptx_conv1x1_skip_f16_fwd(const ptx_conv3d_desc* d, const void* x, const void* w_packed, const float* bias, const void* res,
+                                        void* y, const ptx_conv_fused_ext* ext, ptx_stream_t stream) {
+    if (!d || !x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv1x1_skip_f16: null pointer");
+    if (!ptx_conv1x1_skip_f16_supported(d))
+        return fail(PTX_ERR_UNSUPPORTED, "conv1x1_skip_f16: a 1x1 conv over halfs with 64 / 128 / 256 input channels, a multiple of 128 output "
+                    "channels, at least 32 columns, halfs out, an optional half skip operand (same shape, or nearest-upsampled and channel-truncated)");
+    const bool has_res = (d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) != 0;
+    if (has_res && !res) return fail(PTX_ERR_INVALID, "conv1x1_skip_f16: residual flag set but res == NULL");
+    if ((d->flags & PTX_EPI_AFFINE) && (!ext || !ext->scale || !ext->shift || ext->ld_affine < d->Co || ext->ld_affine % 4))
+        return fail(PTX_ERR_INVALID, "conv1x1_skip_f16: PTX_EPI_AFFINE needs scale / shift tables with a row stride that is a multiple of 4");
+    if ((d->flags & PTX_EPI_DUAL_RAW) && (!ext || !ext->y_raw || ext->ld_raw < d->Co || ext->ld_raw % 8))
+        return fail(PTX_ERR_INVALID, "conv1x1_skip_f16: PTX_EPI_DUAL_RAW needs ext->y_raw with a row stride that is a multiple of 8 halfs");
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)(ext ? ext->y_raw : nullptr)) & 15)
+        return fail(PTX_ERR_INVALID, "conv1x1_skip_f16: misaligned pointer");
+    if ((d->flags & PTX_EPI_DUAL_RAW) && (uint64_t)d->N * d->Hi * d->Wi * ext->ld_raw * 2ull >= 0x80000000ull)
+        return fail(PTX_ERR_UNSUPPORTED, "conv1x1_skip_f16: the raw output of one launch must be < 2 GiB");
+    C1Args a{};
+    a.x = static_cast<const _Float16*>(x); a.w = static_cast<const _Float16*>(w_packed); a.bias = bias;
+    a.res = has_res ? static_cast<const _Float16*>(res) : nullptr;
+    a.scale = (d->flags & PTX_EPI_AFFINE) ? ext->scale : nullptr;
+    a.shift = (d->flags & PTX_EPI_AFFINE) ? ext->shift : nullptr;
+    a.ld_aff = (d->flags & PTX_EPI_AFFINE) ? ext->ld_affine : 0;
+    a.y = static_cast<_Float16*>(y);
+    a.y_raw = (d->flags & PTX_EPI_DUAL_RAW) ? static_cast<_Float16*>(ext->y_raw) : nullptr;
+    a.ld_raw = (d->flags & PTX_EPI_DUAL_RAW) ? ext->ld_raw : 0;
+    a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.ldx = 2 * d->ldx; a.ldy = d->ldy; a.Kc = 2 * d->Kc;
+    a.ldr = d->ldr;
+    if (d->flags & PTX_EPI_RES_PADA) { a.rH = d->res_H; a.rW = d->res_W; a.ush = d->res_sH; }
+    else { a.rH = d->Hi; a.rW = d->Wi; a.ush = 0; }
+    a.tiles_h = cdiv(d->Hi, kC3TH); a.tiles_w = cdiv(d->Wi, kC3TW);
+    a.x_bytes = (unsigned)((uint64_t)d->N * d->Hi * d->Wi * a.ldx * 2ull);
+    a.w_bytes = (unsigned)((uint64_t)d->Co_pad * a.Kc * 2ull);
+    a.r_bytes = has_res ? (unsigned)((uint64_t)d->N * a.rH * a.rW * a.ldr * 2ull) : 0u;
+    a.y_bytes = (unsigned)((uint64_t)d->N * d->Hi * d->Wi * a.ldy * 2ull);
+    a.raw_bytes = (d->flags & PTX_EPI_DUAL_RAW) ? (unsigned)((uint64_t)d->N * d->Hi * d->Wi * a.ld_raw * 2ull) : 0u;
+    a.flags = d->flags;
+    const dim3 grid((unsigned)(d->N * a.tiles_h * a.tiles_w), (unsigned)(d->Co / 128));
+    const hipStream_t st = (hipStream_t)stream;
+    const int K = 2 * d->Ci;
+    return K == 64 ? launch_c1<1>(a, grid, st) : K == 128 ? launch_c1<2>(a, grid, st) : launch_c1<4>(a, grid, st);
 }

@@ -483,14 +483,17 @@ class StemStep:
 
 
 class PatchConvStep:
-    """One ptx_conv3x3_f16_fwd launch: a generator-stage 3x3 conv (64 / 128 channels, halfs) served from one staged input
-    patch per tile (gen_stage_f16.hip) instead of the implicit-GEMM tiles."""
-    __slots__ = ("d", "x", "w", "b", "y", "ext", "label", "macs", "hbm_bytes")
-    kernel = "conv3x3_f16"
+    """One launch of a generator-stage kernel designed for the fp16 matrix cores (gen_stage_f16.hip) instead of the
+    implicit-GEMM tiles: ptx_conv3x3_f16_fwd (a GBlock's 3x3 convs, one staged input patch per tile) or, with `res` set /
+    kernel == "conv1x1_skip_f16", ptx_conv1x1_skip_f16_fwd (its closing 1x1 conv + skip + both outputs)."""
+    __slots__ = ("d", "x", "w", "b", "y", "ext", "res", "kernel", "label", "macs", "hbm_bytes")
 
     def __call__(self, st):
-        check(_lib.lib().ptx_conv3x3_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.y,
-                                             C.byref(self.ext) if self.ext is not None else None, st), self.label)
+        ext = C.byref(self.ext) if self.ext is not None else None
+        if self.kernel == "conv3x3_f16":
+            check(_lib.lib().ptx_conv3x3_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.y, ext, st), self.label)
+        else:
+            check(_lib.lib().ptx_conv1x1_skip_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y, ext, st), self.label)
 
 
 class StemF32Step:
@@ -697,15 +700,23 @@ class Plan:
             d.x2_sT, d.x2_sH, d.x2_sW = _t3(x2_stride)
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
-        if (fused and res is None and not raw and not tanh and x2 is None and os.environ.get("PTX_CONV3X3_F16", "1") != "0"
-                and self.lib.ptx_conv3x3_f16_supported(C.byref(d))):
-            # a GBlock's 3x3 conv at 64 / 128 channels: its own fp16 kernel (one staged patch per tile, no tile table)
+        patch = None
+        if fused and not tanh and x2 is None:
+            # generator stage: a GBlock's 3x3 convs (64 / 128 / 256 channels) and its closing 1x1 conv have their own fp16
+            # kernels (gen_stage_f16.hip: no tile table, nothing to tune); PTX_CONV3X3_F16=0 / PTX_CONV1X1_F16=0: A/B runs
+            if (res is None and not raw and os.environ.get("PTX_CONV3X3_F16", "1") != "0"
+                    and self.lib.ptx_conv3x3_f16_supported(C.byref(d))):
+                patch = "conv3x3_f16"
+            elif os.environ.get("PTX_CONV1X1_F16", "1") != "0" and self.lib.ptx_conv1x1_skip_f16_supported(C.byref(d)):
+                patch = "conv1x1_skip_f16"
+        if patch is not None:
             ps = PatchConvStep()
             ps.d, ps.x, ps.w, ps.b, ps.y, ps.ext, ps.label = d, st.x, st.w, st.b, st.y, ext, label
+            ps.res, ps.kernel = resptr, patch
             ps.macs, ps.hbm_bytes = st.macs, 0
             self.steps.append(ps)
             self.patch_steps = getattr(self, "patch_steps", 0) + 1
-            return y
+            return (y, raw_act) if raw else y
         key = json.dumps(d.key())
         tuned = tuned_lookup(key, _flags_kind(flags))
         if tuned is not None and not self.lib.ptx_conv3d_config_supported(C.byref(d), tuned[0]):

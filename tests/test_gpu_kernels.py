@@ -1679,3 +1679,86 @@ def test_conv3x3_f16_patch_kernel(ptx, N, H, W, Cc, up2, affine, relu):
     assert not lib.ptx_conv3x3_f16_supported(C.byref(d))
     d.Ci, d.flags = Cc // 2, d.flags | L.PTX_EPI_RES_ADD
     assert not lib.ptx_conv3x3_f16_supported(C.byref(d))
+
+
+@pytest.mark.parametrize("N,H,W,K,Co,skip,affine,dual,relu", [
+    (2, 16, 32, 64, 128, "up", True, True, True),        # blocks.5.1-like: upsampled, channel-truncated skip, both outputs
+    (2, 16, 64, 64, 256, "same", True, True, True),      # two output-channel parts over blockIdx.y, same-shape skip
+    (1, 19, 45, 128, 128, "up", True, True, True),       # two input chunks, ragged tiles
+    (1, 8, 32, 256, 256, "chan", True, True, False),     # four input chunks; skip = channel truncation only (log2 factor 0)
+    (2, 8, 32, 64, 128, "up", False, False, False),      # the last block: raw output only
+    (1, 12, 40, 128, 128, None, True, False, True),      # no skip, activated output only
+])
+def test_conv1x1_skip_f16_kernel(ptx, N, H, W, K, Co, skip, affine, dual, relu):
+    """ptx_conv1x1_skip_f16_fwd (a GBlock's closing 1x1 conv: + skip, raw AND activated output) against torch fp32 on the same
+    half-rounded operands; the raw output must be the single rounding of the fp32 sum."""
+    L, lib = ptx._lib, _lib(ptx)
+    x = rnd(N, K, 1, H, W, seed=500 + K + H).half().float()
+    w = rnd(Co, K, 1, 1, 1, seed=501, scale=K ** -0.5).half().float()
+    bias = rnd(Co, seed=502)
+    v = F.conv3d(x, w, bias)
+    d = L.ConvDesc()
+    res_t = None
+    if skip is not None:
+        up = skip == "up"
+        Cr = Co if skip == "same" else Co + 64
+        rh, rw = (-(-H // 2), -(-W // 2)) if up else (H, W)
+        r = rnd(N, Cr, 1, rh, rw, seed=503).half().float()
+        rr = F.interpolate(r[:, :Co, 0], scale_factor=2, mode="nearest")[:, :, :H, :W].unsqueeze(2) if up else r[:, :Co]
+        v = v + rr
+        ldr = Cr + 8
+        rt = torch.zeros(N, 1, rh, rw, ldr, dtype=torch.float16)
+        rt[..., :Cr] = r.permute(0, 2, 3, 4, 1).half()
+        res_t = rt.to(DEV)
+        d.ldr = ldr
+        if skip == "same":
+            d.flags |= L.PTX_EPI_RES_ADD
+        else:
+            d.flags |= L.PTX_EPI_RES_PADA | L.PTX_EPI_RES_UP
+            d.res_C, d.res_T, d.res_H, d.res_W = Cr, 1, rh, rw
+            d.res_sT, d.res_sH, d.res_sW = 0, int(up), int(up)
+        d.flags |= L.PTX_RES_F16
+    raw_want = v[:, :, 0].permute(0, 2, 3, 1)
+    ld_aff = Co + 4
+    sc = torch.rand(N, ld_aff, generator=torch.Generator().manual_seed(505)) + 0.5
+    sh = rnd(N, ld_aff, seed=506, scale=0.3)
+    a = v * sc[:, :Co, None, None, None] + sh[:, :Co, None, None, None] if affine else v
+    a = F.relu(a) if relu else a
+    act_want = a[:, :, 0].permute(0, 2, 3, 1)
+    ldh = K + 8
+    xh = torch.zeros(N, 1, H, W, ldh, dtype=torch.float16)
+    xh[..., :K] = x.permute(0, 2, 3, 4, 1).half()
+    xd = xh.to(DEV)
+    pd = L.PackDesc(Co, K, 1, 1, 1, ldh, (Co + 127) // 128 * 128, 0, 0, 0, 0, 0, 0, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV, dtype=torch.float16)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd, bd, scd, shd = w.to(DEV), bias.to(DEV), sc.to(DEV), sh.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0),
+                                     C.c_void_p(wp.data_ptr()), _p(bp), _st()), "pack f16")
+    ldy, ld_raw = Co + 8, Co + 16
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, H, W, K // 2, ldh // 2
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, H, W, Co, ldy
+    d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+    d.Kc, d.Co_pad, d.groups = ldh // 2, pd.Co_pad, 1
+    d.flags |= (L.PTX_F16_OPERANDS | L.PTX_EPI_OUT_F16 | (L.PTX_EPI_AFFINE if affine else 0) | (L.PTX_EPI_RELU if relu else 0) |
+                (L.PTX_EPI_DUAL_RAW if dual else 0))
+    assert lib.ptx_conv1x1_skip_f16_supported(C.byref(d))
+    yd = torch.full((N, 1, H, W, ldy), float("nan"), device=DEV, dtype=torch.float16)
+    rawd = torch.full((N, 1, H, W, ld_raw), float("nan"), device=DEV, dtype=torch.float16)
+    ext = L.ConvFusedExt()
+    ext.scale, ext.shift, ext.ld_affine, ext.y_raw, ext.ld_raw = scd.data_ptr(), shd.data_ptr(), ld_aff, rawd.data_ptr(), ld_raw
+    L.check(lib.ptx_conv1x1_skip_f16_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), _p(bp),
+                                         C.c_void_p(res_t.data_ptr()) if res_t is not None else None, C.c_void_p(yd.data_ptr()),
+                                         C.byref(ext), _st()), "conv1x1_skip_f16")
+    torch.cuda.synchronize()
+    got = yd.cpu().float()[:, 0]
+    assert torch.isnan(got[..., Co:]).all()
+    err = (got[..., :Co] - act_want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, act_want.abs().max().item()), ("activated", err)
+    if dual:
+        graw = rawd.cpu().float()[:, 0]
+        assert torch.isnan(graw[..., Co:]).all()
+        err = (graw[..., :Co] - raw_want).abs().max().item()
+        assert err <= 2e-3 * max(1.0, raw_want.abs().max().item()), ("raw", err)
+    d.Co = 96
+    assert not lib.ptx_conv1x1_skip_f16_supported(C.byref(d))
