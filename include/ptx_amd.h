@@ -440,6 +440,8 @@ int ptx_linear_setsum_fwd(const float* x, const float* w, const float* b, float*
                           below (lo goes subnormal) -- activations entering an NL block are O(1); the softmax weights, which
                           are not (P ~ 1 / Nk), are split as 2^12 P with the factor folded into 1 / l.  d > 512 runs the
                           exact fp32 kernel.                                                                            */
+#define PTX_NL_OUT_F16 16 /* OR into PTX_NL_F16: y is written as halfs (ld_y / bs_y count halfs, ld_y a multiple of 4): the generator's
+                             attention output feeds a half conv (ptx_conv1x1_skip_f16_fwd)                                    */
 typedef struct ptx_nonlocal_desc {
     int32_t batch, Nq, Nk, d, dv;
     int32_t ld_theta, ld_phi, ld_g, ld_y;        /* row strides (floats)   */

@@ -94,7 +94,7 @@ class NonlocalDesc(C.Structure):
                [(n, C.c_int64) for n in ("bs_theta", "bs_phi", "bs_g", "bs_y")] + [("mode", C.c_int32)]
 
 
-PTX_NL_SOFTMAX, PTX_NL_SCALE, PTX_NL_F16, PTX_NL_X3, PTX_NL_RELU = 0, 1, 2, 4, 8
+PTX_NL_SOFTMAX, PTX_NL_SCALE, PTX_NL_F16, PTX_NL_X3, PTX_NL_RELU, PTX_NL_OUT_F16 = 0, 1, 2, 4, 8, 16
 
 
 class RgbConvDesc(C.Structure):

@@ -37,6 +37,7 @@ struct NlArgs {
     long long bs_t, bs_p, bs_g, bs_y;
     int q_tiles, scale_only;
     int relu;               // PTX_NL_RELU: P = relu(S) / Nk (the 'concatenation' affinity, nonlocalnet.py:213-243)
+    int out_f16;            // PTX_NL_OUT_F16: y holds halfs (ld_y / bs_y count halfs): the generator's fp16 plan feeds it to a half conv
     unsigned p_bytes, g_bytes, t_bytes;
 };
 
@@ -364,7 +365,12 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
             const int ch = c0 + cb * 64 + 4 * n;
             if (qo < p.Nq && ch < p.dv) {
                 const f32x4 o = {O[cb][0][r] * iv, O[cb][1][r] * iv, O[cb][2][r] * iv, O[cb][3][r] * iv};
-                *reinterpret_cast<f32x4*>(yb + (size_t)qo * p.ld_y + ch) = o;
+                if (p.out_f16) {
+                    _Float16* yh = reinterpret_cast<_Float16*>(p.y) + (size_t)b * p.bs_y + (size_t)qo * p.ld_y + ch;
+                    *reinterpret_cast<half4_t*>(yh) = to_half4(o[0], o[1], o[2], o[3]);
+                } else {
+                    *reinterpret_cast<f32x4*>(yb + (size_t)qo * p.ld_y + ch) = o;
+                }
             }
         }
     }
@@ -619,9 +625,11 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
         d->ld_g % 4 || d->ld_y % 4 || d->bs_theta % 4 || d->bs_phi % 4 || d->bs_g % 4 || d->bs_y % 4)
         return fail(PTX_ERR_INVALID, "nonlocal: row / batch strides must be multiples of 4 floats and cover the extents");
     if (((uintptr_t)theta | (uintptr_t)phi | (uintptr_t)g | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "nonlocal: misaligned pointer");
-    if ((d->mode & ~(PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_X3 | PTX_NL_RELU)) || ((d->mode & PTX_NL_F16) && (d->mode & PTX_NL_X3)) ||
+    if ((d->mode & ~(PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_X3 | PTX_NL_RELU | PTX_NL_OUT_F16)) || ((d->mode & PTX_NL_F16) && (d->mode & PTX_NL_X3)) ||
         ((d->mode & PTX_NL_RELU) && !(d->mode & PTX_NL_SCALE)))
         return fail(PTX_ERR_INVALID, "nonlocal: unknown mode %d", d->mode);
+    if ((d->mode & PTX_NL_OUT_F16) && !(d->mode & PTX_NL_F16))
+        return fail(PTX_ERR_UNSUPPORTED, "nonlocal: PTX_NL_OUT_F16 (halfs out) goes with PTX_NL_F16, the generator's fp16 plan");
     const uint64_t tb = (uint64_t)d->Nq * d->ld_theta * 4ull, pb = (uint64_t)d->Nk * d->ld_phi * 4ull, gb = (uint64_t)d->Nk * d->ld_g * 4ull;
     if (tb >= 0x80000000ull || pb >= 0x80000000ull || gb >= 0x80000000ull)
         return fail(PTX_ERR_UNSUPPORTED, "nonlocal: one batch item of theta / phi / g must be < 2 GiB");
@@ -633,6 +641,7 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     a.q_tiles = cdiv(d->Nq, 64);
     a.scale_only = (d->mode & PTX_NL_SCALE) != 0;
     a.relu = (d->mode & PTX_NL_RELU) != 0;
+    a.out_f16 = (d->mode & PTX_NL_OUT_F16) != 0;
     a.t_bytes = (unsigned)tb; a.p_bytes = (unsigned)pb; a.g_bytes = (unsigned)gb;
     hipStream_t st = (hipStream_t)stream;
     if (d->mode & PTX_NL_F16) {          // fp16-operand MFMAs: the generator's self-attention shape family only

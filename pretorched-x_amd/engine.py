@@ -1071,8 +1071,13 @@ class Plan:
             d.mode |= PTX_NL_RELU
         if f16 and not scale_only and th.C <= 64:      # fp16-operand MFMAs (the generator's fp16 plan)
             d.mode |= PTX_NL_F16
+            if getattr(y, "f16", False):               # ... whose output conv reads halfs
+                from ._lib import PTX_NL_OUT_F16
+                d.mode |= PTX_NL_OUT_F16
         elif self.x3 and os.environ.get("PTX_NL_X3", "1") != "0":      # split operands, like the plan's convs
             d.mode |= PTX_NL_X3
+        if getattr(y, "f16", False) and not (d.mode & PTX_NL_F16):
+            raise PtxError("attention: a half output needs the fp16-operand kernel (d <= 64, softmax)")
         if os.environ.get("PTX_NL_FUSED", "1") == "0" or not self.lib.ptx_nonlocal_supported(C.byref(d)):
             return False
         lib, tp, pp, gp, yp = self.lib, _ptr(th.t), _ptr(ph.t), _ptr(g.t), _ptr(y.t)

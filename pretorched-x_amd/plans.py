@@ -340,6 +340,11 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
     for k, (si, bi, blk) in enumerate(flat):
         name = "blocks.%d.%d" % (si, bi)
         nxt = flat[k + 1][2] if k + 1 < len(flat) else None
+        if blk.kind != "gblock" and getattr(xr, "f16", False) and nxt is not None and nxt.kind == "gblock":
+            # self-attention inside the half chain (round 4): projections on the fp16 tiles, the output conv + residual + the
+            # next block's cBN1 + ReLU as ONE launch that writes both things the next block reads
+            xa, xr = biggan_attention_f16(self, xr, blk, name, tab(nxt.bn1))
+            continue
         if blk.kind != "gblock":                 # self-attention on the fp32 raw map, then re-enter the fp16 chain
             h32 = biggan_attention(self, xr, blk, name)
             xa, xr = (cbn(h32, nxt.bn1), h32) if nxt is not None else (None, h32)
@@ -367,6 +372,9 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         elif nxt.kind == "gblock":               # next block's cBN1 + ReLU, plus the raw sum for its skip
             xa, xr = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=tab(nxt.bn1), out_f16=True, raw=True,
                                label=name + ".conv4", **skip)
+        elif _half_attention_ok(flat, k + 1):    # attention next, inside the half chain: the raw sum as halfs
+            xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)
+            xa = None
         else:                                    # attention next: it wants the raw fp32 map
             xr = self.conv(t, pk(blk.conv4), one, zero, label=name + ".conv4", **skip)
             xa = None
@@ -413,6 +421,35 @@ def _rgb_conv(self, x, conv, scale_ptr, shift_ptr, ld_aff):
         check(lib.ptx_rgb_conv3x3_f16_fwd(C.byref(d), xp, scale_ptr, shift_ptr, wpp, bp, yp, st), "ptx_rgb_conv3x3_f16_fwd")
     self.steps.append(_tag(step, "rgb_conv3x3", 2 * x.N * x.H * x.W * x.C + 16 * x.N * x.H * x.W))
     return y
+
+
+def _half_attention_ok(flat, k):
+    """The attention block flat[k] can run inside the half chain: a GBlock follows it (whose cBN1 its output conv folds) and
+    its widths fit the half kernels (theta / phi d = ch / 8 <= 64: the fp16-operand attention; ch / 2 in {64, 128, 256} and
+    ch a multiple of 128: ptx_conv1x1_skip_f16_fwd).  PTX_ATTN_F16=0 keeps the fp32 block (A/B runs)."""
+    import os
+    if os.environ.get("PTX_ATTN_F16", "1") == "0" or k + 1 >= len(flat) or flat[k + 1][2].kind != "gblock":
+        return False
+    ch = flat[k][2].ch
+    return ch // 8 <= 64 and ch // 2 in (64, 128, 256) and ch % 128 == 0
+
+
+def biggan_attention_f16(self, x, att, name, next_affine):
+    """layers.Attention on a HALF raw map x, returning (relu(cBN1_next(out)) halfs, out halfs): theta / phi / g on the fp16-
+    operand tiles (fp32 out: the attention kernel rounds its operands to halfs in registers anyway), 2 x 2 max pools, the
+    fused attention kernel writing halfs (PTX_NL_OUT_F16), and `o` * gamma + x + the next block's cBN1 + ReLU with both
+    outputs as one ptx_conv1x1_skip_f16_fwd launch -- the fp32 round trip of the block, its x3 convs and the separate
+    affine pass behind it are gone."""
+    c8, c2 = att.ch // 8, att.ch // 2
+    one, zero = (1, 1, 1), (0, 0, 0)
+    tpg = self.conv(x, self.pack([att.theta, att.phi, att.g], None, f16=True), one, zero, label=name + ".theta_phi_g")
+    phi = self.maxpool(tpg.slice(c8, c8), (1, 2, 2), (1, 2, 2), (0, 0, 0))
+    g = self.maxpool(tpg.slice(2 * c8, c2), (1, 2, 2), (1, 2, 2), (0, 0, 0))
+    yatt = self.act(x.N, 1, x.H, x.W, c2, f16=True)
+    if not self.attention(tpg.slice(0, c8), phi, g, yatt, f16=True):
+        raise PtxError("%s: the fused fp16 attention refused a shape _half_attention_ok admitted" % name)
+    return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma"), f16=True), one, zero, relu=True, affine=next_affine,
+                     out_f16=True, raw=True, res=x, label=name + ".o")
 
 
 def biggan_attention(self, x, att, name):
