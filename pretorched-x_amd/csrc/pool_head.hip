@@ -229,6 +229,83 @@ __global__ void __launch_bounds__(256) maxpool3d_tile_kernel(ptx_pool3d_desc d, 
     }
 }
 
+// 3 x 3 x 3 / stride 2 / pad 1 (the ResNet3D stem pool, resnet3D.py:156), ROLLING over the frames: a thread owns a 2 x 2 output patch
+// x 4 channels of one clip for ALL output frames, reads every input frame of its 5 x 5 halo window exactly once (25 loads), pools
+// it in (H, W) and folds the 2-D result into the (at most two) output frames whose temporal window holds it -- output frame
+// `to` covers input frames 2 to - 1, 2 to, 2 to + 1.  The tile kernel above re-reads every input frame for 1.5 output frames
+// (15.2 loads per output at 4 x 4 patches); this one issues 25 / 4 x 2 = 12.5.  Same maxima in a different association: exact.
+__global__ void __launch_bounds__(256) maxpool3d_roll_kernel(ptx_pool3d_desc d, const float* __restrict__ x, float* __restrict__ y,
+                                                             unsigned total, int xcd_local) {
+    const int f4r = (d.C + 3) / 4;
+    const int ldy = d.ldy ? d.ldy : d.ld;
+    const int wsegs = (d.Wo + 1) / 2, hsegs = (d.Ho + 1) / 2;
+    const unsigned blk = xcd_local ? (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x) : blockIdx.x;
+    for (unsigned i = blk * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int q = (int)(i % (unsigned)f4r);
+        unsigned r = i / (unsigned)f4r;
+        const int ws = (int)(r % (unsigned)wsegs);
+        r /= (unsigned)wsegs;
+        const int hs = (int)(r % (unsigned)hsegs);
+        const int n = (int)(r / (unsigned)hsegs);
+        const int ho0 = hs * 2, wo0 = ws * 2;
+        const int h0 = ho0 * 2 - 1, w0 = wo0 * 2 - 1;
+        unsigned live_c = 0, live_r = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (w0 + c >= 0 && w0 + c < d.Wi && wo0 + (c < 3 ? 0 : 1) < d.Wo) live_c |= 1u << c;
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr)
+            if (h0 + rr >= 0 && h0 + rr < d.Hi && ho0 + (rr < 3 ? 0 : 1) < d.Ho) live_r |= 1u << rr;
+        const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        f32x4 acc[2][2] = {{ninf, ninf}, {ninf, ninf}};          // running maximum of the output frame being assembled
+        const float* base = x + ((size_t)n * d.Ti * d.Hi * d.Wi) * d.ld + q * 4;
+        float* ybase = y + (((size_t)n * d.To) * d.Ho * d.Wo) * ldy + q * 4;
+        for (int t = 0; t < d.Ti; ++t) {
+            const float* plane = base + (((ptrdiff_t)t * d.Hi + h0) * d.Wi + w0) * (ptrdiff_t)d.ld;
+            f32x4 v[5][5];
+#pragma unroll
+            for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    v[rr][c] = ninf;
+                    if ((live_r >> rr & 1) && (live_c >> c & 1))
+                        v[rr][c] = *reinterpret_cast<const f32x4*>(plane + ((ptrdiff_t)rr * d.Wi + c) * d.ld);
+                }
+            f32x4 f[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 m = ninf;
+#pragma unroll
+                    for (int rr = 2 * a; rr < 2 * a + 3; ++rr)
+#pragma unroll
+                        for (int c = 2 * b; c < 2 * b + 3; ++c) {
+                            m.x = fmaxf(m.x, v[rr][c].x); m.y = fmaxf(m.y, v[rr][c].y);
+                            m.z = fmaxf(m.z, v[rr][c].z); m.w = fmaxf(m.w, v[rr][c].w);
+                        }
+                    f[a][b] = m;
+                }
+            const bool closes = (t & 1) || t == d.Ti - 1;         // frame 2 to + 1 (or the clip's last frame) completes output `to`
+            const int to = t >> 1;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 m = acc[a][b];
+                    m.x = fmaxf(m.x, f[a][b].x); m.y = fmaxf(m.y, f[a][b].y); m.z = fmaxf(m.z, f[a][b].z); m.w = fmaxf(m.w, f[a][b].w);
+                    if (closes) {
+                        if (to < d.To && ho0 + a < d.Ho && wo0 + b < d.Wo)
+                            *reinterpret_cast<f32x4*>(ybase + (((size_t)to * d.Ho + ho0 + a) * d.Wo + wo0 + b) * ldy) = m;
+                        acc[a][b] = (t & 1) ? f[a][b] : ninf;     // an odd frame 2 to + 1 is also frame 2 (to + 1) - 1 of the next output
+                    } else {
+                        acc[a][b] = m;
+                    }
+                }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // global average pool
 // ---------------------------------------------------------------------------------------------
@@ -665,6 +742,21 @@ extern "C" int ptx_maxpool3d_fwd(const ptx_pool3d_desc* d, const float* x, float
     }
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "maxpool3d: misaligned pointer");
     const hipStream_t st = (hipStream_t)stream;
+    {
+        // the ResNet3D stem pool on the rolling kernel when its frames are too big for the XCD-local tile order to pay
+        // (kT-frame window above 6 MB: config 2's 112 x 112 x 64 frames, 111.9 -> 95.5 us = 4.8 TB/s; config 3's 56 x 56
+        // frames run 40 us on the XCD-local tile kernel and 58 us here -- 25 k threads are too few).  PTX_POOL_ROLL=0 / 1 forces.
+        static const int roll_env = getenv("PTX_POOL_ROLL") ? atoi(getenv("PTX_POOL_ROLL")) : -1;
+        const bool fits = d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 2 && d->sH == 2 && d->sW == 2 && d->pT == 1 && d->pH == 1 &&
+                          d->pW == 1 && !(d->flags & (PTX_POOL_SAME | PTX_POOL_PAD_ZERO)) && d->Ti >= 2;
+        const size_t total = (size_t)d->N * cdiv(d->Ho, 2) * cdiv(d->Wo, 2) * (c4 / 4);
+        const size_t window = (size_t)d->kT * d->Hi * d->Wi * d->ld * 4;
+        if (fits && roll_env != 0 && (roll_env == 1 || window > (6u << 20)) && total < (1ull << 31)) {
+            static const int xl_env2 = getenv("PTX_POOL_XCD") ? atoi(getenv("PTX_POOL_XCD")) : 1;
+            hipLaunchKernelGGL(maxpool3d_roll_kernel, dim3(grid_for(total)), dim3(256), 0, st, *d, x, y, (unsigned)total, xl_env2 & 1);
+            return hip_check(hipGetLastError(), "maxpool3d launch");
+        }
+    }
     if (d->kW == 3 && d->kH == 3 && d->sH == d->sW && (d->sW == 1 || d->sW == 2) && d->pW < 3 && d->pH < 3) {
         // measured on the config-2/3/4 geometries (scripts/gpu_pool_bench.py): 2 x 2 patches with a whole halo plane in
         // flight win wherever a launch is short of threads (latency bound); the big stride-1 pools (I3D at batch 8)

@@ -43,4 +43,23 @@ for (N, T, H, W, Cc, k, s) in SHAPES:
     if N == 2:
         tot_ms += ms
     print(f"N={N} {T}x{H}x{W}x{Cc} k={k} s={s}: {ms*1e3:7.1f} us  {mb/ms/1e3:7.2f} TB/s")
+# the ResNet3D stem pool exactly as the plans run it (MaxPool3d(3, 2, 1), resnet3D.py:156: symmetric padding, no SAME flags)
+for (N, T, H, W, Cc) in [(8, 16, 112, 112, 64), (8, 32, 56, 56, 64)]:
+    k, s_, p_ = (3, 3, 3), (2, 2, 2), (1, 1, 1)
+    out = [(i + 2 - 3) // 2 + 1 for i in (T, H, W)]
+    x = torch.randn(N, T, H, W, Cc, device="cuda")
+    y = torch.empty(N, *out, Cc, device="cuda")
+    d = L.PoolDesc(N, T, H, W, Cc, Cc, *out, *k, *s_, *p_, Cc, 0)
+    call = lambda: L.check(lib.ptx_maxpool3d_fwd(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), st), "pool")
+    for _ in range(5):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 50
+    mb = (x.numel() + y.numel()) * 4 / 1e6
+    print(f"resnet stem pool N={N} {T}x{H}x{W}x{Cc}: {ms*1e3:7.1f} us  {mb/ms/1e3:7.2f} TB/s")
 print(f"sum over the config-4 pools (N=2 rows, Mixed_4 x3 counted once each): {tot_ms:.3f} ms  WSEG={os.environ.get('PTX_POOL_WSEG', 'default')}")
