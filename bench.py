@@ -419,7 +419,7 @@ def main():
         def roof(name, ms, flop, launches):
             traffic, traffic_source = traffic_for(name)
             tf = flop / (ms * 1e-3) / 1e12
-            r = {"bound": "mfma", "kernel": ("%s_kernel" if name.startswith(("conv_stem", "conv3x3_f16", "conv1x1_skip_f16")) else "conv_igemm_kernel<%s>") % name,
+            r = {"bound": "mfma", "kernel": ("%s_kernel" if name.startswith(("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16")) else "conv_igemm_kernel<%s>") % name,
                  "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
                  "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches,
                  "avg_launch_ms": round(ms / launches, 4), "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3)}
@@ -560,7 +560,7 @@ def main():
                                   "fp32 accumulate; activations / epilogues / outputs fp32",
                      "value": round(rate3, 2), "unit": "%s/s" % unit, "ms_per_step": round(1e3 * el3 / args.steps, 4),
                      "speedup_vs_fp32_mfma": round(rate3 / (clips_per_s / world), 3),
-                     "roofline": {"bound": "mfma", "kernel": ("%s_kernel" if dn.startswith(("conv_stem", "conv3x3_f16", "conv1x1_skip_f16")) else "conv_igemm_kernel<%s>") % dn,
+                     "roofline": {"bound": "mfma", "kernel": ("%s_kernel" if dn.startswith(("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16")) else "conv_igemm_kernel<%s>") % dn,
                                   "achieved": round(dv["flop"] / dv["ms"] / 1e9, 2), "peak": round(peak3, 1),
                                   "unit": "TFLOP/s (algorithmic fp32-equivalent; peak = 2500 dense f16 / 3 MFMAs per product)",
                                   "frac": round(dv["flop"] / dv["ms"] / 1e9 / peak3, 4), "launches_per_step": dv["launches"],

@@ -511,6 +511,15 @@ int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* desc, const void* x, const 
 int ptx_conv1x1_skip_f16_supported(const ptx_conv3d_desc* desc);
 int ptx_conv1x1_skip_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, const void* res,
                              void* y, const ptx_conv_fused_ext* ext, ptx_stream_t stream);
+/* ptx_conv1x1_pro_f16_fwd -- the opening 1x1 conv of a GBlock (conv1: C -> C/4) with the block's cBN1 + ReLU applied to its
+ * INPUT fragments, so the previous block's closing conv stores one tensor (the raw sum) instead of two:
+ *     y = half(relu?(scale[n] * (W . relu(x * scale_in[n] + shift_in[n]) + bias) + shift[n]))
+ * x: RAW halfs.  ext_in carries the input affine (scale / shift / ld_affine over the K input channels; the other fields are
+ * ignored), ext the output affine (PTX_EPI_AFFINE) as for the other fused stages.  Accepted: K a multiple of 128 in
+ * 128..2048, Co = 64 / 128 / 256 / 512, H * W a multiple of 256, halfs in and out. */
+int ptx_conv1x1_pro_f16_supported(const ptx_conv3d_desc* desc);
+int ptx_conv1x1_pro_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const ptx_conv_fused_ext* ext_in, const void* w_packed,
+                            const float* bias, void* y, const ptx_conv_fused_ext* ext, ptx_stream_t stream);
 int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* desc);
 int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, void* y,
                         const ptx_conv_fused_ext* ext, ptx_stream_t stream);

@@ -160,6 +160,8 @@ SIGNATURES = {
     "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ptx_conv1x1_skip_f16_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv1x1_skip_f16_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(ConvFusedExt), _P]),
+    "ptx_conv1x1_pro_f16_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ptx_conv1x1_pro_f16_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, C.POINTER(ConvFusedExt), _P, _P, _P, C.POINTER(ConvFusedExt), _P]),
     "ptx_conv3x3_f16_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv3x3_f16_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(ConvFusedExt), _P]),
     "ptx_rgb_conv3x3_f16_supported": (C.c_int, [C.POINTER(RgbConvDesc)]),

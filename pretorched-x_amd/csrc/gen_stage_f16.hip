@@ -6,6 +6,7 @@
 //   ptx_rgb_conv3x3_f16_fwd   the output layer  BN -> ReLU -> conv3x3(ch -> 3) -> tanh  in one launch
 //   ptx_conv3x3_f16_fwd       a GBlock's 3x3 convs (64 / 128 / 256 channels) from one staged input patch
 //   ptx_conv1x1_skip_f16_fwd  a GBlock's closing 1x1 conv: + skip (upsampled, channel-truncated) and BOTH outputs the next block reads
+//   ptx_conv1x1_pro_f16_fwd   a GBlock's opening 1x1 conv with the block's cBN1 + ReLU applied to its input fragments
 //
 // ---- the image conv ----------------------------------------------------------------------------------------------------
 // 3 output channels waste 13/16 of the narrowest MFMA tile, and as an implicit GEMM the layer re-stages its input nine
@@ -561,6 +562,185 @@ __global__ void __launch_bounds__(256, 2) conv1x1_skip_f16_kernel(const C1Args p
     copy_out(1, rq1);
 }
 
+
+// ---- the opening 1x1 conv of a GBlock (conv1: C -> C/4) with cBN1 + ReLU in its loader ------------------------------------------
+//     y = half(relu?(scale2[n] * (W . relu(x * scale1[n] + shift1[n]) + bias) + shift2[n]))
+// x is the RAW half output of the previous block, so that block's closing conv stores ONE tensor instead of two (VERDICT r3
+// #5b: the activated copy was a third of conv4's bytes).  The activation is the big operand here (K = 256 ... 2048 channels per
+// position) and every byte of it is used once: it never touches LDS.  A lane loads its B-operand fragments (8 channels of one
+// position) straight from global memory, one 64-channel chunk ahead, applies the per-sample affine + ReLU as packed half math
+// (v_pk_fma_f16 / v_pk_max_f16; the tables sit in LDS as halfs) and feeds the MFMA; only the filter chunk [Co][64] is shared
+// through LDS (DMA'd, double-buffered, one barrier per chunk).  Transposed product and pixel-major epilogue as in the kernels
+// above.  NPT = 32-position tiles per wave (2, or 1 when 256 output channels need the accumulator registers).
+struct P1Args {
+    const _Float16* x;      // [M][ldx] halfs, raw
+    const _Float16* w;      // [Co_pad][Kc] halfs
+    const float* bias;
+    const float* scale1;    // [N][ld1]: the block's cBN1, applied to the INPUT
+    const float* shift1;
+    const float* scale2;    // [N][ld2] or NULL: the affine that follows the conv (cBN2)
+    const float* shift2;
+    _Float16* y;            // [M][ldy] halfs
+    int M, HW, K, ldx, ldy, ld1, ld2, Kc, nch;
+    unsigned x_bytes, w_bytes, y_bytes, flags;
+};
+
+template <int CT, int NPT>
+__global__ void __launch_bounds__(256, 2) conv1x1_pro_f16_kernel(const P1Args p) {
+    constexpr int CO = 32 * CT, POS = 128 * NPT;              // output channels / positions of one workgroup
+    constexpr int BT_BYTES = CO * 128, BT_IT = CO * 8 / 256;  // filter chunk [CO][64 halfs]; its 16-byte pieces per thread
+    constexpr int TP = CO + 8;                                // pitch (halfs) of the output tile
+    constexpr int REGION = (POS * TP * 2 > 2 * BT_BYTES) ? POS * TP * 2 : 2 * BT_BYTES;
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Bt = smem;                                          // [2][BT_BYTES]; later the output tile
+    _Float16* T1 = reinterpret_cast<_Float16*>(smem + REGION);            // [K] scale1 | [K] shift1, halfs
+    float* T2 = reinterpret_cast<float*>(smem + REGION + 4 * p.K);        // [CO] scale2 | [CO] bias * scale2 + shift2
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, kg = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = tile * POS;
+    const int n = m0 / p.HW;                                  // one sample per workgroup (HW % POS == 0)
+    const int co_base = blockIdx.y * CO;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    unsigned xo[2];                                          // (sized by its maximum, NPT <= 2)
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int m = m0 + (wave * NPT + i) * 32 + l32;
+        xo[i] = m < p.M ? (unsigned)((m * p.ldx + kg * 8) * 2) : kOOB;
+    }
+    static_assert(BT_IT <= 4 || CT == 8, "filter pieces");
+    unsigned bt_src8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= BT_IT) break;
+        const int q = tid + 256 * i;
+        const int co = q >> 3, ps = q & 7;
+        bt_src8[i] = (unsigned)(((co_base + co) * p.Kc + (ps ^ ((co >> 1) & 7)) * 8) * 2);
+    }
+    auto issue_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < BT_IT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bt + (c & 1) * BT_BYTES + (wave * 64 + 256 * i) * 16), 16,
+                                                         bt_src8[i] + (unsigned)c * 128u, 0, 0, 0);
+    };
+    // ---- tables -> LDS: the input affine as halfs (K of them), the output affine with the bias folded in ----
+    for (int k4 = tid * 4; k4 < p.K; k4 += 1024) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const f32x4 s = *reinterpret_cast<const f32x4*>(p.scale1 + (size_t)n * p.ld1 + k4), t = *reinterpret_cast<const f32x4*>(p.shift1 + (size_t)n * p.ld1 + k4);
+        *reinterpret_cast<h4*>(T1 + k4) = h4{(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
+        *reinterpret_cast<h4*>(T1 + p.K + k4) = h4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+    }
+    if (tid < CO / 4) {
+        const int c4 = tid * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale2) {
+            sc = *reinterpret_cast<const f32x4*>(p.scale2 + (size_t)n * p.ld2 + co_base + c4);
+            sf = *reinterpret_cast<const f32x4*>(p.shift2 + (size_t)n * p.ld2 + co_base + c4);
+        }
+        if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + co_base + c4);
+        *reinterpret_cast<f32x4*>(T2 + c4) = sc;
+        *reinterpret_cast<f32x4*>(T2 + CO + c4) = f32x4{bs[0] * sc[0] + sf[0], bs[1] * sc[1] + sf[1], bs[2] * sc[2] + sf[2], bs[3] * sc[3] + sf[3]};
+    }
+    issue_b(0);
+    h8 xa0[NPT][4], xa1[NPT][4];                             // the activation fragments of chunk c (even) / c + 1 (odd)
+    auto load_x = [&](h8 (&xa)[NPT][4], int c) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xa[i][j] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo[i] == kOOB ? kOOB : xo[i] + (unsigned)(c * 128 + j * 32), 0, 0));
+    };
+    load_x(xa0, 0);
+    f32x16 acc[CT][NPT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+    int b_off[CT], b_sw[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) {
+        const int co = 32 * a + l32;
+        b_off[a] = co * 128;
+        b_sw[a] = (co >> 1) & 7;
+    }
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto compute = [&](const h8 (&xa)[NPT][4], int c) {
+        const char* Bb = Bt + (c & 1) * BT_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = 2 * j + kg;
+            const h8 sc = *reinterpret_cast<const h8*>(T1 + c * 64 + slot * 8), sh = *reinterpret_cast<const h8*>(T1 + p.K + c * 64 + slot * 8);
+            h8 v[NPT], wb[CT];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) v[i] = __builtin_elementwise_max(__builtin_elementwise_fma(xa[i][j], sc, sh), zero);
+#pragma unroll
+            for (int a = 0; a < CT; ++a) wb[a] = *reinterpret_cast<const h8*>(Bb + b_off[a] + ((slot ^ b_sw[a]) << 4));
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[a], v[i], acc[a][i], 0, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int c = 0; c < p.nch; c += 2) {                      // (nch is even)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // filter chunk c landed, slot (c + 1) & 1 is free, tables visible
+        issue_b(c + 1);
+        load_x(xa1, c + 1);
+        compute(xa0, c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 2 < p.nch) {
+            issue_b(c + 2);
+            load_x(xa0, c + 2);
+        }
+        compute(xa1, c + 1);
+    }
+    // ---- epilogue ----
+    __syncthreads();                                          // the filter ring becomes the output tile
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+    _Float16* T = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = 32 * a + 8 * g + 4 * kg;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(T2 + co), sf = *reinterpret_cast<const f32x4*>(T2 + CO + co);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][i][4 * g + e] * sc[e] + sf[e];
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    o[e] = (_Float16)v;
+                }
+                *reinterpret_cast<h4*>(T + ((wave * NPT + i) * 32 + l32) * TP + co) = o;
+            }
+        }
+    __syncthreads();
+    constexpr int SL = CO / 8;
+#pragma unroll
+    for (int it = 0; it < POS * SL / 256; ++it) {
+        const int q = tid + 256 * it;
+        const int pl = q / SL, sl = q - pl * SL;
+        const int m = m0 + pl;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + pl * TP + sl * 8);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, m < p.M ? (unsigned)((m * p.ldy + co_base + sl * 8) * 2) : kOOB, 0, 0);
+    }
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -753,4 +933,70 @@ extern "C" int ptx_conv1x1_skip_f16_fwd(const ptx_conv3d_desc* d, const void* x,
     const hipStream_t st = (hipStream_t)stream;
     const int K = 2 * d->Ci;
     return K == 64 ? launch_c1<1>(a, grid, st) : K == 128 ? launch_c1<2>(a, grid, st) : launch_c1<4>(a, grid, st);
+}
+
+// ---- ptx_conv1x1_pro_f16: descriptor = ptx_conv3d_desc of the 1x1 conv; the INPUT affine travels in ext_in (scale / shift /
+// ld_affine of the block's cBN1), the output affine in ext as for the other fused stages ----
+extern "C" int ptx_conv1x1_pro_f16_supported(const ptx_conv3d_desc* d) {
+    if (!d) return 0;
+    const unsigned need = PTX_F16_OPERANDS | PTX_EPI_OUT_F16;
+    const unsigned may = need | PTX_EPI_AFFINE | PTX_EPI_RELU;
+    if ((d->flags & need) != need || (d->flags & ~may)) return 0;
+    const int K = 2 * d->Ci;
+    if (K < 128 || K > 2048 || K % 128 || d->groups > 1) return 0;                  // whole PAIRS of 64-channel chunks
+    if (d->Co != 64 && d->Co != 128 && d->Co != 256 && d->Co != 512) return 0;
+    if (d->kT != 1 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT || d->pH || d->pW) return 0;
+    if (d->Ti != 1 || d->To != 1 || d->Ho != d->Hi || d->Wo != d->Wi || d->N <= 0) return 0;
+    if (((int64_t)d->Hi * d->Wi) % 256) return 0;                                   // a workgroup's positions belong to one sample
+    if (2 * d->ldx < K || (2 * d->ldx) % 8 || d->ldy < d->Co || d->ldy % 8 || 2 * d->Kc < K || (2 * d->Kc) % 8 || d->Co_pad < d->Co) return 0;
+    const uint64_t M = (uint64_t)d->N * d->Hi * d->Wi;
+    if (M * d->ldx * 4ull >= 0x80000000ull || M * d->ldy * 2ull >= 0x80000000ull || (uint64_t)d->Co_pad * d->Kc * 4ull >= 0x80000000ull) return 0;
+    return 1;
+}
+
+template <int CT, int NPT>
+static int launch_p1(const P1Args& a, dim3 grid, hipStream_t st) {
+    constexpr int CO = 32 * CT, POS = 128 * NPT;
+    constexpr int region = (POS * (CO + 8) * 2 > 2 * CO * 128) ? POS * (CO + 8) * 2 : 2 * CO * 128;
+    const size_t lds = (size_t)region + 4 * (size_t)a.K + 2 * CO * sizeof(float);
+    if (lds > 80 * 1024) return fail(PTX_ERR_UNSUPPORTED, "conv1x1_pro_f16: %zu bytes of LDS", lds);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_pro_f16_kernel<CT, NPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_pro_f16_kernel<CT, NPT>), grid, dim3(256), lds, st, a);
+    return hip_check(hipGetLastError(), "conv1x1_pro_f16 launch");
+}
+
+extern "C" int ptx_conv1x1_pro_f16_fwd(const ptx_conv3d_desc* d, const void* x, const ptx_conv_fused_ext* ext_in, const void* w_packed,
+                                       const float* bias, void* y, const ptx_conv_fused_ext* ext, ptx_stream_t stream) {
+    if (!d || !x || !w_packed || !y || !ext_in || !ext_in->scale || !ext_in->shift) return fail(PTX_ERR_INVALID, "conv1x1_pro_f16: null pointer");
+    if (!ptx_conv1x1_pro_f16_supported(d))
+        return fail(PTX_ERR_UNSUPPORTED, "conv1x1_pro_f16: a 1x1 conv over halfs, K a multiple of 128 in 128..2048, Co in {64, 128, 256, 512}, "
+                    "H * W a multiple of 256, halfs out");
+    const int K = 2 * d->Ci;
+    if (ext_in->ld_affine < K || ext_in->ld_affine % 4) return fail(PTX_ERR_INVALID, "conv1x1_pro_f16: input affine row stride must cover K and be a multiple of 4");
+    if ((d->flags & PTX_EPI_AFFINE) && (!ext || !ext->scale || !ext->shift || ext->ld_affine < d->Co || ext->ld_affine % 4))
+        return fail(PTX_ERR_INVALID, "conv1x1_pro_f16: PTX_EPI_AFFINE needs scale / shift tables with a row stride that is a multiple of 4");
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)ext_in->scale | (uintptr_t)ext_in->shift) & 15)
+        return fail(PTX_ERR_INVALID, "conv1x1_pro_f16: misaligned pointer");
+    P1Args a{};
+    a.x = static_cast<const _Float16*>(x); a.w = static_cast<const _Float16*>(w_packed); a.bias = bias;
+    a.scale1 = ext_in->scale; a.shift1 = ext_in->shift; a.ld1 = ext_in->ld_affine;
+    a.scale2 = (d->flags & PTX_EPI_AFFINE) ? ext->scale : nullptr;
+    a.shift2 = (d->flags & PTX_EPI_AFFINE) ? ext->shift : nullptr;
+    a.ld2 = (d->flags & PTX_EPI_AFFINE) ? ext->ld_affine : 0;
+    a.y = static_cast<_Float16*>(y);
+    a.M = d->N * d->Hi * d->Wi; a.HW = d->Hi * d->Wi; a.K = K; a.ldx = 2 * d->ldx; a.ldy = d->ldy; a.Kc = 2 * d->Kc; a.nch = K / 64;
+    a.x_bytes = (unsigned)((uint64_t)a.M * a.ldx * 2ull);
+    a.w_bytes = (unsigned)((uint64_t)d->Co_pad * a.Kc * 2ull);
+    a.y_bytes = (unsigned)((uint64_t)a.M * a.ldy * 2ull);
+    a.flags = d->flags;
+    const hipStream_t st = (hipStream_t)stream;
+    if (d->Co == 64) return launch_p1<2, 2>(a, dim3((unsigned)(a.M / 256), 1), st);
+    if (d->Co == 128) return launch_p1<4, 2>(a, dim3((unsigned)(a.M / 256), 1), st);
+    return launch_p1<8, 1>(a, dim3((unsigned)(a.M / 128), (unsigned)(d->Co / 256)), st);
 }

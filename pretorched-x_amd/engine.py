@@ -486,11 +486,13 @@ class PatchConvStep:
     """One launch of a generator-stage kernel designed for the fp16 matrix cores (gen_stage_f16.hip) instead of the
     implicit-GEMM tiles: ptx_conv3x3_f16_fwd (a GBlock's 3x3 convs, one staged input patch per tile) or, with `res` set /
     kernel == "conv1x1_skip_f16", ptx_conv1x1_skip_f16_fwd (its closing 1x1 conv + skip + both outputs)."""
-    __slots__ = ("d", "x", "w", "b", "y", "ext", "res", "kernel", "label", "macs", "hbm_bytes")
+    __slots__ = ("d", "x", "w", "b", "y", "ext", "res", "kernel", "label", "macs", "hbm_bytes", "ext_in")
 
     def __call__(self, st):
         ext = C.byref(self.ext) if self.ext is not None else None
-        if self.kernel == "conv3x3_f16":
+        if self.kernel == "conv1x1_pro_f16":
+            check(_lib.lib().ptx_conv1x1_pro_f16_fwd(C.byref(self.d), self.x, C.byref(self.ext_in), self.w, self.b, self.y, ext, st), self.label)
+        elif self.kernel == "conv3x3_f16":
             check(_lib.lib().ptx_conv3x3_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.y, ext, st), self.label)
         else:
             check(_lib.lib().ptx_conv1x1_skip_f16_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y, ext, st), self.label)
@@ -605,7 +607,7 @@ class Plan:
 
     def conv(self, x, pk, stride, padding, relu=False, res=None, res_kind=None, res_stride=1,
              label="conv", y=None, x2=None, x2_stride=1, same=False, up2=False, affine=None, out_f16=False,
-             raw=False, tanh=False):
+             raw=False, tanh=False, pro_affine=None):
         """Fused generator-stage extras (fp16-operand convs only, ptx_conv3d_fused_fwd):
         up2      the conv slides over the nearest-2x upsampled input (the loader does the upsampling);
         affine   (scale_ptr, shift_ptr, ld): per-sample affine after bias (+ skip) -- the NEXT layer's cBN, folded;
@@ -701,6 +703,20 @@ class Plan:
             st.x2 = _ptr(x2.t)
             st.macs += x.N * To * Ho * Wo * pk.Co * x2.C
         patch = None
+        if pro_affine is not None:
+            # the conv reads the RAW map and applies (scale, shift, ld) + ReLU to its input fragments: ptx_conv1x1_pro_f16_fwd only
+            from ._lib import ConvFusedExt
+            if not (fused and res is None and not raw and not tanh and x2 is None and self.lib.ptx_conv1x1_pro_f16_supported(C.byref(d))):
+                raise PtxError("%s: an input affine needs the shapes ptx_conv1x1_pro_f16_fwd covers" % label)
+            ps = PatchConvStep()
+            ps.ext_in = ConvFusedExt()
+            ps.ext_in.scale, ps.ext_in.shift, ps.ext_in.ld_affine = pro_affine[0], pro_affine[1], int(pro_affine[2])
+            ps.d, ps.x, ps.w, ps.b, ps.y, ps.ext, ps.label = d, st.x, st.w, st.b, st.y, ext, label
+            ps.res, ps.kernel = resptr, "conv1x1_pro_f16"
+            ps.macs, ps.hbm_bytes = st.macs, 0
+            self.steps.append(ps)
+            self.patch_steps = getattr(self, "patch_steps", 0) + 1
+            return y
         if fused and not tanh and x2 is None:
             # generator stage: a GBlock's 3x3 convs (64 / 128 / 256 channels) and its closing 1x1 conv have their own fp16
             # kernels (gen_stage_f16.hip: no tile table, nothing to tune); PTX_CONV3X3_F16=0 / PTX_CONV1X1_F16=0: A/B runs

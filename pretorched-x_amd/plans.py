@@ -336,14 +336,25 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         o = offs[id(bn)]
         return (_ptr(scale_all, o), _ptr(shift_all, o), tot)
 
+    def pro_ok(nb, H, W):
+        """The NEXT block's conv1 can apply its own cBN1 + ReLU to its input fragments (ptx_conv1x1_pro_f16_fwd), so the conv
+        that produces its input stores the raw sum only.  PTX_CONV1_PRO=0: the two-output flow (A/B runs)."""
+        import os
+        if nb is None or nb.kind != "gblock" or os.environ.get("PTX_CONV1_PRO", "1") == "0":
+            return False
+        K, Co = nb.conv1.in_channels, nb.conv1.out_channels
+        # (16 x 16 maps stay on the two-output flow: 64 workgroups of 16 serial chunks measured 0.031 vs 0.020 ms)
+        return K % 128 == 0 and 128 <= K <= 2048 and Co in (64, 128, 256, 512) and (H * W) % 256 == 0 and H * W >= 1024
+
     xa, xr = cbn(h, flat[0][2].bn1), h          # activated input of the first block (halfs), its skip operand (fp32)
     for k, (si, bi, blk) in enumerate(flat):
         name = "blocks.%d.%d" % (si, bi)
         nxt = flat[k + 1][2] if k + 1 < len(flat) else None
         if blk.kind != "gblock" and getattr(xr, "f16", False) and nxt is not None and nxt.kind == "gblock":
             # self-attention inside the half chain (round 4): projections on the fp16 tiles, the output conv + residual + the
-            # next block's cBN1 + ReLU as ONE launch that writes both things the next block reads
-            xa, xr = biggan_attention_f16(self, xr, blk, name, tab(nxt.bn1))
+            # next block's cBN1 + ReLU as ONE launch that writes both things the next block reads (or the raw sum alone when
+            # the next conv1 activates its own input)
+            xa, xr = biggan_attention_f16(self, xr, blk, name, None if pro_ok(nxt, xr.H, xr.W) else tab(nxt.bn1))
             continue
         if blk.kind != "gblock":                 # self-attention on the fp32 raw map, then re-enter the fp16 chain
             h32 = biggan_attention(self, xr, blk, name)
@@ -351,7 +362,11 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
             continue
         up = bool(blk.upsample)
         pk = lambda c: self.pack(c, None, f16=True)            # noqa: E731
-        t = self.conv(xa, pk(blk.conv1), one, zero, relu=True, affine=tab(blk.bn2), out_f16=True, label=name + ".conv1")
+        if xa is None:                           # raw input: cBN1 + ReLU on this conv's input fragments
+            t = self.conv(xr, pk(blk.conv1), one, zero, relu=True, affine=tab(blk.bn2), out_f16=True, pro_affine=tab(blk.bn1),
+                          label=name + ".conv1")
+        else:
+            t = self.conv(xa, pk(blk.conv1), one, zero, relu=True, affine=tab(blk.bn2), out_f16=True, label=name + ".conv1")
         t = self.conv(t, pk(blk.conv2), one, (0, 1, 1), relu=True, affine=tab(blk.bn3), out_f16=True, up2=up,
                       label=name + ".conv2")
         t = self.conv(t, pk(blk.conv3), one, (0, 1, 1), relu=True, affine=tab(blk.bn4), out_f16=True, label=name + ".conv3")
@@ -369,6 +384,10 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
             xa = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=(_ptr(oscale), _ptr(oshift), obn.channels),
                            out_f16=True, label=name + ".conv4", **skip)
             xr = None
+        elif pro_ok(nxt, t.H, t.W) and _conv4_patch_ok(self, blk, t, xr, up):
+            # the next block activates its own input: ONE output, the raw sum (half of what this conv used to write)
+            xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)
+            xa = None
         elif nxt.kind == "gblock":               # next block's cBN1 + ReLU, plus the raw sum for its skip
             xa, xr = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=tab(nxt.bn1), out_f16=True, raw=True,
                                label=name + ".conv4", **skip)
@@ -423,6 +442,12 @@ def _rgb_conv(self, x, conv, scale_ptr, shift_ptr, ld_aff):
     return y
 
 
+def _conv4_patch_ok(self, blk, t, xr, up):
+    """The raw-only conv4 is only taken where the skip operand already is halfs (the first block's skip is the fp32 linear
+    output: it keeps the two-output fused stage so the chain of halfs starts there)."""
+    return bool(getattr(xr, "f16", False))
+
+
 def _half_attention_ok(flat, k):
     """The attention block flat[k] can run inside the half chain: a GBlock follows it (whose cBN1 its output conv folds) and
     its widths fit the half kernels (theta / phi d = ch / 8 <= 64: the fp16-operand attention; ch / 2 in {64, 128, 256} and
@@ -448,8 +473,10 @@ def biggan_attention_f16(self, x, att, name, next_affine):
     yatt = self.act(x.N, 1, x.H, x.W, c2, f16=True)
     if not self.attention(tpg.slice(0, c8), phi, g, yatt, f16=True):
         raise PtxError("%s: the fused fp16 attention refused a shape _half_attention_ok admitted" % name)
-    return self.conv(yatt, self.pack(att.o, None, scale=(att, "gamma"), f16=True), one, zero, relu=True, affine=next_affine,
-                     out_f16=True, raw=True, res=x, label=name + ".o")
+    pko = self.pack(att.o, None, scale=(att, "gamma"), f16=True)
+    if next_affine is None:                      # the next conv1 activates its own input: the raw sum only
+        return None, self.conv(yatt, pko, one, zero, out_f16=True, res=x, label=name + ".o")
+    return self.conv(yatt, pko, one, zero, relu=True, affine=next_affine, out_f16=True, raw=True, res=x, label=name + ".o")
 
 
 def biggan_attention(self, x, att, name):

@@ -1762,3 +1762,59 @@ def test_conv1x1_skip_f16_kernel(ptx, N, H, W, K, Co, skip, affine, dual, relu):
         assert err <= 2e-3 * max(1.0, raw_want.abs().max().item()), ("raw", err)
     d.Co = 96
     assert not lib.ptx_conv1x1_skip_f16_supported(C.byref(d))
+
+
+@pytest.mark.parametrize("N,H,W,K,Co,affine,relu", [
+    (2, 16, 16, 256, 64, True, True),        # blocks.5.x-like: Co = 64 (two 32-position tiles per wave)
+    (1, 16, 32, 512, 128, True, True),       # Co = 128
+    (2, 16, 16, 128, 256, True, False),      # Co = 256: one position tile per wave, 128-position workgroups
+    (1, 32, 32, 1024, 512, False, True),     # Co = 512 over blockIdx.y, 16 chunks, no output affine
+])
+def test_conv1x1_pro_f16_kernel(ptx, N, H, W, K, Co, affine, relu):
+    """ptx_conv1x1_pro_f16_fwd (a GBlock's opening 1x1 conv with cBN1 + ReLU on its input fragments) against torch fp32:
+    relu(x * s1 + t1) rounded to half (the fragment math is one fp16 fma with half tables), conv1x1, output affine, ReLU."""
+    L, lib = ptx._lib, _lib(ptx)
+    x = rnd(N, K, 1, H, W, seed=600 + K).half().float()
+    w = rnd(Co, K, 1, 1, 1, seed=601, scale=K ** -0.5).half().float()
+    bias = rnd(Co, seed=602)
+    ld1, ld2 = K + 4, Co + 4
+    g_ = torch.Generator().manual_seed(603)
+    s1, t1 = torch.rand(N, ld1, generator=g_) + 0.5, torch.randn(N, ld1, generator=g_) * 0.3
+    s2, t2 = torch.rand(N, ld2, generator=g_) + 0.5, torch.randn(N, ld2, generator=g_) * 0.3
+    act = F.relu((x * s1[:, :K, None, None, None].half().float() + t1[:, :K, None, None, None].half().float()).half().float())
+    v = F.conv3d(act, w, bias)
+    v = v * s2[:, :Co, None, None, None] + t2[:, :Co, None, None, None] if affine else v
+    v = F.relu(v) if relu else v
+    want = v[:, :, 0].permute(0, 2, 3, 1)
+    ldh = K + 8
+    xh = torch.zeros(N, 1, H, W, ldh, dtype=torch.float16)
+    xh[..., :K] = x.permute(0, 2, 3, 4, 1).half()
+    xd = xh.to(DEV)
+    pd = L.PackDesc(Co, K, 1, 1, 1, ldh, (Co + 127) // 128 * 128, 0, 0, 0, 0, 0, 0, 1)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV, dtype=torch.float16)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd, bd = w.to(DEV), bias.to(DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), _p(bd), None, None, None, None, C.c_float(0),
+                                     C.c_void_p(wp.data_ptr()), _p(bp), _st()), "pack f16")
+    s1d, t1d, s2d, t2d = s1.to(DEV), t1.to(DEV), s2.to(DEV), t2.to(DEV)
+    ldy = Co + 8
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, 1, H, W, K // 2, ldh // 2
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, H, W, Co, ldy
+    d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+    d.Kc, d.Co_pad, d.groups = ldh // 2, pd.Co_pad, 1
+    d.flags = L.PTX_F16_OPERANDS | L.PTX_EPI_OUT_F16 | (L.PTX_EPI_AFFINE if affine else 0) | (L.PTX_EPI_RELU if relu else 0)
+    assert lib.ptx_conv1x1_pro_f16_supported(C.byref(d))
+    ext_in, ext = L.ConvFusedExt(), L.ConvFusedExt()
+    ext_in.scale, ext_in.shift, ext_in.ld_affine = s1d.data_ptr(), t1d.data_ptr(), ld1
+    ext.scale, ext.shift, ext.ld_affine = s2d.data_ptr(), t2d.data_ptr(), ld2
+    yd = torch.full((N, 1, H, W, ldy), float("nan"), device=DEV, dtype=torch.float16)
+    L.check(lib.ptx_conv1x1_pro_f16_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.byref(ext_in), C.c_void_p(wp.data_ptr()), _p(bp),
+                                        C.c_void_p(yd.data_ptr()), C.byref(ext) if affine else None, _st()), "conv1x1_pro_f16")
+    torch.cuda.synchronize()
+    got = yd.cpu().float()[:, 0]
+    assert torch.isnan(got[..., Co:]).all()
+    err = (got[..., :Co] - want).abs().max().item()
+    assert err <= 3e-3 * max(1.0, want.abs().max().item()), (N, H, W, K, Co, err)
+    d.Hi = d.Ho = 15                                         # H * W no longer a multiple of 256
+    assert not lib.ptx_conv1x1_pro_f16_supported(C.byref(d))
