@@ -279,7 +279,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // three-slot ring (one input chunk): the tile requested during the previous step may stay in flight -- only tile s
+            // (and at tap 0 the patch) must have landed.  vmcnt counts this thread's requests in order: BT_IT pieces per tile.
+            if (NBUF == 3 && NCH == 1 && tap + 1 < 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BT_IT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                       // filter tile s (and at tap 0 the patch chunk) landed; slot (s - 1) % NBUF is free
             if (s + NBUF - 1 < NS) issue_filter(s + NBUF - 1);
             const char* Bb = Bt + (s % NBUF) * BT_BYTES;

@@ -764,3 +764,46 @@ def test_replaced_parameters_and_modules_change_the_weight_signature(ptx):
     assert eager.wanted(m, x) is True
     with torch.no_grad():
         assert eager.wanted(m, x) is False
+
+
+def test_generator_fp16_plan_wiring_without_gpu(ptx, monkeypatch):
+    """Round 4: which launches the fp16 generator plan is made of (dry plan, no GPU).  From the 32 x 32 stage on every GBlock runs
+    conv1 = ptx_conv1x1_pro_f16_fwd (cBN1 + ReLU on its input fragments, so the conv before it stores the raw sum only),
+    conv2 / conv3 = ptx_conv3x3_f16_fwd, conv4 = ptx_conv1x1_skip_f16_fwd; the attention block sits inside the half chain
+    (its output conv is a conv1x1_skip launch, no affine pass behind it); the image conv is ptx_rgb_conv3x3_f16_fwd on the
+    RAW last feature map.  Each PTX_* switch restores the generic path of its piece."""
+    from pretorched_x_amd.engine import ConvStep, PatchConvStep
+    L = ptx._lib
+
+    def kinds(**env):
+        for k in ("PTX_CONV3X3_F16", "PTX_CONV1X1_F16", "PTX_CONV1_PRO", "PTX_RGB_CONV", "PTX_ATTN_F16"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        G = ptx.biggan_deep(256, precision="fp16")
+        p = G.engine().dry_plan(G, (4, G.dim_z))
+        out = {}
+        for s in p.steps:
+            lab = getattr(s, "label", getattr(s, "__name__", "?"))
+            out.setdefault(lab, []).append(s.kernel if isinstance(s, PatchConvStep) else type(s).__name__ if isinstance(s, ConvStep) else "pass")
+        return out, p
+
+    k, plan = kinds()
+    for blk in ("blocks.3.0", "blocks.3.1", "blocks.4.0", "blocks.4.1", "blocks.5.0", "blocks.5.1"):
+        assert k[blk + ".conv1"] == ["conv1x1_pro_f16"], blk
+        assert k[blk + ".conv2"] == k[blk + ".conv3"] == ["conv3x3_f16"], blk
+        assert k[blk + ".conv4"] == ["conv1x1_skip_f16"], blk
+    assert k["blocks.3.2.o"] == ["conv1x1_skip_f16"] and k["blocks.3.2.theta_phi_g"] == ["ConvStep"]
+    assert k["rgb_conv3x3"] == ["pass"] and "output_layer.2" not in k
+    assert k["blocks.0.0.conv2"] == ["ConvStep"]                       # 4 x 4 maps stay on the implicit-GEMM tiles
+    assert len(k.get("affine_act_upsample", [])) == 1                   # only the first cBN of the network is a pass
+    # a conv in front of a prologue conv1 stores ONE tensor: no dual output, no affine
+    byl = {getattr(s, "label", ""): s for s in plan.steps if hasattr(s, "d")}
+    assert not byl["blocks.4.1.conv4"].d.flags & (L.PTX_EPI_DUAL_RAW | L.PTX_EPI_AFFINE)
+    assert byl["blocks.1.0.conv4"].d.flags & L.PTX_EPI_DUAL_RAW         # ... in front of a generic conv1 it still stores both
+    # switches
+    k, _ = kinds(PTX_CONV1_PRO="0")
+    assert k["blocks.5.0.conv1"] == ["ConvStep"] and k["blocks.5.0.conv4"] == ["conv1x1_skip_f16"]
+    k, _ = kinds(PTX_CONV3X3_F16="0", PTX_CONV1X1_F16="0", PTX_CONV1_PRO="0", PTX_RGB_CONV="0", PTX_ATTN_F16="0")
+    assert not any(v != ["ConvStep"] and v != ["pass"] and v != ["pass", "pass"] for v in k.values()), k
+    assert "output_layer.2" in k and len(k["affine_act_upsample"]) == 2
