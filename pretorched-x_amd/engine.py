@@ -728,7 +728,7 @@ class Plan:
         if patch is not None:
             ps = PatchConvStep()
             ps.d, ps.x, ps.w, ps.b, ps.y, ps.ext, ps.label = d, st.x, st.w, st.b, st.y, ext, label
-            ps.res, ps.kernel = resptr, patch
+            ps.res, ps.kernel, ps.ext_in = resptr, patch, None
             ps.macs, ps.hbm_bytes = st.macs, 0
             self.steps.append(ps)
             self.patch_steps = getattr(self, "patch_steps", 0) + 1

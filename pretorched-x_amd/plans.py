@@ -384,7 +384,9 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
             xa = self.conv(t, pk(blk.conv4), one, zero, relu=True, affine=(_ptr(oscale), _ptr(oshift), obn.channels),
                            out_f16=True, label=name + ".conv4", **skip)
             xr = None
-        elif pro_ok(nxt, t.H, t.W) and _conv4_patch_ok(self, blk, t, xr, up):
+        elif pro_ok(nxt, t.H, t.W) and getattr(xr, "f16", False):
+            # (only where the skip operand already is halfs: the first block's skip is the fp32 linear output and keeps the
+            #  two-output fused stage, so the chain of halfs starts there)
             # the next block activates its own input: ONE output, the raw sum (half of what this conv used to write)
             xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)
             xa = None
@@ -440,12 +442,6 @@ def _rgb_conv(self, x, conv, scale_ptr, shift_ptr, ld_aff):
         check(lib.ptx_rgb_conv3x3_f16_fwd(C.byref(d), xp, scale_ptr, shift_ptr, wpp, bp, yp, st), "ptx_rgb_conv3x3_f16_fwd")
     self.steps.append(_tag(step, "rgb_conv3x3", 2 * x.N * x.H * x.W * x.C + 16 * x.N * x.H * x.W))
     return y
-
-
-def _conv4_patch_ok(self, blk, t, xr, up):
-    """The raw-only conv4 is only taken where the skip operand already is halfs (the first block's skip is the fp32 linear
-    output: it keeps the two-output fused stage so the chain of halfs starts there)."""
-    return bool(getattr(xr, "f16", False))
 
 
 def _half_attention_ok(flat, k):
