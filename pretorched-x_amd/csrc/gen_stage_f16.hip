@@ -151,12 +151,13 @@ __global__ void __launch_bounds__(256) pack_rgb_conv_kernel(const float* __restr
 // workgroup (4 waves) owns 8 x 32 output positions x ALL output channels and stages the halo'd INPUT PATCH once -- 10 x 34
 // positions x 64 channels = 42.5 KB by LDS-DMA, 16-byte slots XOR-swizzled by position so the fragment reads are conflict
 // free; with PTX_PRO_UP2 every patch position is fetched from its source pixel (h / 2, w / 2): the upsampled map never exists
-// -- and serves all nine taps from it.  Only the filter streams: one [C][64] tile per tap (8 / 16 KB) through a 3- / 2-slot
-// ring, requested one or two taps ahead.  Per tap a wave issues 16 (C = 64) or 32 (C = 128, per 64-channel input chunk)
-// v_mfma_f32_32x32x16_f16 between barriers, fed by as many ds_read_b128.  The product is computed TRANSPOSED (filter rows as
-// the A operand): a lane then owns 4 consecutive output channels of one position, so the epilogue -- affine tables from LDS,
-// ReLU, 4 halfs per ds_write_b64 into a position-major tile, 16-byte row-major copy-out -- stores whole 128 / 256-byte pixels.
-// 59.5 KB (C = 64) / 75.5 KB (C = 128) of LDS: two workgroups per CU cover each other's patch load and epilogue.
+// -- and serves all nine taps from it.  Only the filter streams: 8 KiB tiles ([64][64 halfs] per tap at C = 64, [128][32 halfs]
+// per half tap at C >= 128 -- 16 v_mfma_f32_32x32x16_f16 per wave and step either way) through a four-slot ring, requested three
+// steps ahead and waited for with a COUNTED vmcnt and a bare s_barrier; the fragments of step s + 1 are read from LDS while
+// step s multiplies, group by group into the registers the MFMAs have just consumed.  The product is computed TRANSPOSED
+// (filter rows as the A operand): a lane then owns 4 consecutive output channels of one position, so the epilogue -- affine
+// tables from LDS, ReLU, 4 halfs per ds_write_b64 into a position-major tile, 16-byte row-major copy-out -- stores whole
+// 128 / 256-byte pixels.  76.5 / 77 KB of LDS: two workgroups per CU cover each other's patch load and epilogue.
 struct C3Args {
     const _Float16* x;      // [N][Hs][Ws][ldx] halfs (Hs = H / 2 under PTX_PRO_UP2)
     const _Float16* w;      // ptx_pack_conv_weight(f16 = 1): [9][Co_pad][Kc] halfs
@@ -172,19 +173,41 @@ constexpr int kC3TH = 8, kC3TW = 32, kC3PW = kC3TW + 2, kC3Pos = (kC3TH + 2) * k
 constexpr int kC3PatchPieces = (kC3Pos * 8 + 255) / 256 * 256;                              // 16-byte pieces, padded to whole rounds
 constexpr int kC3PatchBytes = kC3PatchPieces * 16;                                          // 45056
 
+// Phase clock of a workgroup (diagnostic build only: scripts/micro/build_timeline.sh compiles this file with -DPTX_C3_TIMELINE
+// into a SEPARATE library; the product library carries none of it).  Thread 0 writes the 100 MHz wall clock at: 0 entry, 1 requests
+// issued, 2 patch + first filter tile landed, 3 last MFMA issued, 4 output tile parked in LDS, 5 stores retired; 6 = __smid().
+#ifdef PTX_C3_TIMELINE
+__device__ unsigned long long* g_c3_tl = nullptr;
+#define PTX_C3_TL(k)                                                                                                   \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && g_c3_tl) g_c3_tl[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (k) == 6 ? (unsigned long long)__smid() : (unsigned long long)wall_clock64(); \
+    } while (0)
+#else
+#define PTX_C3_TL(k) do {} while (0)
+#endif
+
 // NCH: 64-channel input chunks (Ci = 64 NCH); CT: 32-channel output tiles of ONE workgroup (Co_wg = 32 CT: 64 or 128 --
 // wider outputs are cut along blockIdx.y, each part re-staging the patch: C = 256 runs as <4, 4> x 2)
 template <int NCH, int CT, bool UP2>
 __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
     constexpr int C = 32 * CT;                     // output channels of this workgroup
-    constexpr int NBUF = CT == 2 ? 3 : 2;          // filter ring
-    constexpr int BT_BYTES = C * 128;              // one (tap, chunk) filter tile: C rows x 64 halfs
-    constexpr int BT_IT = C * 8 / 256;             // its 16-byte pieces per thread
+    constexpr int KH = CT == 2 ? 64 : 32;          // input channels of one filter tile = one step (16 MFMAs per wave either way)
+    constexpr int SPT = 64 / KH;                   // steps per (tap, 64-channel chunk)
+    constexpr int NJ = KH / 16;                    // MFMA k-groups per step
+    constexpr int NBUF = 4;                        // filter ring: tile s + 1 is read while s multiplies and s + 2, s + 3 fly
+    constexpr int BT_BYTES = C * KH * 2;           // one filter tile: C rows x KH halfs = 8 KiB
+    constexpr int BT_IT = BT_BYTES / 16 / 256;     // its 16-byte pieces per thread (2)
+    constexpr int RS = KH / 8;                     // 16-byte slots per filter row (8 or 4)
     constexpr int PA_IT = kC3PatchPieces / 256;    // patch pieces per thread (11)
     constexpr int TP = C + 8;                      // pitch (halfs) of the output tile in LDS: conflict-free ds_write_b64
+    constexpr int SPC = 9 * SPT;                   // steps per input chunk
+    constexpr int NS = SPC * NCH;
+    static_assert(BT_BYTES == 8192 && BT_IT == 2, "one step = an 8 KiB filter tile");
     constexpr unsigned kOOB = 0x80000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    PTX_C3_TL(0);
+    PTX_C3_TL(6);
     char* Pa = smem;                               // the patch chunk, later the output tile
     char* Bt = smem + kC3PatchBytes;               // [NBUF][BT_BYTES]
     float* Sc = reinterpret_cast<float*>(smem + kC3PatchBytes + NBUF * BT_BYTES);     // [C] scale, [C] shift' = bias * scale + shift
@@ -202,6 +225,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
 
+    // affine tables of this sample: requested FIRST (vmcnt retires in order -- asked for after the patch they would make the
+    // table write wait for the whole patch), parked in LDS once the prologue's wait has passed
+    f32x4 t_sc = {1.f, 1.f, 1.f, 1.f}, t_sf = {0.f, 0.f, 0.f, 0.f}, t_bs = {0.f, 0.f, 0.f, 0.f};
+    if (tid < C / 4) {
+        const int c4 = tid * 4;
+        if (p.scale) {
+            t_sc = *reinterpret_cast<const f32x4*>(p.scale + (size_t)n * p.ld_aff + co_base + c4);
+            t_sf = *reinterpret_cast<const f32x4*>(p.shift + (size_t)n * p.ld_aff + co_base + c4);
+        }
+        if (p.bias) t_bs = *reinterpret_cast<const f32x4*>(p.bias + co_base + c4);
+    }
+
     // ---- DMA sources (byte offsets), fixed for the tile: piece q = wave * 64 + 256 i + lane lands at Pa + 16 q ----
     unsigned pa_src[PA_IT];
 #pragma unroll
@@ -215,15 +250,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
         const int sh_ = UP2 ? (h >> 1) : h, sw_ = UP2 ? (w >> 1) : w;
         pa_src[i] = ok ? (unsigned)((((n * p.Hs + sh_) * p.Ws + sw_) * p.ldx + slot * 8) * 2) : kOOB;
     }
-    unsigned bt_src[4];      // (sized by its maximum: a template-dependent extent indexed inside the voffset operand of the LDS-DMA
-                             //  builtin makes hipcc's host pass drop the kernel's stub -- DESIGN.md 3.8)
-    static_assert(BT_IT <= 4, "filter tile pieces per thread");
+    // filter tile: piece q -> row q / RS, physical slot q % RS holding logical slot (q % RS) ^ swz(row).  128-byte rows (KH = 64)
+    // swizzle by (row >> 1) & 7, 64-byte rows (KH = 32) by (row >> 2) & 3: either way the 16 lanes ds_read_b128 serves per cycle
+    // (rows l32 of one logical slot) cover the sixteen 16-byte columns of the 256-byte bank line once
+    unsigned bt_src[2];      // (a literal extent: a template-dependent one indexed inside the voffset operand of the LDS-DMA builtin
+                             //  makes hipcc's host pass drop the kernel's stub -- DESIGN.md 3.8)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i >= BT_IT) break;
+    for (int i = 0; i < 2; ++i) {
         const int q = tid + 256 * i;
-        const int co = q >> 3, ps = q & 7;
-        bt_src[i] = (unsigned)(((co_base + co) * p.Kc + (ps ^ ((co >> 1) & 7)) * 8) * 2);
+        const int co = q / RS, ps = q % RS;
+        const int swz = RS == 8 ? (co >> 1) & 7 : (co >> 2) & 3;
+        bt_src[i] = (unsigned)(((co_base + co) * p.Kc + (ps ^ swz) * 8) * 2);
     }
     auto issue_patch = [&](int chunk) {
 #pragma unroll
@@ -231,31 +268,20 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Pa + (wave * 64 + 256 * i) * 16), 16,
                                                      pa_src[i] == kOOB ? kOOB : pa_src[i] + (unsigned)chunk * 128u, 0, 0, 0);
     };
-    auto issue_filter = [&](int s) {                                  // step s = chunk * 9 + tap
-        const int chunk = s / 9, tap = s - chunk * 9, buf = s % NBUF;
-        const unsigned base = (unsigned)(tap * p.tap_stride) * 2u + (unsigned)chunk * 128u;
+    // step s = (chunk * 9 + tap) * SPT + half: the filter's rows [tap][co][chunk * 64 + half * KH ...]
+    auto issue_filter = [&](int chunk, int r) {                       // r = tap * SPT + half, the step inside the chunk
+        const int tap = r / SPT, hf = r - tap * SPT, buf = (chunk * SPC + r) % NBUF;
+        const unsigned base = (unsigned)(tap * p.tap_stride) * 2u + (unsigned)(chunk * 128 + hf * KH * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < BT_IT)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bt + buf * BT_BYTES + (wave * 64 + 256 * i) * 16), 16,
-                                                         bt_src[i] + base, 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bt + buf * BT_BYTES + (wave * 64 + 256 * i) * 16), 16,
+                                                     bt_src[i] + base, 0, 0, 0);
     };
-    constexpr int NS = 9 * NCH;
     issue_patch(0);
-    issue_filter(0);
-    if (NBUF == 3) issue_filter(1);
-    // affine tables of this sample -> LDS (shift' = bias * scale + shift: one fma per output in the epilogue)
-    if (tid < C / 4) {
-        const int c4 = tid * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) {
-            sc = *reinterpret_cast<const f32x4*>(p.scale + (size_t)n * p.ld_aff + co_base + c4);
-            sf = *reinterpret_cast<const f32x4*>(p.shift + (size_t)n * p.ld_aff + co_base + c4);
-        }
-        if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + co_base + c4);
-        *reinterpret_cast<f32x4*>(Sc + c4) = sc;
-        *reinterpret_cast<f32x4*>(Sh + c4) = f32x4{bs[0] * sc[0] + sf[0], bs[1] * sc[1] + sf[1], bs[2] * sc[2] + sf[2], bs[3] * sc[3] + sf[3]};
-    }
+    issue_filter(0, 0);
+    issue_filter(0, 1);
+    issue_filter(0, 2);
+    PTX_C3_TL(1);
 
     f32x16 acc[CT][2];
 #pragma unroll
@@ -264,59 +290,92 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
-    // fragment addresses: filter row co = 32 a + l32 (tap independent), patch position of output (row 2 wave + i, column l32)
+    // fragment addresses: filter row co = 32 a + l32 (step independent), patch position of output (row 2 wave + i, column l32)
     int b_off[CT], b_sw[CT];
 #pragma unroll
     for (int a = 0; a < CT; ++a) {
         const int co = 32 * a + l32;
-        b_off[a] = co * 128;
-        b_sw[a] = (co >> 1) & 7;
+        b_off[a] = co * KH * 2;
+        b_sw[a] = RS == 8 ? (co >> 1) & 7 : (co >> 2) & 3;
     }
-    const int p_base = (2 * wave) * kC3PW + l32;
+    int p_base = (2 * wave) * kC3PW + l32;
+
+    // The fragments of step s + 1 are requested while step s multiplies: group j's registers are refilled right after group
+    // j's MFMAs have issued, so inside an input chunk no MFMA waits on an LDS read issued behind the same barrier (measured with
+    // the phase clock, scripts/gpu_c3_timeline.py: read-then-multiply per tap took 2.4x the tap's MFMA time).
+    h8 xa[NJ][2], wb[NJ][CT];
+    auto load_group = [&](int j, int r, const char* Bb) {            // fragments of k-group j of step r (inside its chunk)
+        const int tap = r / SPT, hf = r - tap * SPT;
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pos = p_base + (i + kh) * kC3PW + kw;
+            xa[j][i] = *reinterpret_cast<const h8*>(Pa + pos * 128 + (((hf * RS + 2 * j + kg) ^ ((pos >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < CT; ++a) wb[j][a] = *reinterpret_cast<const h8*>(Bb + b_off[a] + (((2 * j + kg) ^ b_sw[a]) << 4));
+    };
+    auto mma_group = [&](int j) {
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j][a], xa[j][i], acc[a][i], 0, 0, 0);   // C^T[co][position]
+    };
+
+    // prologue: everything but filter tile 2 has landed -> tables to LDS, fragments of step 0
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BT_IT) : "memory");
+    if (tid < C / 4) {
+        const int c4 = tid * 4;
+        *reinterpret_cast<f32x4*>(Sc + c4) = t_sc;
+        *reinterpret_cast<f32x4*>(Sh + c4) = f32x4{t_bs[0] * t_sc[0] + t_sf[0], t_bs[1] * t_sc[1] + t_sf[1], t_bs[2] * t_sc[2] + t_sf[2],
+                                                   t_bs[3] * t_sc[3] + t_sf[3]};
+    }
+    __syncthreads();
+    PTX_C3_TL(2);
+    asm volatile("; LDS reads stay below the barrier" : "+v"(p_base)::"memory");
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) load_group(j, 0, Bt);
 
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) {
+        const int s0 = chunk * SPC;                // (SPC % NBUF != 0: ring slots are taken from the running step index)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int s = chunk * 9 + tap;
-            // three-slot ring (one input chunk): the tile requested during the previous step may stay in flight -- only tile s
-            // (and at tap 0 the patch) must have landed.  vmcnt counts this thread's requests in order: BT_IT pieces per tile.
-            if (NBUF == 3 && NCH == 1 && tap + 1 < 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BT_IT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                       // filter tile s (and at tap 0 the patch chunk) landed; slot (s - 1) % NBUF is free
-            if (s + NBUF - 1 < NS) issue_filter(s + NBUF - 1);
-            const char* Bb = Bt + (s % NBUF) * BT_BYTES;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            int a_off[2], a_sw[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int pos = p_base + (i + kh) * kC3PW + kw;
-                a_off[i] = pos * 128;
-                a_sw[i] = (pos >> 1) & 7;
+        for (int r = 0; r < SPC; ++r) {
+            const int s = s0 + r;
+            if (r > 0) {
+                // filter tile s + 1 has landed for everyone (s + 2 may still fly); every wave is done with slot (s - 1) % NBUF.
+                // A bare s_barrier: __syncthreads() fences with vmcnt(0) lgkmcnt(0), which would wait for tile s + 2 and for the
+                // fragments just requested.  Nothing is WRITTEN to LDS by a wave inside the loop (the DMA is counted by vmcnt).
+                if (s + 2 < NS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(BT_IT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            asm volatile("; LDS reads stay below the barrier" : "+v"(a_off[0]), "+v"(a_off[1])::"memory");
+            if (r + 3 < SPC) issue_filter(chunk, r + 3);            // (issued between MFMA groups instead: same time, measured)
+            else if (chunk + 1 < NCH) issue_filter(chunk + 1, r + 3 - SPC);
+            const bool prefetch = r + 1 < SPC;     // (the next chunk's first fragments wait for its patch, below)
+            const char* Bn = Bt + ((s + 1) % NBUF) * BT_BYTES;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int slot = 2 * j + kg;
-                h8 xa[2], wb[CT];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) xa[i] = *reinterpret_cast<const h8*>(Pa + a_off[i] + ((slot ^ a_sw[i]) << 4));
-#pragma unroll
-                for (int a = 0; a < CT; ++a) wb[a] = *reinterpret_cast<const h8*>(Bb + b_off[a] + ((slot ^ b_sw[a]) << 4));
-#pragma unroll
-                for (int a = 0; a < CT; ++a)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[a], xa[i], acc[a][i], 0, 0, 0);   // C^T[co][position]
+            for (int j = 0; j < NJ; ++j) {
+                mma_group(j);
+                __builtin_amdgcn_sched_barrier(0);
+                if (prefetch) load_group(j, r + 1, Bn);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (chunk + 1 < NCH) {
             __syncthreads();                       // every wave is done with this patch chunk
             issue_patch(chunk + 1);                // exposed; the CU's other workgroup covers it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            asm volatile("; LDS reads stay below the barrier" : "+v"(p_base)::"memory");
+            const char* Bn = Bt + ((s0 + SPC) % NBUF) * BT_BYTES;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) load_group(j, 0, Bn);
         }
     }
 
     // ---- epilogue: lane = position (2 wave + i, l32); element r of acc[a][i] = channel 32 a + 8 (r >> 2) + 4 kg + (r & 3) ----
+    PTX_C3_TL(3);
     __syncthreads();                               // all fragment reads done: the patch area becomes the output tile
     const bool relu = (p.flags & PTX_EPI_RELU) != 0;
     _Float16* T = reinterpret_cast<_Float16*>(Pa);
@@ -340,6 +399,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
             }
         }
     __syncthreads();
+    PTX_C3_TL(4);
     constexpr int SL = C / 8;                      // 16-byte pieces per pixel
     const size_t y_img = (size_t)n * p.H * p.W * p.ldy;      // element offset of this image
 #pragma unroll
@@ -352,6 +412,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_f16_kernel(const C3Args p) {
             *reinterpret_cast<f32x4*>(p.y + y_img + ((size_t)h * p.W + w) * p.ldy + co_base + sl * 8) = v;
         }
     }
+#ifdef PTX_C3_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PTX_C3_TL(5);
+#endif
 }
 
 
@@ -793,6 +857,12 @@ extern "C" int ptx_rgb_conv3x3_f16_fwd(const ptx_rgb_conv_desc* d, const void* x
     return hip_check(hipGetLastError(), "rgb_conv3x3_f16 launch");
 }
 
+#ifdef PTX_C3_TIMELINE
+extern "C" int ptx_c3_timeline(void* buf) {        // diagnostic build only: 8 x u64 per workgroup, or NULL to switch off
+    return hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_c3_tl), &buf, sizeof(buf)), "ptx_c3_timeline");
+}
+#endif
+
 extern "C" int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* d) {
     if (!d) return 0;
     const unsigned need = PTX_F16_OPERANDS | PTX_EPI_OUT_F16;
@@ -814,7 +884,7 @@ extern "C" int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* d) {
 
 template <int NCH, int CT, bool UP2>
 static int launch_c3(const C3Args& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = kC3PatchBytes + (size_t)(CT == 2 ? 3 : 2) * (32 * CT) * 128 + 2 * (32 * CT) * sizeof(float);
+    constexpr size_t lds = kC3PatchBytes + 4 * 8192 + 2 * (32 * CT) * sizeof(float);       // patch + four filter tiles + tables
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     static bool attr_set[64] = {};
     int dev = 0;
