@@ -583,6 +583,12 @@ extern "C" const char* ptx_conv3d_config_name(int config) {
     return kConfigs[config].name;
 }
 
+#ifdef PTX_IGEMM_TIMELINE
+extern "C" int ptx_igemm_timeline(void* buf) {     // diagnostic build only: 8 x u64 per workgroup, or NULL to switch off
+    return hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_ig_tl), &buf, sizeof(buf)), "ptx_igemm_timeline");
+}
+#endif
+
 extern "C" int ptx_conv3d_config_supported(const ptx_conv3d_desc* d, int config) {
     if (validate_desc(d) != PTX_OK || config < 0 || config >= kNumConfigs) return 0;
     // the refusals of launch_conv, decided from the descriptor alone -- so a stale tuned-table entry is dropped when a plan

@@ -474,9 +474,33 @@ __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM
 // pointwise GEMMs through M mid channels, r2plus1d.py:68-88): the intermediate tensor's HBM round trip, one launch and the
 // second conv's per-tile prologue disappear, and the HBM-bound tail (residual read + 4x wider write) overlaps the
 // MFMA-bound body of the co-resident workgroups.  fp32 tiles with 2-stage LDS-DMA only.
+// Phase clock of a workgroup (diagnostic build only: scripts/micro/build_timeline.sh compiles conv_igemm.hip with
+// -DPTX_IGEMM_TIMELINE into a SEPARATE library; the product library carries none of it).  Thread 0 writes the 100 MHz wall clock
+// at: 0 entry, 1 operand tables built, 2 first tile landed, 3 last k-step done, 4 row-major epilogue past its wait, 5 stores
+// retired; 6 = __smid().
+#ifdef PTX_IGEMM_TIMELINE
+static __device__ unsigned long long* g_ig_tl = nullptr;
+#define PTX_IG_TL(k)                                                                                                   \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && g_ig_tl)                                                                               \
+            g_ig_tl[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k)] =             \
+                (k) == 6 ? (unsigned long long)__smid() : (unsigned long long)wall_clock64();                          \
+    } while (0)
+#define PTX_IG_TL_END()                                                                                                \
+    do {                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        PTX_IG_TL(5);                                                                                                  \
+    } while (0)
+#else
+#define PTX_IG_TL(k) do {} while (0)
+#define PTX_IG_TL_END() do {} while (0)
+#endif
+
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
           bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
+    PTX_IG_TL(0);
+    PTX_IG_TL(6);
     static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
     static_assert(!(CHAIN && KWR && REPI), "kw-reuse chained tiles keep the column-wise tail epilogue");
     static_assert(!CHAIN || BN >= BK, "chained tail: the parked tile is cut into BN / BK k-chunks");
@@ -1034,6 +1058,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // (its last fragments were completed before that barrier), so step s may overwrite it; those
     // writes complete (lgkmcnt(0)) before the barrier of step s, after which step s+1 reads them.
     constexpr int STORE_KS = KSUB >= 3 ? 1 : 0;
+    PTX_IG_TL(1);
     if constexpr (DMA && NSTAGE >= 3) {
         // N-stage LDS-DMA ring: tile s+NSTAGE is requested right after the barrier of step s, i.e.
         // NSTAGE-1 k-steps before it is read.  Every wave issues exactly NPS DMA instructions per
@@ -1055,6 +1080,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 advance();
             }
             ring_barrier();
+            PTX_IG_TL(2);
             int offa = frag_off_a, offb = frag_off_b;
             post_barrier_offsets(offa, offb);
             load_tiles(NSTAGE - 1 < my_steps, NSTAGE - 1);
@@ -1090,6 +1116,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             load_tiles(true, 0);
             advance();
             step_barrier();
+            PTX_IG_TL(2);
             int offa = frag_off_a, offb = frag_off_b;
             post_barrier_offsets(offa, offb);
             load_tiles(my_steps > 1, 1);
@@ -1144,6 +1171,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         }
     }
 
+    PTX_IG_TL(3);
     if constexpr (CHAIN) {
         // ================= chained pointwise tail =================
         // P: the intermediate tile as the A operand of the second GEMM -- [BN / BK k-chunks][BM][BK] floats, 16-byte slots
@@ -1378,9 +1406,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             // become the waves' parking slices
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * RE::NP) : "memory");      // (the residual loads just issued may stay in flight)
             __syncthreads();
+            PTX_IG_TL(4);
             rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT>(acc, res4, smem + wave_u * RE::FLOATS, p.bias, rs_y,
                                                           (p.flags & PTX_EPI_RELU) != 0, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol,
                                                           p.ldy, lane);
+            PTX_IG_TL_END();
             return;
         }
     }
@@ -1426,6 +1456,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     // all splits -- in split order, so the result is bit-identical to the separate reduce kernel and independent of
     // which block happens to be last -- applies the epilogue and writes y.  No second launch.  Release / acquire:
     // device-scope fences around one atomic arrival counter per tile; the last block leaves the counter at zero.
+    PTX_IG_TL_END();
     if (to_partial && p.counters) {
         __threadfence();
         __syncthreads();
