@@ -201,6 +201,22 @@ int ptx_conv_stem_x3_supported(const ptx_conv3d_desc* desc);
 int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_packed, const float* bias, float* y,
                          ptx_stream_t stream);
 
+/* The PLANAR split-operand stem (conv_stem_x3.hip, round 4): same convolution, same descriptor and same arithmetic as
+ * ptx_conv_stem_x3_fwd for the RGB stems with stride_w == 2 (Ci <= 3, kW <= 7, Wi a multiple of 8) -- `conv1` of the
+ * ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D stems, the (1,7,7) spatial stem of R2Plus1D (r2plus1d.py:73-88)
+ * -- on 21 % fewer matrix instructions: the input is six half planes per frame (ptx_ncdhw_to_split_planes:
+ * [N][T][c0 c1 c2 hi | c0 c1 c2 lo][H][W], lo scaled by 2^12) and the K = 8 operand is one (kh, channel) run of 8 columns,
+ * so a filter row is 3 operands instead of 4.  w_stem: ptx_pack_stem_x3p_weight of the ptx_pack_conv_weight(fold_kw = 1,
+ * Ci = 4, Kc = 32, f16 = 2) filter ptx_conv_stem_x3_fwd takes (BatchNorm already folded there), ptx_stem_x3p_weight_elems
+ * floats; bias: [Co_pad] of the same pack.  ptx_conv_stem_x3p_supported: 1 if the descriptor can run here (a subset of
+ * ptx_conv_stem_x3_supported).                                                                                          */
+int ptx_ncdhw_to_split_planes(const float* x, void* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, ptx_stream_t stream);
+int ptx_conv_stem_x3p_supported(const ptx_conv3d_desc* desc);
+size_t ptx_stem_x3p_weight_elems(const ptx_conv3d_desc* desc);
+int ptx_pack_stem_x3p_weight(const ptx_conv3d_desc* desc, const float* w_x3, float* w_stem, ptx_stream_t stream);
+int ptx_conv_stem_x3p_fwd(const ptx_conv3d_desc* desc, const void* x, const float* w_stem, const float* bias, float* y,
+                          ptx_stream_t stream);
+
 /* RGB STEM convolution on the fp32 matrix cores, read straight from the caller's NCDHW tensor -- `conv1` + `bn1` + ReLU of
  * the ResNet3D family (resnet3D.py:153-155 / :204-206), the 2-D ResNet stem (torchvision_models.py), the (1,7,7) spatial
  * stem of R2Plus1D (r2plus1d.py:73-88), the SAME-padded I3D stem.  No fold / layout pass: a workgroup owns 256 consecutive

@@ -129,6 +129,11 @@ SIGNATURES = {
     "ptx_ncdhw_to_split4": (C.c_int, [_P, _P, _I, _I, _L, _P]),
     "ptx_conv_stem_x3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv_stem_x3_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "ptx_ncdhw_to_split_planes": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ptx_conv_stem_x3p_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ptx_stem_x3p_weight_elems": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ptx_pack_stem_x3p_weight": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
+    "ptx_conv_stem_x3p_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "ptx_conv_stem_f32_supported": (C.c_int, [C.POINTER(ConvDesc), _L, _L, _L]),
     "ptx_stem_f32_weight_elems": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ptx_pack_stem_f32_weight": (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),

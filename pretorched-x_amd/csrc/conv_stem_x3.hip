@@ -247,6 +247,279 @@ __global__ void __launch_bounds__(kStemNT) conv_stem_x3_kernel(const StemArgs p)
     }
 }
 
+
+// ---- the PLANAR variant (round 4; VERDICT r3 #6: "issue fewer MFMAs") -------------------------------------------------------
+// Of the 32 K slots of a (kt, kh) row above only 21 are live: channel 3 of every position is zero and so is kw = 7.  Here the
+// input is SIX half planes per frame (c0 c1 c2 hi, then lo: ptx_ncdhw_to_split_planes) and the K = 8 operand of a lane group
+// is one (kh, channel) CHUNK: 8 consecutive columns of one plane's patch row -- kw' = 0..7 with the filter shifted so the
+// window starts on an even column (kw' = kw + (pW & 1); the unused end is a zero weight).  A row is 3 chunks instead of 4,
+// two rows are 3 MFMA blocks instead of 4, a 7-row tap is 11 instead of 14: 21 % fewer v_mfma_f32_32x32x16_f16, a patch of
+// 12 instead of 16 bytes per pixel, a filter stream of 48 instead of 64 bytes per row and output channel, and one barrier per
+// TWO rows.  The 16 bytes of a chunk sit at a 4-byte-aligned LDS address (column 2 wo + const halfs): four ds_read_b32 per
+// operand, conflict-free (consecutive lanes, consecutive dwords).  Arithmetic identical to the kernel above.
+struct StemPArgs {
+    const _Float16* x;    // [N][Ti][6][Hi][Wi] halfs: planes c0 c1 c2 hi, c0 c1 c2 lo (lo scaled by 2^12)
+    const _Float16* w;    // [kT][NS][w_tiles][3 blocks][64 co][4 slots][8 halfs] (ptx_pack_stem_x3p_weight, slots swizzled)
+    const float* bias;
+    float* y;             // [N][To][Ho][Wo][ldy]
+    int N, Ti, Hi, Wi, To, Ho, Wo, ldy, ncol;
+    int kT, kH, sT, sH, pT, pH;
+    int R, PR, PCW;       // output rows per tile; patch rows; halfs per patch row (a multiple of 8)
+    int P2;               // a window starts at input column 2 wo - P2 (P2 = pW rounded up to even)
+    int NS;               // steps per temporal tap: (kH + 1) / 2 row pairs
+    int h_tiles, n_tiles, n_pieces, w_tiles;
+    unsigned flags;
+    unsigned x_bytes, w_bytes, y_bytes;
+    unsigned dv_wo[2];
+};
+
+constexpr int kPPatchBytes = 49152;                    // one patch buffer
+constexpr int kPBTile = 3 * 64 * 64;                   // bytes of one step's filter tile: 3 blocks x 64 channels x (2 chunks x (hi8 | lo8))
+constexpr int kPPiecesPerWave = (kPPatchBytes / 1024 + kStemWaves - 1) / kStemWaves;   // 7
+
+__device__ __forceinline__ f32x4 lds_chunk(const char* p) {       // 16 bytes at a 4-byte-aligned LDS address
+    const unsigned* q = reinterpret_cast<const unsigned*>(p);
+    return __builtin_bit_cast(f32x4, uint4{q[0], q[1], q[2], q[3]});
+}
+
+__global__ void __launch_bounds__(kStemNT) conv_stem_x3p_kernel(const StemPArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smemp[];
+    char* As = smemp;                                   // [2][kPPatchBytes]
+    char* Bs = smemp + 2 * kPPatchBytes;                // [2][kPBTile]
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int nt = blockIdx.y, n0 = nt * kStemBN;
+    const int to = tile % p.To;
+    int t_ = tile / p.To;
+    const int ht = t_ % p.h_tiles;
+    const int n = t_ / p.h_tiles;
+    const int ho0 = ht * p.R;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-lane DMA sources of the patch pieces this wave moves (frame independent): piece q = 8 columns of one plane row ----
+    unsigned a_src[kPPiecesPerWave];
+    const int h_base = ho0 * p.sH - p.pH;
+    const int pc8 = p.PCW >> 3, per_plane = p.PR * pc8;
+#pragma unroll
+    for (int i = 0; i < kPPiecesPerWave; ++i) {
+        const int q = (wave + kStemWaves * i) * 64 + lane;
+        const int pl = q / per_plane;
+        const int rem = q - pl * per_plane;
+        const int pr = rem / pc8;
+        const int h = h_base + pr, w = (rem - pr * pc8) * 8 - 8;            // patch column 0 is input column -8
+        const bool ok = pl < 6 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+        a_src[i] = ok ? (unsigned)(((pl * p.Hi + h) * p.Wi + w) * 2) : kOOB;
+    }
+    const unsigned frame_bytes = (unsigned)(6 * p.Hi * p.Wi * 2);
+
+    // ---- valid temporal taps (uniform) ----
+    const int t_first = to * p.sT - p.pT;
+    const int kt_lo = max(0, -t_first), kt_hi = min(p.kT - 1, p.Ti - 1 - t_first);
+    const int n_kt = kt_hi - kt_lo + 1;
+
+    auto issue_a_piece = [&](int buf, int i, int kt) {
+        if (wave + kStemWaves * i < p.n_pieces) {
+            const unsigned fbase = (unsigned)(n * p.Ti + t_first + kt) * frame_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(As + buf * kPPatchBytes + (wave + kStemWaves * i) * 1024), 16,
+                                                     a_src[i] == kOOB ? kOOB : a_src[i] + fbase, 0, 0, 0);
+        }
+    };
+    auto issue_b = [&](int buf, int kt, int s) {                     // 768 pieces of 16 bytes, stored contiguously (pre-swizzled)
+        const unsigned tbase = (unsigned)(((kt * p.NS + s) * p.w_tiles + nt) * kPBTile);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (wave * 64 + kStemNT * i < kPBTile / 16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + buf * kPBTile + (wave * 64 + kStemNT * i) * 16), 16,
+                                                         tbase + (unsigned)((tid + kStemNT * i) * 16), 0, 0, 0);
+    };
+
+    // ---- this lane's output positions: ml = wave * 64 + i * 32 + lane % 32 -> (r, wo) ----
+    const int g = lane >> 5, l32 = lane & 31;
+    int a_row[2];            // byte offset of (patch row r * sH, column 2 wo - P2 + 8) inside a plane
+    bool row_ok[2];
+    int m_out[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = wave * 64 + i * 32 + l32;
+        const unsigned r = fdiv((unsigned)ml, p.dv_wo);
+        const int wo = ml - (int)r * p.Wo;
+        row_ok[i] = (int)r < p.R && ho0 + (int)r < p.Ho;
+        const int rr = row_ok[i] ? (int)r : 0, ww = row_ok[i] ? wo : 0;
+        a_row[i] = ((rr * p.sH) * p.PCW + 2 * ww - p.P2 + 8) * 2;
+        m_out[i] = ((n * p.To + to) * p.Ho + ho0 + rr) * p.Wo + ww;
+    }
+    // chunk of (block b, lane group g) inside a row pair: chunks run (kh0,c0) (kh0,c1) (kh0,c2) (kh0+1,c0) (kh0+1,c1) (kh0+1,c2)
+    const int plane_b = p.PR * p.PCW * 2, row_b = p.PCW * 2, lo_b = 3 * plane_b;
+    const int o_blk0 = g ? plane_b : 0;
+    const int o_blk1 = g ? row_b : 2 * plane_b;
+    const int o_blk2 = g ? row_b + 2 * plane_b : row_b + plane_b;
+    const int o_blk1_last = 2 * plane_b;     // odd kH: the second row of the last pair does not exist -- group 1 multiplies a zero
+                                             // filter chunk by (finite) data it re-reads from group 0's address
+    const int b_lane = (l32 * 4) * 16;       // this lane's filter row inside a 32-channel half block: 4 slots of 16 bytes
+    const int b_sw = (l32 >> 2) & 3;         // 64-byte rows: physical slot = logical ^ ((row >> 2) & 3)  (row = 32 j + l32: same bits)
+
+    f32x16 acc[2][2], acc2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+
+    if (n_kt > 0) {
+#pragma unroll
+        for (int i = 0; i < kPPiecesPerWave; ++i) issue_a_piece(0, i, kt_lo);
+        issue_b(0, kt_lo, 0);
+        int bbuf = 0;
+        const bool odd = (p.kH & 1) != 0;
+        for (int ik = 0; ik < n_kt; ++ik) {
+            const int kt = kt_lo + ik;
+            const int abuf = ik & 1;
+            for (int s = 0; s < p.NS; ++s) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int off_a0 = a_row[0], off_a1 = a_row[1];
+                asm volatile("; LDS reads of this step depend on these" : "+v"(off_a0), "+v"(off_a1)::"memory");
+                const bool last_s = s == p.NS - 1;
+                if (!last_s) issue_b(bbuf ^ 1, kt, s + 1);
+                else if (ik + 1 < n_kt) issue_b(bbuf ^ 1, kt + 1, 0);
+                if (ik + 1 < n_kt) {
+                    const int per = (kPPiecesPerWave + p.NS - 1) / p.NS;
+#pragma unroll
+                    for (int i = 0; i < kPPiecesPerWave; ++i)
+                        if (i / per == s) issue_a_piece(abuf ^ 1, i, kt + 1);
+                }
+                const char* Ab = As + abuf * kPPatchBytes + (2 * s) * row_b;
+                const char* Bb = Bs + bbuf * kPBTile + b_lane;
+                const bool half_step = last_s && odd;
+#pragma unroll
+                for (int blk = 0; blk < 3; ++blk) {
+                    if (blk == 2 && half_step) break;                      // (uniform)
+                    const int o = blk == 0 ? o_blk0 : blk == 1 ? (half_step ? o_blk1_last : o_blk1) : o_blk2;
+                    f32x4 ahi[2], alo[2];
+                    ahi[0] = lds_chunk(Ab + off_a0 + o);
+                    alo[0] = lds_chunk(Ab + off_a0 + o + lo_b);
+                    ahi[1] = lds_chunk(Ab + off_a1 + o);
+                    alo[1] = lds_chunk(Ab + off_a1 + o + lo_b);
+                    f32x4 bhi[2], blo[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const char* bj = Bb + (blk * 64 + j * 32) * 64;
+                        bhi[j] = *reinterpret_cast<const f32x4*>(bj + (((2 * g) ^ b_sw) << 4));
+                        blo[j] = *reinterpret_cast<const f32x4*>(bj + (((2 * g + 1) ^ b_sw) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc2[i][j] = mma16(ahi[i], blo[j], acc2[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc2[i][j] = mma16(alo[i], bhi[j], acc2[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = mma16(ahi[i], bhi[j], acc[i][j]);
+                }
+                bbuf ^= 1;
+            }
+        }
+    }
+
+    // ---- epilogue: as the kernel above ----
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + j * 32 + l32;
+        const bool co_ok = co < p.ncol;
+        const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int m = __shfl(m_out[i], trow, 64);
+                const int ok = __shfl((int)row_ok[i], trow, 64);
+                float v = fmaf(acc2[i][j][r], 1.0f / 4096.0f, acc[i][j][r]) + bv;
+                v = relu ? fmaxf(v, 0.f) : v;
+                const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ok) ? off : kOOB, 0, 0);
+            }
+        }
+    }
+}
+
+// w_x3: ptx_pack_conv_weight(fold_kw = 1, Ci = 4, Kc = 32, f16 = 2) = [kT*kH][Co_pad][64 halfs], 8-channel blocks (hi8 | lo8) of
+// k = kw * 4 + c  ->  the planar stem's step tiles.  One thread per destination half.
+__global__ void __launch_bounds__(256) pack_stem_x3p_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int kT, int kH,
+                                                            int kW, int Co_pad, int w_tiles, int NS, int shift, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kwp = (int)(i & 7);
+        long long t = i >> 3;
+        const int phys = (int)(t & 3);
+        t >>= 2;
+        const int co_in = (int)(t & 63);
+        t >>= 6;
+        const int blk = (int)(t % 3);
+        t /= 3;
+        const int nt = (int)(t % w_tiles);
+        t /= w_tiles;
+        const int s = (int)(t % NS), kt = (int)(t / NS);
+        const int slot = phys ^ ((co_in >> 2) & 3);              // logical slot this physical one holds
+        const int gch = slot >> 1, lo = slot & 1;
+        const int qs = blk * 2 + gch;                            // chunk inside the row pair
+        const int kh = 2 * s + qs / 3, c = qs % 3;
+        const int kw = kwp - shift;
+        const int co = nt * 64 + co_in;
+        _Float16 v = (_Float16)0.f;
+        if (kh < kH && kw >= 0 && kw < kW && co < Co_pad)
+            v = src[((size_t)(kt * kH + kh) * Co_pad + co) * 64 + (kw >> 1) * 16 + lo * 8 + (kw & 1) * 4 + c];
+        dst[i] = v;
+    }
+}
+
+// fp32 [N][C][T][H][W] -> halfs [N][T][6][H][W]: planes c0 c1 c2 hi, c0 c1 c2 lo; 8 columns per thread
+__global__ void __launch_bounds__(256) ncdhw_to_split_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int C, int T,
+                                                                    int H, int W8, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w8 = (int)(i % W8);
+        long long t = i / W8;
+        const int h = (int)(t % H);
+        t /= H;
+        const int tt = (int)(t % T);
+        const long long n = t / T;
+        const size_t S = (size_t)T * H * W8 * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            half8 hi, lo;
+            if (c < C) {
+                const float* xs = x + ((size_t)n * C + c) * S + ((size_t)tt * H + h) * W8 * 8 + (size_t)w8 * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xs), v1 = *reinterpret_cast<const f32x4*>(xs + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? v0[e] : v1[e - 4];
+                    const _Float16 hh = (_Float16)v;
+                    hi[e] = hh;
+                    lo[e] = (_Float16)((v - (float)hh) * 4096.f);      // scaled lo (conv_igemm.hip, X3)
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }
+            }
+            _Float16* yp = y + ((((size_t)n * T + tt) * 6 + c) * H + h) * W8 * 8 + (size_t)w8 * 8;
+            *reinterpret_cast<half8*>(yp) = hi;
+            *reinterpret_cast<half8*>(yp + (size_t)3 * H * W8 * 8) = lo;
+        }
+    }
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -314,4 +587,85 @@ extern "C" int ptx_conv_stem_x3_fwd(const ptx_conv3d_desc* d, const float* x, co
     const dim3 grid((unsigned)a.n_tiles, (unsigned)cdiv(a.ncol, kStemBN));
     hipLaunchKernelGGL(conv_stem_x3_kernel, grid, dim3(kStemNT), lds, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "conv_stem_x3 launch");
+}
+
+// ---- the planar variant: same descriptor as ptx_conv_stem_x3_fwd, narrower domain ----
+static bool stem_x3p_geometry(const ptx_conv3d_desc* d, int& R, int& PR, int& PCW, int& P2) {
+    R = std::min(kStemRows / d->Wo, d->Ho);
+    PR = (R - 1) * d->sH + d->kH;
+    P2 = d->pW + (d->pW & 1);
+    PCW = (2 * (d->Wo - 1) - P2 + 16 + 7) / 8 * 8;
+    return R >= 1 && (int64_t)6 * PR * PCW * 2 <= kPPatchBytes;
+}
+
+extern "C" int ptx_conv_stem_x3p_supported(const ptx_conv3d_desc* d) {
+    if (!ptx_conv_stem_x3_supported(d)) return 0;
+    if (d->Ci > 3 || d->sW != 2 || d->Wi % 8 || d->kW > 7 || d->pW < 0 || d->pW + (d->pW & 1) > 8) return 0;
+    int R, PR, PCW, P2;
+    if (!stem_x3p_geometry(d, R, PR, PCW, P2)) return 0;
+    return (int64_t)d->N * d->Ti * 6 * d->Hi * d->Wi * 2 < 0x80000000LL;
+}
+
+extern "C" size_t ptx_stem_x3p_weight_elems(const ptx_conv3d_desc* d) {         // in floats (4-byte units)
+    if (!d || d->kT < 1 || d->kH < 1 || d->Co < 1) return 0;
+    const int w_tiles = cdiv((d->Co + 3) / 4 * 4, kStemBN);
+    return (size_t)d->kT * ((d->kH + 1) / 2) * w_tiles * (kPBTile / 4);
+}
+
+extern "C" int ptx_pack_stem_x3p_weight(const ptx_conv3d_desc* d, const float* w_x3, float* w_stem, ptx_stream_t stream) {
+    if (!d || !w_x3 || !w_stem) return fail(PTX_ERR_INVALID, "pack_stem_x3p_weight: null pointer");
+    if (!ptx_conv_stem_x3p_supported(d)) return fail(PTX_ERR_UNSUPPORTED, "pack_stem_x3p_weight: not a planar split-operand stem");
+    const int w_tiles = cdiv((d->Co + 3) / 4 * 4, kStemBN), NS = (d->kH + 1) / 2;
+    const long long total = (long long)ptx_stem_x3p_weight_elems(d) * 2;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, (long long)kNumCU * 16);
+    hipLaunchKernelGGL(pack_stem_x3p_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(w_x3),
+                       reinterpret_cast<_Float16*>(w_stem), d->kT, d->kH, d->kW, d->Co_pad, w_tiles, NS, d->pW & 1, total);
+    return hip_check(hipGetLastError(), "pack_stem_x3p_weight launch");
+}
+
+extern "C" int ptx_ncdhw_to_split_planes(const float* x, void* y, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, ptx_stream_t stream) {
+    if (!x || !y) return fail(PTX_ERR_INVALID, "ncdhw_to_split_planes: null pointer");
+    if (N <= 0 || C <= 0 || C > 3 || T <= 0 || H <= 0 || W <= 0 || W % 8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+        return fail(PTX_ERR_INVALID, "ncdhw_to_split_planes: 1..3 channels, W a multiple of 8, 16-byte aligned pointers");
+    const long long total = (long long)N * T * H * (W / 8);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, (long long)kNumCU * 32);
+    hipLaunchKernelGGL(ncdhw_to_split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, static_cast<_Float16*>(y), C, T, H, W / 8, total);
+    return hip_check(hipGetLastError(), "ncdhw_to_split_planes launch");
+}
+
+extern "C" int ptx_conv_stem_x3p_fwd(const ptx_conv3d_desc* d, const void* x, const float* w_stem, const float* bias, float* y,
+                                     ptx_stream_t stream) {
+    if (!d || !x || !w_stem || !y) return fail(PTX_ERR_INVALID, "conv_stem_x3p: null pointer");
+    if (((uintptr_t)x | (uintptr_t)w_stem | (uintptr_t)y) & 15) return fail(PTX_ERR_INVALID, "conv_stem_x3p: pointers must be 16-byte aligned");
+    if (!ptx_conv_stem_x3p_supported(d))
+        return fail(PTX_ERR_UNSUPPORTED, "conv_stem_x3p: needs a split-operand stem ptx_conv_stem_x3_fwd accepts with Ci <= 3, stride_w == 2, kW <= 7, "
+                    "an input width that is a multiple of 8 and a six-plane patch of at most %d bytes", kPPatchBytes);
+    if (d->ldy < d->Co || d->ldy % 4) return fail(PTX_ERR_INVALID, "conv_stem_x3p: bad output stride");
+    StemPArgs a{};
+    a.x = static_cast<const _Float16*>(x); a.w = reinterpret_cast<const _Float16*>(w_stem); a.bias = bias; a.y = y;
+    a.N = d->N; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.ldy = d->ldy;
+    a.ncol = (d->Co + 3) / 4 * 4;
+    a.kT = d->kT; a.kH = d->kH; a.sT = d->sT; a.sH = d->sH; a.pT = d->pT; a.pH = d->pH;
+    stem_x3p_geometry(d, a.R, a.PR, a.PCW, a.P2);
+    a.NS = (d->kH + 1) / 2;
+    a.h_tiles = cdiv(d->Ho, a.R);
+    a.n_tiles = d->N * d->To * a.h_tiles;
+    a.n_pieces = cdiv(6 * a.PR * (a.PCW / 8), 64);
+    a.w_tiles = cdiv(a.ncol, kStemBN);
+    a.flags = d->flags;
+    a.x_bytes = (unsigned)((uint64_t)d->N * d->Ti * 6 * d->Hi * d->Wi * 2ull);
+    a.w_bytes = (unsigned)(ptx_stem_x3p_weight_elems(d) * 4ull);
+    a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
+    fdiv_make((unsigned)d->Wo, a.dv_wo);
+    constexpr size_t lds = (size_t)(2 * kPPatchBytes + 2 * kPBTile);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)a.w_tiles);
+    hipLaunchKernelGGL(conv_stem_x3p_kernel, grid, dim3(kStemNT), lds, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "conv_stem_x3p launch");
 }

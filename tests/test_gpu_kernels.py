@@ -1280,7 +1280,10 @@ def test_conv_stem_x3_direct(ptx):
         (4, 1, 1, 28, 28, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
         (1, 3, 3, 224, 224, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),          # full 112-wide rows: R = 4 rows per workgroup
         (2, 3, 6, 21, 24, 64, (7, 7, 7), (2, 2, 2), "same"),               # TF-SAME (I3D Unit3D): front pad 2, back pad 3 / 2
+        (2, 3, 2, 40, 48, 110, (1, 7, 7), (1, 2, 2), (0, 3, 3)),           # planar: two channel tiles, one temporal tap
+        (1, 2, 3, 19, 32, 64, (3, 6, 5), (1, 1, 2), (1, 2, 2)),            # planar: even kH, 5-wide filter with an even pad, 2 channels
     ]
+    n_planar = 0
     for (N, Ci, T, H, W, Co, k, s_, p_) in cases:
         x = rnd(N, Ci, T, H, W, seed=80)
         w = rnd(Co, Ci, *k, seed=81, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5)
@@ -1328,6 +1331,31 @@ def test_conv_stem_x3_direct(ptx):
         assert err <= 2e-5, ((N, Ci, T, H, W, Co, k, s_), err)
         pad = yd[..., Co:ldy]
         assert pad.numel() == 0 or bool((pad == 0).all())
+        # the PLANAR kernel (six half planes per frame, 3 operands per filter row): same descriptor, same packed filter
+        # (re-laid by ptx_pack_stem_x3p_weight), same products in a different summation order
+        planar_ok = bool(lib.ptx_conv_stem_x3p_supported(C.byref(d)))
+        assert planar_ok == (Ci <= 3 and s_[2] == 2 and W % 8 == 0 and k[2] <= 7), (N, Ci, T, H, W, k, s_)
+        if planar_ok:
+            n_planar += 1
+            xpl = torch.full((N, T, 6, H, W), float("nan"), device=DEV, dtype=torch.float16)
+            L.check(lib.ptx_ncdhw_to_split_planes(_p(xsrc), C.c_void_p(xpl.data_ptr()), N, Ci, T, H, W, _st()), "split planes")
+            torch.cuda.synchronize()
+            pl = xpl.float().cpu()
+            back = (pl[:, :, :3] + pl[:, :, 3:] / 4096.0)[:, :, :Ci].permute(0, 2, 1, 3, 4)
+            assert (back - x).abs().max().item() <= 2.0 ** -21 * max(1.0, x.abs().max().item())
+            assert bool((pl[:, :, Ci:3] == 0).all()) and bool((pl[:, :, 3 + Ci:] == 0).all())
+            wq = torch.full((lib.ptx_stem_x3p_weight_elems(C.byref(d)),), float("nan"), device=DEV)
+            L.check(lib.ptx_pack_stem_x3p_weight(C.byref(d), _p(wp), _p(wq), _st()), "pack planar stem")
+            yq = torch.full((N, To, Ho, Wo, ldy), float("nan"), device=DEV)
+            L.check(lib.ptx_conv_stem_x3p_fwd(C.byref(d), C.c_void_p(xpl.data_ptr()), _p(wq), _p(bp), _p(yq), _st()), "stem x3 planar")
+            torch.cuda.synchronize()
+            assert not torch.isnan(wq).any()
+            gq = from_cl(yq, Co)
+            errq = (gq - want).abs().max().item() / max(1.0, want.abs().max().item())
+            assert errq <= 2e-5, ("planar", (N, Ci, T, H, W, Co, k, s_), errq)
+            padq = yq[..., Co:ldy]
+            assert padq.numel() == 0 or bool((padq == 0).all())
+    assert n_planar >= 3
     # refused, not mis-computed: fp32 operands, a 64-channel input, a 16-wide filter
     d.flags = L.PTX_EPI_RELU
     assert not lib.ptx_conv_stem_x3_supported(C.byref(d))
