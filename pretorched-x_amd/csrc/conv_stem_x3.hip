@@ -485,37 +485,38 @@ __global__ void __launch_bounds__(256) pack_stem_x3p_kernel(const _Float16* __re
     }
 }
 
-// fp32 [N][C][T][H][W] -> halfs [N][T][6][H][W]: planes c0 c1 c2 hi, c0 c1 c2 lo; 8 columns per thread
+// fp32 [N][C][T][H][W] -> halfs [N][T][6][H][W]: planes c0 c1 c2 hi, c0 c1 c2 lo.  A thread converts 8 columns of one row;
+// a block of 256 threads is TY rows x TX column groups (TX = the power of two >= W / 8), rows = (n, t, h) triples decoded with
+// 32-bit arithmetic (64-bit divisions per thread made the first version run at 2.9 TB/s)
 __global__ void __launch_bounds__(256) ncdhw_to_split_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int C, int T,
-                                                                    int H, int W8, long long total) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int w8 = (int)(i % W8);
-        long long t = i / W8;
-        const int h = (int)(t % H);
-        t /= H;
-        const int tt = (int)(t % T);
-        const long long n = t / T;
-        const size_t S = (size_t)T * H * W8 * 8;
+                                                                    int H, int W8, int rows, int tx_log2) {
+    const size_t plane = (size_t)H * W8 * 8, S = (size_t)T * plane;
+    const int tx = threadIdx.x & ((1 << tx_log2) - 1), ty = threadIdx.x >> tx_log2, TY = 256 >> tx_log2;
+    for (unsigned row = blockIdx.x * TY + ty; row < (unsigned)rows; row += gridDim.x * TY) {      // row = (n * T + t) * H + h
+        const unsigned nt = row / (unsigned)H, h = row - nt * (unsigned)H;
+        const unsigned n = nt / (unsigned)T, t = nt - n * (unsigned)T;
+        for (int w8 = tx; w8 < W8; w8 += 1 << tx_log2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            half8 hi, lo;
-            if (c < C) {
-                const float* xs = x + ((size_t)n * C + c) * S + ((size_t)tt * H + h) * W8 * 8 + (size_t)w8 * 8;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xs), v1 = *reinterpret_cast<const f32x4*>(xs + 4);
+            for (int c = 0; c < 3; ++c) {
+                half8 hi, lo;
+                if (c < C) {
+                    const float* xs = x + ((size_t)n * C + c) * S + (size_t)t * plane + ((size_t)h * W8 + w8) * 8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xs), v1 = *reinterpret_cast<const f32x4*>(xs + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = e < 4 ? v0[e] : v1[e - 4];
-                    const _Float16 hh = (_Float16)v;
-                    hi[e] = hh;
-                    lo[e] = (_Float16)((v - (float)hh) * 4096.f);      // scaled lo (conv_igemm.hip, X3)
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = e < 4 ? v0[e] : v1[e - 4];
+                        const _Float16 hh = (_Float16)v;
+                        hi[e] = hh;
+                        lo[e] = (_Float16)((v - (float)hh) * 4096.f);      // scaled lo (conv_igemm.hip, X3)
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }
+                _Float16* yp = y + ((size_t)nt * 6 + c) * plane + ((size_t)h * W8 + w8) * 8;
+                *reinterpret_cast<half8*>(yp) = hi;
+                *reinterpret_cast<half8*>(yp + 3 * plane) = lo;
             }
-            _Float16* yp = y + ((((size_t)n * T + tt) * 6 + c) * H + h) * W8 * 8 + (size_t)w8 * 8;
-            *reinterpret_cast<half8*>(yp) = hi;
-            *reinterpret_cast<half8*>(yp + (size_t)3 * H * W8 * 8) = lo;
         }
     }
 }
@@ -627,9 +628,14 @@ extern "C" int ptx_ncdhw_to_split_planes(const float* x, void* y, int32_t N, int
     if (!x || !y) return fail(PTX_ERR_INVALID, "ncdhw_to_split_planes: null pointer");
     if (N <= 0 || C <= 0 || C > 3 || T <= 0 || H <= 0 || W <= 0 || W % 8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
         return fail(PTX_ERR_INVALID, "ncdhw_to_split_planes: 1..3 channels, W a multiple of 8, 16-byte aligned pointers");
-    const long long total = (long long)N * T * H * (W / 8);
-    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, (long long)kNumCU * 32);
-    hipLaunchKernelGGL(ncdhw_to_split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, static_cast<_Float16*>(y), C, T, H, W / 8, total);
+    if ((int64_t)N * T * H > 0x7fffffffLL) return fail(PTX_ERR_INVALID, "ncdhw_to_split_planes: too many rows");
+    const int rows = N * T * H;
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < W / 8 && tx_log2 < 8) ++tx_log2;
+    const int TY = 256 >> tx_log2;
+    const unsigned blocks = (unsigned)std::min(cdiv(rows, TY), kNumCU * 32);
+    hipLaunchKernelGGL(ncdhw_to_split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, static_cast<_Float16*>(y), C, T, H, W / 8, rows,
+                       tx_log2);
     return hip_check(hipGetLastError(), "ncdhw_to_split_planes launch");
 }
 
