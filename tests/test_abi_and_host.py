@@ -521,6 +521,22 @@ def test_x3_precision_plan_wiring_without_gpu(ptx, monkeypatch):
     stem = [s for s in plan.steps if isinstance(s, engine.StemStep)][0]
     assert (stem.d.Kc, stem.d.ldx, stem.d.Ci, stem.d.kW) == (32, 4, 3, 7) and stem.label == "conv1"
     assert not any(getattr(s, "label", "") == "fold_kw" for s in plan.steps)
+    # round 4: RGB stems with stride_w == 2 run the PLANAR kernel (six half planes per frame, 3 operands per filter row)
+    assert stem.planar and any(getattr(s, "label", "") == "ncdhw_to_split_planes" for s in plan.steps)
+    assert lib.ptx_conv_stem_x3p_supported(C.byref(stem.d)) == 1
+    assert lib.ptx_stem_x3p_weight_elems(C.byref(stem.d)) == 7 * 4 * 1 * (3 * 64 * 64 // 4)      # kT x row pairs x channel tiles x 12 KiB
+    monkeypatch.setenv("PTX_STEM_X3P", "0")
+    old = eng.dry_plan(m, (2, 3, 16, 224, 224))
+    st_old = [s for s in old.steps if isinstance(s, engine.StemStep)][0]
+    assert not st_old.planar and any(getattr(s, "label", "") == "ncdhw_to_split4" for s in old.steps)
+    monkeypatch.delenv("PTX_STEM_X3P")
+    dq = L.ConvDesc()
+    for f, _ in L.ConvDesc._fields_:
+        setattr(dq, f, getattr(stem.d, f))
+    dq.Wi, dq.Wo = 220, 110                                   # width not a multiple of 8: 16-byte pieces would straddle the row end
+    assert lib.ptx_conv_stem_x3_supported(C.byref(dq)) == 1 and lib.ptx_conv_stem_x3p_supported(C.byref(dq)) == 0
+    dq.Wi, dq.Wo, dq.sW = 112, 112, 1                         # unit stride: a window would start on an odd half
+    assert lib.ptx_conv_stem_x3_supported(C.byref(dq)) == 1 and lib.ptx_conv_stem_x3p_supported(C.byref(dq)) == 0
     for s in plan.conv_steps:
         assert s.d.flags & L.PTX_F16X3_OPERANDS and s.d.Kc % 8 == 0, s.label
         assert lib.ptx_conv3d_config_name(s.cfg).decode().endswith("/x3"), s.label
