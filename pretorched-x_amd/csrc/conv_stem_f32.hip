@@ -40,6 +40,7 @@ struct StemF32Args {
     unsigned flags;
     unsigned x_bytes, w_bytes, y_bytes;
     unsigned dv_wo[2];
+    unsigned dv_plane4[2], dv_pc4[2];     // fast division by plane / 4 and PC / 4 (the prologue's patch-piece decode)
     // longest-first tile order inside an XCD's chunk (0 = plain order): output frames grouped by their number of valid
     // temporal taps, most taps first -- the workgroups that finish a launch are the short ones
     int lpt, n_classes, groups_per_xcd;
@@ -77,11 +78,28 @@ static inline void f32_fdiv_make(unsigned d, unsigned (&out)[2]) {
                                                          a_src[i_] == kOOB ? kOOB : a_src[i_] + fbase_, 0, 0, 0);      \
     } while (0)
 
+// Phase clock of a workgroup (diagnostic build only: scripts/micro/build_timeline.sh, -DPTX_STEM_TIMELINE; the product library
+// carries none of it): thread 0 writes the 100 MHz wall clock at 0 entry, 1 requests issued, 2 first patch landed, 3 last
+// step done, 5 stores retired; 6 = __smid().
+#ifdef PTX_STEM_TIMELINE
+__device__ unsigned long long* g_stem_tl = nullptr;
+#define PTX_STEM_TL(k)                                                                                                 \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && g_stem_tl)                                                                             \
+            g_stem_tl[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] =                                       \
+                (k) == 6 ? (unsigned long long)__smid() : (unsigned long long)wall_clock64();                          \
+    } while (0)
+#else
+#define PTX_STEM_TL(k) do {} while (0)
+#endif
+
 // NP: 16-byte patch pieces per thread (4, 8 or 12).  STAGE: the next frame's patch waits in registers (2 workgroups per CU);
 // else it is LDS-DMA'd at the frame change, exposed, and a third workgroup per CU covers the wait (<= 168 registers).
 template <int NP, bool STAGE>
 __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    PTX_STEM_TL(0);
+    PTX_STEM_TL(6);
     float* As = smem;                                   // [3 * plane]: the patch of the current temporal tap
     float* Bs = smem + 3 * p.plane;                     // [3][kF32BTile]: filter tiles of steps s, s + 1, s + 2
     constexpr unsigned kOOB = 0x80000000u;
@@ -118,13 +136,16 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
 
     // ---- per-thread sources of the patch pieces (frame independent): piece q = tid + 256 i of the three planes ----
     unsigned a_src[12];       // (sized 12, used to NP: a template-dependent extent here makes hipcc's host pass drop the kernel stub)
+    // (multiply-shift divisions: two plain integer divisions per piece were ~1000 VALU instructions per thread, and VALU
+    //  work shares the fp32 datapath with the co-resident workgroups' MFMAs -- the phase clock, scripts/gpu_stem_timeline.py,
+    //  showed 22 us of a 177-us workgroup life before the first request went out, 9.6 of 34 us on the (1,7,7) stem)
     const int pc4 = p.PC >> 2, plane4 = p.plane >> 2;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int q = tid + kF32NT * i;
-        const int c = q / plane4;                                     // (once per thread: plain divisions)
+        const int c = (int)f32_fdiv((unsigned)q, p.dv_plane4);
         const int rem = q - c * plane4;
-        const int pr = rem / pc4;
+        const int pr = (int)f32_fdiv((unsigned)rem, p.dv_pc4);
         const int h = h_base + pr, w = (rem - pr * pc4) * 4 + p.wbase;
         const bool ok = c < 3 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
         a_src[i] = ok ? (unsigned)((c * p.sc + h * p.pitch + w) * 4) : kOOB;
@@ -232,8 +253,10 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
         issue_b(0, kt_lo, 0);
         if (n_steps > 1) issue_b(1, kt_lo, 1);           // (kH >= 2)
         if (STAGE) store_patch();
+        PTX_STEM_TL(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        PTX_STEM_TL(2);
         asm volatile("; LDS reads stay below the barrier" : "+v"(a_base[0][0]), "+v"(a_base[1][0])::"memory");
 #pragma unroll
         for (int q = 0; q < 4; ++q) load_group(q, As, Bs + g * kF32BN + l32);
@@ -284,6 +307,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
 
     // ---- epilogue: bias (+ folded BN) + ReLU; lane = output channel, 16 rows per accumulator tile.  Outputs of a tile are
     // consecutive in (n, to, ho, wo) raster order, so the row index is arithmetic ----
+    PTX_STEM_TL(3);
     const bool relu = (p.flags & PTX_EPI_RELU) != 0;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const int m_frame = (n * p.To + to) * frame_out;
@@ -305,6 +329,10 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
             }
         }
     }
+#ifdef PTX_STEM_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PTX_STEM_TL(5);
+#endif
 }
 
 
@@ -364,6 +392,12 @@ static bool stem_f32_geom(const ptx_conv3d_desc* d, StemF32Geom* g) {
 }  // namespace ptx
 
 using namespace ptx;
+
+#ifdef PTX_STEM_TIMELINE
+extern "C" int ptx_stem_f32_timeline(void* buf) {  // diagnostic build only: 8 x u64 per workgroup, or NULL to switch off
+    return hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_stem_tl), &buf, sizeof(buf)), "ptx_stem_f32_timeline");
+}
+#endif
 
 extern "C" int ptx_conv_stem_f32_supported(const ptx_conv3d_desc* d, int64_t stride_n, int64_t stride_c, int64_t stride_t) {
     if (!d) return 0;
@@ -435,6 +469,8 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     a.w_bytes = (unsigned)(ptx_stem_f32_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
     f32_fdiv_make((unsigned)d->Wo, a.dv_wo);
+    f32_fdiv_make((unsigned)(a.plane / 4), a.dv_plane4);
+    f32_fdiv_make((unsigned)(a.PC / 4), a.dv_pc4);
     {
         const int groups = d->N * g.tiles_per_frame;
         static const bool lpt_env = !(getenv("PTX_STEM_F32_LPT") && atoi(getenv("PTX_STEM_F32_LPT")) == 0);

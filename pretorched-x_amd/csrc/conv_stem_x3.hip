@@ -270,7 +270,7 @@ struct StemPArgs {
     int h_tiles, n_tiles, n_pieces, w_tiles;
     unsigned flags;
     unsigned x_bytes, w_bytes, y_bytes;
-    unsigned dv_wo[2];
+    unsigned dv_wo[2], dv_pp[2], dv_pc8[2];     // fast division by Wo, by the pieces of a plane, by the pieces of a patch row
 };
 
 constexpr int kPPatchBytes = 49152;                    // one patch buffer
@@ -309,9 +309,9 @@ __global__ void __launch_bounds__(kStemNT) conv_stem_x3p_kernel(const StemPArgs 
 #pragma unroll
     for (int i = 0; i < kPPiecesPerWave; ++i) {
         const int q = (wave + kStemWaves * i) * 64 + lane;
-        const int pl = q / per_plane;
-        const int rem = q - pl * per_plane;
-        const int pr = rem / pc8;
+        const int pl = (int)fdiv((unsigned)q, p.dv_pp);        // (multiply-shift: prologue VALU work competes with the MFMAs of
+        const int rem = q - pl * per_plane;                   //  the CU's other waves, scripts/gpu_stem_timeline.py)
+        const int pr = (int)fdiv((unsigned)rem, p.dv_pc8);
         const int h = h_base + pr, w = (rem - pr * pc8) * 8 - 8;            // patch column 0 is input column -8
         const bool ok = pl < 6 && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
         a_src[i] = ok ? (unsigned)(((pl * p.Hi + h) * p.Wi + w) * 2) : kOOB;
@@ -663,6 +663,8 @@ extern "C" int ptx_conv_stem_x3p_fwd(const ptx_conv3d_desc* d, const void* x, co
     a.w_bytes = (unsigned)(ptx_stem_x3p_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)((uint64_t)d->N * d->To * d->Ho * d->Wo * d->ldy * 4ull);
     fdiv_make((unsigned)d->Wo, a.dv_wo);
+    fdiv_make((unsigned)(a.PR * (a.PCW / 8)), a.dv_pp);
+    fdiv_make((unsigned)(a.PCW / 8), a.dv_pc8);
     constexpr size_t lds = (size_t)(2 * kPPatchBytes + 2 * kPBTile);
     static bool attr_set[64] = {};
     int dev = 0;
