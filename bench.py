@@ -113,7 +113,9 @@ def timed_steps(run, total_units, steps, warmup, dev, sync):
     drives this very function under gloo with a stand-in forward.
     A step = one forward of this rank's units (+ the one all-gather of logits when N > 1).  `total_units`: units of
     the WHOLE job per step (weak scaling: units per GPU x N; strong scaling: the fixed global batch, shards may be ragged).
-    Returns (elapsed seconds, last step output, verify dict or None)."""
+    Returns (elapsed seconds [MAX over ranks], last step output, verify dict or None, per-rank timing dict): the MAX hides
+    WHICH rank was slow, so every rank's own time is all-gathered too -- {"ms_per_step": [rank 0 .. N-1], "min", "max",
+    "argmax_rank", "spread"} -- and a straggler in an 8-GPU run is visible in the line itself."""
     import torch.distributed as dist
     from pretorched_x_amd.parallel import gather_logits, verify_gather
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -140,10 +142,13 @@ def timed_steps(run, total_units, steps, warmup, dev, sync):
     sync()
     elapsed = time.perf_counter() - t0
     verify = None
+    per_rank = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [float(e.item()) for e in every]
+        elapsed = max(per_rank)
         local = run()
         if local.dim() == 2:
             verify = verify_gather(local, gather_logits(local, total=total_units))
@@ -152,93 +157,36 @@ def timed_steps(run, total_units, steps, warmup, dev, sync):
             flag = torch.tensor([int(verify["deterministic"])], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             verify["deterministic"] = bool(flag.item())
-    return elapsed, out, verify
+    ms = [1e3 * e / max(steps, 1) for e in per_rank]
+    rank_ms = {"ms_per_step": [round(v, 4) for v in ms], "min": round(min(ms), 4), "max": round(max(ms), 4),
+               "argmax_rank": int(max(range(len(ms)), key=lambda i: ms[i])),
+               "spread": round((max(ms) - min(ms)) / max(max(ms), 1e-12), 4)}
+    return elapsed, out, verify, rank_ms
 
 
 def self_launch(n):
     """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`.
     Fails loudly when the node has fewer than n GPUs (PTX_BENCH_BACKEND=gloo -- the functional check in which ranks share
     devices -- is exempt)."""
-    import socket
     import torch
     have = torch.cuda.device_count()
     if os.environ.get("PTX_BENCH_BACKEND", "nccl") == "nccl" and have < n:
         raise SystemExit("bench.py --gpus %d: this node has %d visible GPU(s); one rank per GPU is required "
                          "(PTX_BENCH_BACKEND=gloo runs a functional check with ranks sharing devices)" % (n, have))
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the agent binds its own free rendezvous port (c10d store on port 0) -- nothing is picked here and
+    # re-bound later; 127.0.0.1 because the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     sys.stderr.flush()
     os.execv(sys.executable, cmd)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--no-x3", action="store_true", help="skip the secondary split-precision (x3) leg")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5-fp32"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default, the headline): a fixed batch PER GPU; strong: BASELINE's global batch (cfg2 / cfg3: 8 "
-                         "clips, cfg4: 16) sharded over the ranks -- at 8 GPUs the headline batch leaves 1 clip per GPU")
-    args = ap.parse_args()
-
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU, RCCL) by re-executing under
-        # torch.distributed.run -- the same command line the driver uses.  The N = 1 path never gets here.
-        self_launch(args.gpus)
-
+def measure(args, scaling, world, rank, local, dev, backend, first=True):
+    """One bench line (a dict on rank 0, None elsewhere) for `scaling` in {"weak", "strong"}."""
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # PTX_BENCH_BACKEND=gloo: a functional check of the N > 1 branches on a box with FEWER GPUs than ranks (ranks share
-    # devices round-robin, collectives go through gloo) -- never a scaling figure; the line says so in `config.parallelism`
-    backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
-    if os.environ.get("PTX_BENCH_LAUNCH_CHECK") == "1":
-        # launcher check (runs without GPUs, tests/test_parallel_gloo.py): the ranks `--gpus N` started rendezvous over gloo,
-        # report who they are, rank 0 prints the line's launch-related fields, nothing is measured
-        if args.gpus != world:
-            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
-        if world > 1:
-            dist.init_process_group("gloo")
-        seen = [None] * world
-        me = {"rank": rank, "local_rank": local, "pid": os.getpid()}
-        if world > 1:
-            dist.all_gather_object(seen, me)
-            dist.barrier()
-        else:
-            seen = [me]
-        if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": {
-                "world_size": dist.get_world_size() if world > 1 else 1, "distinct_pids": len({r["pid"] for r in seen}),
-                "local_ranks": sorted(r["local_rank"] for r in seen)}}))
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    if backend != "nccl":
-        local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    if args.gpus != world:
-        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
     import pretorched_x_amd as ptx
     from pretorched_x_amd.parallel import broadcast_tuned_table
     from pretorched_x_amd.testing import synth_clips, synth_state_dict
@@ -259,11 +207,11 @@ def main():
     else:
         model, recipe, make, per_gpu, fwd, cpu_fn, unit, workload_label, sample_idx = other_workload(args.workload, rank)
         sd = synth_state_dict(model.state_dict(), 1234, **recipe)
-    x_cpu, total_units = local_batch(make, per_gpu, args.workload, args.scaling, world, rank)
+    x_cpu, total_units = local_batch(make, per_gpu, args.workload, scaling, world, rank)
     units_per_gpu = x_cpu.shape[0]                # this rank's share (strong scaling: may be ragged, may be 0 past the batch)
     if units_per_gpu == 0:
         raise SystemExit("--scaling strong: %d ranks for a %d-%s batch leaves rank %d without work" % (world, total_units, unit, rank))
-    if args.scaling == "strong":
+    if scaling == "strong":
         workload_label += " -- STRONG scaling: one %d-%s global batch sharded over %d GPU(s), %d on rank 0" % (
             total_units, unit[:-1], world, units_per_gpu)
     model.load_state_dict(sd)
@@ -274,7 +222,7 @@ def main():
 
     eng = model.engine()
     tuned_entries = None
-    if not args.no_autotune:
+    if not args.no_autotune and first:
         # tile configurations are timed on rank 0 ONLY and broadcast: N tuners running at once on one node
         # perturb each other's HIP-event timings, and every rank must launch the same kernels
         if rank == 0:
@@ -284,19 +232,27 @@ def main():
                 run()                              # first call compiles the plan and times untuned tiles
             torch.cuda.synchronize()
         if world > 1:
-            tuned_entries = broadcast_tuned_table(src=0)
+            # the other ranks sit in this broadcast while rank 0 tunes: the process group's timeout (PTX_BENCH_TIMEOUT,
+            # default 1800 s) bounds that wait; say WHAT was being waited for instead of a bare collective timeout
+            try:
+                tuned_entries = broadcast_tuned_table(src=0)
+            except Exception as e:     # noqa: BLE001
+                raise SystemExit("bench.py rank %d: the broadcast of rank 0's tuned tile table failed or timed out after "
+                                 "PTX_BENCH_TIMEOUT=%ss -- rank 0's autotune outlasted the other ranks' wait (raise the "
+                                 "timeout or pass --no-autotune): %s" % (rank, os.environ.get("PTX_BENCH_TIMEOUT", "1800"), e))
             eng.invalidate()                       # plans pick their tiles at compile time: recompile with the table
         if headline and rank == 0 and os.environ.get("PTX_TUNED_OUT"):
             from pretorched_x_amd.engine import save_tuned_table
             save_tuned_table(os.environ["PTX_TUNED_OUT"])
 
-    elapsed, out, verify = timed_steps(run, total_units, args.steps, args.warmup, dev, torch.cuda.synchronize)
-    ranks_seen = None
+    elapsed, out, verify, rank_ms = timed_steps(run, total_units, args.steps, args.warmup, dev, torch.cuda.synchronize)
+    me = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
+          "name": torch.cuda.get_device_name(local), "pid": os.getpid(), "plan_builds": eng.plan_builds}
+    ranks_seen = {"world_size": 1, "device_count": torch.cuda.device_count(), "distinct_devices": 1, "ranks": [me],
+                  "tuned_entries_broadcast": None}
     if world > 1:
         seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
-                                      "name": torch.cuda.get_device_name(local), "pid": os.getpid(),
-                                      "plan_builds": eng.plan_builds})
+        dist.all_gather_object(seen, me)
         ranks_seen = {"world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(),
                       "distinct_devices": len({r["device"] for r in seen}), "ranks": seen,
                       "tuned_entries_broadcast": tuned_entries}
@@ -440,8 +396,15 @@ def main():
         roofline_longest["label"] = ll[0]
         gflop_per_unit = GFLOP_PER_CLIP if headline else sum(2e-9 * r[1] for r in rows + stem_rows) / plan.shape[0]
         net_tf = gflop_per_unit * 1e9 * clips_per_s / world / 1e12
+        # `frac` prices padding taps as work (SURVEY.md 8d's convention: layer4's T = 1 3x3x3 convs then "run" above the
+        # peak); `issued_frac` is its twin on the FLOP the MFMA instructions of one step really issue (pruned tap planes
+        # excluded, tile / K padding included: engine.issued_conv_flop, the stem's issued_flop) over the same step time
+        issued_step = sum(t.issued_flop() for t in plan.all_convs() if hasattr(t, "issued_flop"))
+        issued_tf = issued_step / (ms_per_step * 1e-3) / 1e12 if f16 is False else None
         roofline_net = {"bound": "mfma", "achieved": round(net_tf, 2), "peak": peak_tf,
                         "unit": "TFLOP/s", "frac": round(net_tf / peak_tf, 4),
+                        "issued_gflop_per_step": round(issued_step / 1e9, 3) if issued_tf is not None else None,
+                        "issued_frac": round(issued_tf / peak_tf, 4) if issued_tf is not None else None,
                         "conv_ms_sum": round(conv_ms, 3),
                         "per_kernel": {k: {"ms": round(v["ms"], 3), "tflops": round(v["flop"] / v["ms"] / 1e9, 1),
                                            "launches": v["launches"]} for k, v in sorted(by_kernel.items())}}
@@ -471,7 +434,7 @@ def main():
                       "max_abs_logit": float(want.abs().max().item()),
                       "argmax_equal": bool(torch.equal(got.argmax(1), want.argmax(1))) if got.dim() == 2 else None,
                       "tolerance": tolerance, "scope": "rank 0's shard (%d %s) vs the CPU oracle" % (xs.shape[0], unit)}
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
+        if not args.no_cpu_baseline and world == 1 and first:      # reported at N = 1 only (bench contract)
             ncpu = os.cpu_count() or 1
             # bounded sample: the full batch for config 2, at most 2 units for the heavier configurations
             idx = sample_indices()
@@ -514,7 +477,7 @@ def main():
         # the headline with its own |d output| vs the CPU path and its own denominator (the fp16 dense MFMA peak / 3
         # issued MFMAs per algorithmic product); the headline `value` above stays the plain fp32-MFMA path.
         split = None
-        if world == 1 and not f16 and args.workload != "cfg5-fp32" and not args.no_x3:
+        if world == 1 and first and not f16 and args.workload != "cfg5-fp32" and not args.no_x3:
             eng.precision = "x3"
             if not args.no_autotune:
                 if headline or (os.environ.get("PTX_FULL_TUNE") == "1" and fwd is None):
@@ -587,7 +550,7 @@ def main():
                        "%s/sec, %s (+ max|d output| vs CPU)" % (unit, args.workload)),
             "value": round(clips_per_s, 2), "unit": "%s/s" % unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
             "config": {"workload": workload_label,
                        "clips_per_gpu": units_per_gpu, "global_batch": total_units,
                        "parallelism": "clip-parallel x%d, one all-gather of logits" % world +
@@ -600,8 +563,85 @@ def main():
             "commit": os.environ.get("PTX_COMMIT"),
             # which sources the loaded libptx_amd.so was compiled from, and whether that is this tree (build.py stamps it)
             "binary": {"version": ptx._lib.lib().ptx_version().decode(), "source_sha256_matches_tree": ptx._lib.binary_source_hash() == ptx._lib.source_hash()},
-            "distributed_check": verify, "ranks_seen": ranks_seen,
+            "distributed_check": verify, "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms,
         }
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  Default: the launcher's WORLD_SIZE when there is one, else 1; an explicit value "
+                         "that disagrees with the launcher is an error")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-x3", action="store_true", help="skip the secondary split-precision (x3) leg")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5-fp32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+                    help="weak (default, the headline): a fixed batch PER GPU; strong: BASELINE's global batch (cfg2 / cfg3: 8 "
+                         "clips, cfg4: 16) sharded over the ranks -- at 8 GPUs the headline batch leaves 1 clip per GPU; "
+                         "both: the weak line, then the strong line, in one invocation")
+    args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU, RCCL) by re-executing under
+        # torch.distributed.run -- the same command line the driver uses.  The N = 1 path never gets here.
+        self_launch(args.gpus)
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PTX_BENCH_BACKEND=gloo: a functional check of the N > 1 branches on a box with FEWER GPUs than ranks (ranks share
+    # devices round-robin, collectives go through gloo) -- never a scaling figure; the line says so in `config.parallelism`
+    backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
+    if os.environ.get("PTX_BENCH_LAUNCH_CHECK") == "1":
+        # launcher check (runs without GPUs, tests/test_parallel_gloo.py): the ranks `--gpus N` started rendezvous over gloo,
+        # report who they are, rank 0 prints the line's launch-related fields, nothing is measured
+        if args.gpus != world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = [None] * world
+        me = {"rank": rank, "local_rank": local, "pid": os.getpid()}
+        if world > 1:
+            dist.all_gather_object(seen, me)
+            dist.barrier()
+        else:
+            seen = [me]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": {
+                "world_size": dist.get_world_size() if world > 1 else 1, "distinct_pids": len({r["pid"] for r in seen}),
+                "local_ranks": sorted(r["local_rank"] for r in seen)}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("PTX_BENCH_TIMEOUT", "1800")))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
+        else:
+            dist.init_process_group(backend, timeout=pg_timeout)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    results = []
+    for i, scaling in enumerate(["weak", "strong"] if args.scaling == "both" else [args.scaling]):
+        # --scaling both: the weak line (the headline), then the strong one, from the same ranks in one invocation; the
+        # second pass reuses the first's tuned tiles and skips the N = 1 extras (CPU baseline timing, split-operand leg)
+        results.append(measure(args, scaling, world, rank, local, dev, backend, first=(i == 0)))
     if rank == 0 and os.environ.get("PTX_TUNED_OUT"):      # tile choices of this run (both legs), for tuned_gfx950.json
         from pretorched_x_amd.engine import save_tuned_table
         save_tuned_table(os.environ["PTX_TUNED_OUT"])
@@ -609,7 +649,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        for result in results:
+            print(json.dumps(result))
 
 
 if __name__ == "__main__":

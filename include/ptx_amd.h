@@ -185,6 +185,59 @@ int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tai
                          const float* bias, const float* w2_packed, const float* bias2, const float* res, float* y,
                          int config, ptx_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Conv PROGRAM: an ordered list of fp32 convolutions (bias / ReLU / same-shape residual epilogues, optional second source)
+ * executed by ONE persistent launch -- the small-M tail of a video ResNet, where a launch per conv is bound by tile
+ * quantisation on 256 CUs and per-launch ramps rather than by the matrix cores.  Replaces the op sequence of whole
+ * bottlenecks:  conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu, block after block
+ * (resnet3D.py:125-143 with shortcut B :175-185; the six factored GEMMs of a (2+1)D bottleneck, r2plus1d.py:68-88).
+ * The tiles of all stages sit on one queue in stage order; persistent workgroups take them in order and a tile waits only for
+ * the ROW TILES of the producing stages it reads (per-row-tile completion counters), so consecutive stages overlap and no grid
+ * barrier exists -- the launch completes for any grid size (csrc/conv_program.hip).  Arithmetic and k-order are those of
+ * ptx_conv3d_fwd on the same tile and split: results are bit-identical to the stage-by-stage launches.
+ *   stage.tile     index into ptx_conv_program_tile_name (the tile shapes compiled into the program kernel), < 0: library's pick
+ *   stage.split_k  <= 0: library's pick.  Split-K stages reduce in-launch (last arriver, split order).
+ * Rules: every stage writes its own buffer (no reuse inside a program); a stage that reads an earlier stage's output reads
+ * it with the producer's row stride; flags other than PTX_EPI_RELU | PTX_EPI_RES_ADD, grouped and fp16 / split-operand convs
+ * are refused (PTX_ERR_UNSUPPORTED: keep those as their own launches).
+ * Use: ptx_conv_program_plan (sizes) -> allocate `workspace_bytes` of device workspace (256-byte aligned) and `image_bytes`
+ * of host + device memory -> ptx_conv_program_build fills the HOST image (it embeds the stage pointers and workspace
+ * addresses) -> copy it to the device once -> ptx_conv_program_fwd per forward (asynchronous; one memset node + one kernel).
+ * ptx_conv_program_error synchronises the stream and reads the program's error word (a dependency wait that ran out of
+ * polls -- a bug or a wedged device, never a data-dependent condition): code4 = {code, waiting stage, queue index, producer}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_conv_stage {
+    ptx_conv3d_desc desc;
+    const float* x;          /* input  (may be an earlier stage's y)                         */
+    const float* x2;         /* second source (ptx_conv3d_dual_fwd semantics) or NULL        */
+    const float* w_packed;
+    const float* bias;       /* or NULL                                                      */
+    const float* res;        /* PTX_EPI_RES_ADD operand (may be an earlier stage's y) or NULL */
+    float* y;
+    int32_t tile;
+    int32_t split_k;
+} ptx_conv_stage;
+
+typedef struct ptx_conv_program_info {
+    int32_t n_stages, total_items;   /* queue length = sum over stages of tiles x splits              */
+    int32_t ctrl_words;              /* 32-bit words at the head of the workspace zeroed per launch   */
+    int32_t lds_bytes;               /* dynamic LDS of the program kernel                             */
+    int32_t launches_replaced;       /* conv + split-K reduce launches the program stands for         */
+    int32_t reserved;
+    uint64_t image_bytes, workspace_bytes;
+} ptx_conv_program_info;
+
+int ptx_conv_program_num_tiles(void);
+const char* ptx_conv_program_tile_name(int tile);
+int ptx_conv_program_plan(const ptx_conv_stage* stages, int32_t n, ptx_conv_program_info* info);
+/* the plan as text, one line per stage: tile, split, tiles, halo rows, producers ("<stage>:x|res|x2") -- host only */
+int ptx_conv_program_describe(const ptx_conv_stage* stages, int32_t n, char* text, size_t text_bytes);
+int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, void* workspace, size_t workspace_bytes,
+                           void* image_host, size_t image_bytes, ptx_conv_program_info* info);
+int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
+                         ptx_stream_t stream);
+int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream);
+
 /* Small-Cin STEM convolution with split operands (PTX_F16X3_OPERANDS), read straight from a channels-last input whose
  * positions are 16 bytes (Ci <= 4, ldx == 4) -- `conv1` of the ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D
  * stems, the (1,7,7) spatial stem of R2Plus1D (r2plus1d.py:73-88).  A workgroup stages the input patch of one temporal

@@ -21,6 +21,8 @@ from . import _lib
 from ._lib import PtxError
 from .engine import Engine, relation_mlp
 from . import transforms  # noqa: F401
+from . import models, utils  # noqa: F401  (utils.Identity: README.md:543-546; models.Identity: models/__init__.py:79)
+from .adopt import accelerate  # noqa: F401
 from .biggan import BigGANDeepGenerator, biggan_deep  # noqa: F401
 from .i3d import InceptionI3d, i3d  # noqa: F401
 from . import slowfast  # noqa: F401  (reference: `from .models import slowfast`, pretorched/__init__.py:83)
@@ -191,6 +193,33 @@ def nonlocalresnet3d50(num_classes=339, num_nonlocal_blocks=5, pretrained="kinet
     return model
 
 
+def _nonlocal_factory(name, block, layers):
+    def factory(**kwargs):
+        """reference nonlocalnet.py:524-577: `NonLocalResNet3D(block, layers, **kwargs)` -- `nonlocal_layers` is a REQUIRED
+        constructor argument these factories do not supply, so a bare call raises TypeError upstream and
+        here; with `nonlocal_layers=[...]` (and optionally shortcut_type='A', num_classes=339) it builds, as upstream."""
+        if "nonlocal_layers" not in kwargs:
+            raise TypeError("NonLocalResNet3D.__init__() missing 1 required positional argument: 'nonlocal_layers'")
+        nl = tuple(int(v) for v in kwargs.pop("nonlocal_layers"))
+        shortcut_type = kwargs.pop("shortcut_type", "A")
+        num_classes = kwargs.pop("num_classes", 339)
+        if kwargs:
+            raise TypeError("NonLocalResNet3D.__init__() got an unexpected keyword argument %r" % sorted(kwargs)[0])
+        if len(nl) != 4:
+            raise IndexError("list index out of range")       # what `nonlocal_layers[3]` raises upstream (nonlocalnet.py:443)
+        key = "%s/nl%s" % (name, "-".join(str(v) for v in nl))
+        if key not in ARCHS:
+            ARCHS[key] = Arch(block, layers, "A", nonlocal_layers=nl)
+        return _build(key, num_classes, shortcut_type)
+    factory.__name__ = name
+    return factory
+
+
+nonlocalresnet3d18 = _nonlocal_factory("nonlocalresnet3d18", "basic", (2, 2, 2, 2))
+nonlocalresnet3d34 = _nonlocal_factory("nonlocalresnet3d34", "basic", (3, 4, 6, 3))
+nonlocalresnet3d101 = _nonlocal_factory("nonlocalresnet3d101", "bottleneck", (3, 4, 23, 3))
+
+
 def _r2plus1d_factory(name):
     def factory(num_classes=339, shortcut_type="B"):
         return _build(name, num_classes, shortcut_type)
@@ -324,7 +353,8 @@ def trn(num_classes=339, num_segments=8, consensus="MSTRN", arch="resnet50", pre
 
 
 model_names = ["resnet3d10", "resnet3d18", "resnet3d34", "resnet3d50", "resnet3d101", "resnet3d152",
-               "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "r2plus1d10", "r2plus1d18",
+               "resnet3d200", "resneti3d50", "nonlocalresnet3d50", "nonlocalresnet3d18", "nonlocalresnet3d34",
+               "nonlocalresnet3d101", "r2plus1d10", "r2plus1d18",
                "r2plus1d34", "r2plus1d50", "nonlocal_r2plus1d50", "resnet18", "resnet34", "resnet50",
                "resnet101", "resnet152", "trn", "i3d", "resnext3d10", "resnext3d18", "resnext3d34", "resnext3d50",
                "resnext3d101", "resnext3d152", "resnext3d200", "wideresnet3d50", "preact_resnet3d10", "preact_resnet3d18", "preact_resnet3d34",

@@ -46,6 +46,19 @@ class ConvDesc(C.Structure):
         return tuple((getattr(self, f) & ~0x10000) if f == "flags" else getattr(self, f) for f, _ in self._fields_)
 
 
+class ConvStage(C.Structure):
+    """ptx_conv_stage: one convolution of a conv program (ptx_conv_program_*)."""
+    _fields_ = [("desc", ConvDesc), ("x", C.c_void_p), ("x2", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("res", C.c_void_p), ("y", C.c_void_p), ("tile", C.c_int32), ("split_k", C.c_int32)]
+
+
+class ConvProgramInfo(C.Structure):
+    """ptx_conv_program_info: sizes of a planned / built conv program."""
+    _fields_ = [("n_stages", C.c_int32), ("total_items", C.c_int32), ("ctrl_words", C.c_int32), ("lds_bytes", C.c_int32),
+                ("launches_replaced", C.c_int32), ("reserved", C.c_int32), ("image_bytes", C.c_uint64),
+                ("workspace_bytes", C.c_uint64)]
+
+
 class ConvFusedExt(C.Structure):
     """ptx_conv_fused_ext: operands of the fused generator-stage epilogue."""
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("ld_affine", C.c_int32), ("ld_raw", C.c_int32),
@@ -126,6 +139,13 @@ SIGNATURES = {
     "ptx_conv3d_chain_supported": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int]),
     "ptx_conv3d_chain_pick_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "ptx_conv3d_chain_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "ptx_conv_program_num_tiles": (C.c_int, []),
+    "ptx_conv_program_tile_name": (C.c_char_p, [C.c_int]),
+    "ptx_conv_program_plan": (C.c_int, [C.POINTER(ConvStage), _I, C.POINTER(ConvProgramInfo)]),
+    "ptx_conv_program_describe": (C.c_int, [C.POINTER(ConvStage), _I, C.c_char_p, _Z]),
+    "ptx_conv_program_build": (C.c_int, [C.POINTER(ConvStage), _I, _P, _Z, _P, _Z, C.POINTER(ConvProgramInfo)]),
+    "ptx_conv_program_fwd": (C.c_int, [C.POINTER(ConvProgramInfo), _P, _P, _I, _P]),
+    "ptx_conv_program_error": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     "ptx_ncdhw_to_split4": (C.c_int, [_P, _P, _I, _I, _L, _P]),
     "ptx_conv_stem_x3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "ptx_conv_stem_x3_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),

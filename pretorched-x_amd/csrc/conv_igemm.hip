@@ -677,23 +677,19 @@ extern "C" size_t ptx_conv3d_workspace_bytes(const ptx_conv3d_desc* d, int split
 }
 
 namespace ptx {
-int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
-                hipStream_t st) {
-    const ConvConfig& c = kConfigs[config];
-    if ((a.f16 != 0) != c.f16)
-        return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16-operand problems run on the /f16 tile configurations only (and vice versa)");
-    if ((a.x3 != 0) != c.x3)
-        return fail(PTX_ERR_UNSUPPORTED, "conv3d: split-operand problems run on the /x3 tile configurations only (and vice versa)");
-    if (c.kwr) {
-        if (a.kW != c.kwr || a.sW != 1 || a.dual || batch > 1 || a.groups > 1 || a.Wo < 8 || c.BM % a.Wo ||
+// Tile-dependent half of the kernel arguments (tile counts, K chunks, split, extents): shared by the plain launch below and
+// by conv_program.hip, which runs the same tile bodies from a persistent workgroup.
+int finalize_conv_args(ConvArgs& a, int BM, int BN, int BK, int kwr, bool direct, int split_k, int batch) {
+    if (kwr) {
+        if (a.kW != kwr || a.sW != 1 || a.dual || batch > 1 || a.groups > 1 || a.Wo < 8 || BM % a.Wo ||
             a.Wo != a.Wi + 2 * a.pW - a.kW + 1)
             return fail(PTX_ERR_UNSUPPORTED, "conv3d: a kw-reuse tile needs a dense %d-wide stride-1 filter and a %d-row tile made of "
-                        "whole output rows (Wo = %d >= 8)", c.kwr, c.BM, a.Wo);
-        fastdiv_make((unsigned)(a.Wo + c.kwr - 1), a.dv_hw);
+                        "whole output rows (Wo = %d >= 8)", kwr, BM, a.Wo);
+        fastdiv_make((unsigned)(a.Wo + kwr - 1), a.dv_hw);
     }
-    if (a.groups > 1 && !c.direct && (a.cog % c.BN || a.dual || batch > 1))
+    if (a.groups > 1 && !direct && (a.cog % BN || a.dual || batch > 1))
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: an MFMA tile must divide the %d output channels of a group", a.cog);
-    a.m_tiles = cdiv(a.M, c.BM);
+    a.m_tiles = cdiv(a.M, BM);
     fastdiv_make((unsigned)a.Wo, a.dv_wo);      // every launch path (conv, dual, batched GEMM) decodes rows with these
     fastdiv_make((unsigned)a.Ho, a.dv_ho);
     fastdiv_make((unsigned)a.To, a.dv_to);
@@ -703,20 +699,20 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
         const int plane = a.Ho * a.Wo;
         const int64_t in_clip_bytes = (int64_t)a.Ti * a.Hi * a.Wi * a.ldx * 4;
         // worth it only when one clip's input exceeds the per-XCD L2 (4 MiB) and the filter spans frames
-        a.tiles_per_plane = (t_inner && a.kT > 1 && a.To > 1 && plane % c.BM == 0 && in_clip_bytes > (8 << 20))
-                                ? plane / c.BM : 0;
+        a.tiles_per_plane = (t_inner && a.kT > 1 && a.To > 1 && plane % BM == 0 && in_clip_bytes > (8 << 20))
+                                ? plane / BM : 0;
     }
     a.ncol = (a.Co + 3) / 4 * 4;
-    a.n_tiles = cdiv(a.ncol, c.BN);
-    a.kchunks = cdiv(std::max(a.kA, a.kB), c.BK);
+    a.n_tiles = cdiv(a.ncol, BN);
+    a.kchunks = cdiv(std::max(a.kA, a.kB), BK);
     if (a.dual) {
-        a.kc1 = cdiv(a.kA, c.BK);
-        a.kchunks = a.kc1 + cdiv(a.kA2, c.BK);
+        a.kc1 = cdiv(a.kA, BK);
+        a.kchunks = a.kc1 + cdiv(a.kA2, BK);
     }
     const int steps_total = a.kT * a.kH * a.kW * a.kchunks;
     if (split_k < 1) split_k = 1;
     if (split_k > steps_total) split_k = steps_total;
-    if (batch > 1 || c.direct) split_k = 1;
+    if (batch > 1 || direct) split_k = 1;
     a.split_k = split_k;
     {
         const uint64_t yb = (uint64_t)a.M * a.ldy * ((a.flags & PTX_EPI_OUT_F16) ? 2ull : 4ull);
@@ -740,6 +736,21 @@ int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace
     a.counters = nullptr;
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
                         a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && !a.up2) ? 1 : 0;
+    return PTX_OK;
+}
+
+int launch_conv(ConvArgs& a, int config, int split_k, int batch, void* workspace, size_t workspace_bytes,
+                hipStream_t st) {
+    const ConvConfig& c = kConfigs[config];
+    if ((a.f16 != 0) != c.f16)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: fp16-operand problems run on the /f16 tile configurations only (and vice versa)");
+    if ((a.x3 != 0) != c.x3)
+        return fail(PTX_ERR_UNSUPPORTED, "conv3d: split-operand problems run on the /x3 tile configurations only (and vice versa)");
+    {
+        const int fs = finalize_conv_args(a, c.BM, c.BN, c.BK, c.kwr, c.direct, split_k, batch);
+        if (fs != PTX_OK) return fs;
+        split_k = a.split_k;
+    }
     bool fused_reduce = false;
     if (split_k > 1) {
         const size_t head = (a.flags & PTX_SPLITK_FUSED) ? kCounterBytes : 0;
@@ -787,9 +798,11 @@ int linear_gemm(const float* x, const float* w, const float* b, float* y, int M,
 }
 }  // namespace ptx
 
-static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed,
-                         const float* bias, const float* res, float* y, void* workspace, size_t workspace_bytes,
-                         int config, int split_k, ptx_stream_t stream, const ptx_conv_fused_ext* ext = nullptr) {
+namespace ptx {
+// Descriptor + tensors -> the tile-independent half of the kernel arguments (validation included).  Shared by every conv
+// entry point here and by conv_program.hip.
+int make_conv_args(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed, const float* bias,
+                   const float* res, float* y, const ptx_conv_fused_ext* ext, ConvArgs& a) {
     int s = validate_desc(d);
     if (s != PTX_OK) return s;
     if ((d->flags & (PTX_EPI_AFFINE | PTX_EPI_DUAL_RAW)) && !ext)
@@ -797,15 +810,8 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
     if (!x || !w_packed || !y) return fail(PTX_ERR_INVALID, "conv3d: null tensor pointer");
     if ((d->flags & (PTX_EPI_RES_ADD | PTX_EPI_RES_PADA)) && !res)
         return fail(PTX_ERR_INVALID, "conv3d: residual flag set but res == NULL");
-    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)res | (uintptr_t)workspace) & 15)
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)res) & 15)
         return fail(PTX_ERR_INVALID, "conv3d: pointers must be 16-byte aligned");
-    if (config >= kNumConfigs) return fail(PTX_ERR_INVALID, "conv3d: config %d out of range", config);
-    if (config < 0) {
-        int sk = 1;
-        config = ptx_conv3d_pick_config(d, &sk);
-        if (split_k <= 0) split_k = sk;
-    }
-    if (split_k <= 0) split_k = 1;
     if (d->flags & PTX_PRO_RELU)
         return fail(PTX_ERR_UNSUPPORTED, "conv3d: PTX_PRO_RELU is only implemented by ptx_linear_fwd");
     if (d->flags & PTX_EPI_RES_ADD) {
@@ -827,7 +833,7 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
             return fail(PTX_ERR_INVALID, "conv3d: shortcut-A residual geometry out of range");
         }
     }
-    ConvArgs a{};
+    a = ConvArgs{};
     a.x = x; a.w = w_packed; a.bias = bias; a.res = res; a.y = y;
     a.N = d->N; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx; a.kA = d->ldx;
     a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy; a.k_live = d->Ci;
@@ -908,6 +914,24 @@ static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* 
         a.w_bytes = (unsigned)((uint64_t)d->Co_pad * a.ldw * 4ull);
         a.k_live = d->Ci + d->x2_C;
     }
+    return PTX_OK;
+}
+}  // namespace ptx
+
+static int conv3d_common(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed,
+                         const float* bias, const float* res, float* y, void* workspace, size_t workspace_bytes,
+                         int config, int split_k, ptx_stream_t stream, const ptx_conv_fused_ext* ext = nullptr) {
+    ConvArgs a;
+    const int s = make_conv_args(d, x, x2, w_packed, bias, res, y, ext, a);
+    if (s != PTX_OK) return s;
+    if ((uintptr_t)workspace & 15) return fail(PTX_ERR_INVALID, "conv3d: pointers must be 16-byte aligned");
+    if (config >= kNumConfigs) return fail(PTX_ERR_INVALID, "conv3d: config %d out of range", config);
+    if (config < 0) {
+        int sk = 1;
+        config = ptx_conv3d_pick_config(d, &sk);
+        if (split_k <= 0) split_k = sk;
+    }
+    if (split_k <= 0) split_k = 1;
     return launch_conv(a, config, split_k, 1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

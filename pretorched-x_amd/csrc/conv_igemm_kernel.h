@@ -395,7 +395,7 @@ struct RowEpi {
     static_assert(WTN % 4 == 0 && 64 % LPR == 0 && LPR <= 64, "wave tile width");
 };
 
-template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+template <class MF, int TM, int TN, int WTM, int WTN, int MT, int COH = 0>
 __device__ __forceinline__ void rowmajor_load_residual(f32x4* res4 /* [TM][NP] */, const __amdgpu_buffer_rsrc_t rs_r,
                                                        bool has_res, int mbase, int co_base, int M, int ncol, int ldr, int lane) {
     using RE = RowEpi<WTN, MT>;
@@ -409,11 +409,11 @@ __device__ __forceinline__ void rowmajor_load_residual(f32x4* res4 /* [TM][NP] *
             const int m = mbase + i * MT + row;
             const bool ok = has_res && row < MT && m < M && co4 < ncol;
             const unsigned off = ((unsigned)m * (unsigned)ldr + (unsigned)co4) * 4u;
-            res4[i * RE::NP + ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? off : kOOB, 0, 0));
+            res4[i * RE::NP + ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? off : kOOB, 0, COH));
         }
 }
 
-template <class MF, int TM, int TN, int WTM, int WTN, int MT>
+template <class MF, int TM, int TN, int WTM, int WTN, int MT, int COH = 0>
 __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM][TN], const f32x4* res4 /* [TM][NP] */,
                                                     float* Ls, const float* bias, const __amdgpu_buffer_rsrc_t rs_y, bool relu,
                                                     int mbase, int co_base, int M, int ncol, int ldy, int lane) {
@@ -441,7 +441,7 @@ __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             const unsigned off = ((unsigned)m * (unsigned)ldy + (unsigned)co4) * 4u;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_y,
-                                                   ok ? off : kOOB, 0, 0);
+                                                   ok ? off : kOOB, 0, COH);
         }
     }
 }
@@ -496,9 +496,17 @@ static __device__ unsigned long long* g_ig_tl = nullptr;
 #define PTX_IG_TL_END() do {} while (0)
 #endif
 
+// The body of one workgroup's tile.  `tile` = m_tile * n_tiles + n_tile, `zb` the batched-GEMM item, `zs` the split-K slice,
+// `smem` the workgroup's dynamic LDS.  conv_igemm_kernel (one tile per workgroup, below) and conv_program_kernel
+// (conv_program.hip: a persistent workgroup walking a queue of tiles of SEVERAL convs in one launch) both run it.
+// COH: cache-policy bits (`aux`) of every access to data ANOTHER workgroup of the same launch may have produced or will
+// consume -- activation / residual loads, output and split-K partial stores.  0 for a plain launch; 16 (sc1: L1 bypass on
+// loads, write-through on stores) inside a conv program, whose stages hand tensors to each other without a kernel boundary
+// (cdna_hip_programming.md Guideline 16: sc1 stores + drained flag on the producer, sc1 loads on the consumer).
+// Filters and biases are read-only for the whole launch and keep the default policy.
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
-__global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
+          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false, int COH = 0>
+__device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const int tile, const int zb, const int zs, float* smem) {
     PTX_IG_TL(0);
     PTX_IG_TL(6);
     static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
@@ -543,7 +551,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         return (DMA ? (ps ^ ((row >> SWS) & (F4R - 1))) : ps) * 4;
     };
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [NSTAGE][AR][LDK]
     float* Bs = smem + NSTAGE * ASTG;        // [NSTAGE][KW_T][BN][LDK]
 
@@ -552,7 +559,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
     const int n_tile = tile % p.n_tiles;
     int m_tile = tile / p.n_tiles;
     if (p.tiles_per_plane > 0) {
@@ -564,8 +570,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         m_tile = c * clip_tiles + (r % p.To) * p.tiles_per_plane + r / p.To;
     }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int zb = blockIdx.y;
-    const int zs = blockIdx.z;
 
     // grouped conv: this N tile lies inside one group and reads only that group's input columns
     const float* __restrict__ xg = p.x + (size_t)zb * p.bs_x + (p.groups > 1 ? (n0 / p.cog) * p.cig : 0);
@@ -791,9 +795,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                     // wave-uniform LDS destination: this wave's 1-KiB chunk of the tile image
                     if ((A_F4 % NT == 0) || (wave_u * 64 + NT * i < A_F4))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rs, (lds_ptr_t)(As + dbuf * ASTG + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, 0);
+                            rs, (lds_ptr_t)(As + dbuf * ASTG + (wave_u * 64 + NT * i) * 4), 16, ok ? off : kOOB, 0, 0, COH);
                 } else {
-                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, 0));
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, COH));
                 }
             }
         };
@@ -877,7 +881,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             const int m = mrow + MF::row(r, lane);
             const unsigned off = ((unsigned)m * (unsigned)p.ldr + (unsigned)co) * 4u;
             rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                        rsrc_r, (res_add && co < p.ncol && m < p.M) ? off : kOOB, 0, 0));
+                                                        rsrc_r, (res_add && co < p.ncol && m < p.M) ? off : kOOB, 0, COH));
         }
     };
     // (REPI tiles fetch the residual row-major in their own epilogue; the column-wise prefetch only serves the paths that
@@ -1401,13 +1405,13 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
             using RE = RowEpi<WTN, MT>;
             const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)zb * p.bs_y, 0, p.y_bytes, 0x00020000);
             f32x4 res4[TM * RE::NP];
-            rowmajor_load_residual<MF, TM, TN, WTM, WTN, MT>(res4, rsrc_r, res_add, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol, p.ldr, lane);
+            rowmajor_load_residual<MF, TM, TN, WTM, WTN, MT, COH>(res4, rsrc_r, res_add, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol, p.ldr, lane);
             // every wave is done with the operand tiles and the trailing (zero-writing) DMAs have landed: the tile buffers
             // become the waves' parking slices
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * RE::NP) : "memory");      // (the residual loads just issued may stay in flight)
             __syncthreads();
             PTX_IG_TL(4);
-            rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT>(acc, res4, smem + wave_u * RE::FLOATS, p.bias, rs_y,
+            rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT, COH>(acc, res4, smem + wave_u * RE::FLOATS, p.bias, rs_y,
                                                           (p.flags & PTX_EPI_RELU) != 0, m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol,
                                                           p.ldy, lane);
             PTX_IG_TL_END();
@@ -1448,7 +1452,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
                 v = relu ? fmaxf(v, 0.f) : v;
                 const unsigned off = ((unsigned)m * ldo + (unsigned)co) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y,
-                                                      (co_ok && m < p.M) ? off : kOOB, 0, 0);
+                                                      (co_ok && m < p.M) ? off : kOOB, 0, COH);
             }
         }
     }
@@ -1491,7 +1495,20 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     }
 }
 
+// one tile per workgroup: the plain launch
+template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
+          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false>
+__global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_igemm_tile<BM, BN, BK, WM, WN, MT, KTAIL, K22, DMA, NSTAGE, F16, X3, KWR, CHAIN, REPI, 0>(
+        p, xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles), (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
 // conv_igemm.hip: descriptor validation shared by every conv entry point
 int validate_desc(const ptx_conv3d_desc* d);
+// conv_igemm.hip: descriptor + tensors -> kernel arguments (tile-independent half), then the tile-dependent half
+int make_conv_args(const ptx_conv3d_desc* d, const float* x, const float* x2, const float* w_packed, const float* bias,
+                   const float* res, float* y, const ptx_conv_fused_ext* ext, ConvArgs& a);
+int finalize_conv_args(ConvArgs& a, int BM, int BN, int BK, int kwr, bool direct, int split_k, int batch);
 
 }  // namespace ptx

@@ -1,0 +1,482 @@
+// conv_program.hip -- SEVERAL convolutions in ONE persistent launch (libptx_amd, gfx950).
+//
+// Why.  The tail of a video ResNet is a chain of small-M convolutions: layer3 / layer4 of resnet3d50 at 8 x 16 x 224^2 have
+// M = 3136 / 392 output rows, the (2+1)D bottlenecks of config 3 M = 1568 / 256 -- six GEMMs per bottleneck of 0.1-4 GFLOP
+// each (resnet3D.py:125-143, r2plus1d.py:68-88).  As one launch per conv they are bound by what happens AROUND the MFMAs:
+// 196 tiles on 256 CUs leave 60 CUs idle for the whole launch, 392 tiles run as two rounds (1.53 -> 2), the smallest launches
+// take 7.5 us for 1.6 us of matrix work (profiles/r04_rows_cfg3.txt: 58 launches, 1.17 ms, 21-57 TF).
+//
+// What.  A conv PROGRAM is an ordered list of convolutions ("stages") whose tiles are put on ONE work queue, stage after
+// stage, row tile after row tile.  conv_program_kernel is launched once with 1-3 persistent 256-thread workgroups per CU; each
+// workgroup repeatedly (1) takes the next queue index with one returning agent-scope atomicAdd, (2) waits until the row
+// tiles of the producing stages that its tile reads are complete -- per-(stage, row tile) completion counters, polled by
+// one wave with relaxed sc1 loads -- (3) runs the SAME tile body a plain launch would (conv_igemm_tile, conv_igemm_kernel.h)
+// with write-through (sc1) output stores and L1-bypassing (sc1) activation / residual loads, (4) drains its stores and bumps
+// the completion counter of its row tile.  There is no grid barrier: a workgroup that runs out of tiles of stage s starts
+// on stage s + 1 wherever the rows it needs are done, so the partial last round of every stage overlaps the next stage's
+// first, and stages that do not depend on each other (a bottleneck's shortcut conv and its conv1 -> conv2 chain) interleave.
+// Split-K stages keep one fp32 partial slab per split IN THEIR OWN workspace region (stages overlap in time) and a ticket
+// per tile; the last arriver sums the slabs in split order -- the order of splitk_reduce_kernel, so the result is
+// bit-identical to the unfused launches -- applies bias / residual / ReLU and publishes.
+//
+// Progress.  A queue index's dependencies are tiles of EARLIER stages, i.e. smaller queue indices; indices are handed out in
+// order, so the smallest unfinished index is always held by a running workgroup whose dependencies are complete: the
+// launch finishes for any grid size and any residency -- nothing here needs co-residency, unlike a grid barrier.  Every spin
+// is bounded all the same (PTX_PROG_SPIN_LIMIT polls, ~seconds): on expiry the workgroup sets the error word, every other
+// workgroup sees it and leaves; ptx_conv_program_error reports it.
+//
+// Visibility (cdna_hip_programming.md Guideline 16, R1): payload stores carry sc1 (write-through), every storing wave
+// drains (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane bumps the counter with a relaxed agent-scope atomic; the
+// consumer polls that word relaxed and then reads the payload with sc1 loads.  Correctness never depends on which XCD a
+// workgroup runs on.  All polled words are zeroed by a memset node ahead of EVERY launch (ptx_conv_program_fwd).
+#include "conv_igemm_kernel.h"
+
+namespace ptx {
+
+constexpr int kProgMaxDeps = 4;
+constexpr int kProgMaxStages = 256;
+constexpr int kProgCtrlHead = 16;          // ctrl words [0] queue head, [1] error code, [2] error stage; counters from word 16
+constexpr int kCoh = 16;                   // sc1
+
+struct ProgDep {
+    int stage;        // producing stage
+    int kind;         // 0: this conv's input x (rows through stride / halo), 1: same rows (residual), 2: strided second source x2
+    int bm;           // rows per row tile of the producer
+    int mtiles;       // its row tiles
+    int done_off;     // ctrl word of its first row-tile counter
+    int target;       // completions per row tile = its N tiles
+};
+
+struct ProgStage {
+    ConvArgs a;
+    int cfg;          // tile shape (kProgTiles index)
+    int bm, bn;
+    int item_begin, items;
+    int done_off;     // ctrl word of this stage's first row-tile counter
+    int tick_off;     // ctrl word of its first split-K ticket (one per tile), -1 without split-K
+    int halo_lo, halo_hi, rows_in;
+    int ndeps;
+    ProgDep deps[kProgMaxDeps];
+};
+
+struct ProgTileShape { int BM, BN, BK; const char* name; };
+static const ProgTileShape kProgTiles[] = {
+    {32, 64, 64, "32x64x64/2x2/m16/dma/re"},
+    {32, 128, 32, "32x128x32/2x2/m16/dma/re"},
+    {32, 64, 32, "32x64x32/2x2/m16/dma/re"},
+};
+constexpr int kNumProgTiles = sizeof(kProgTiles) / sizeof(kProgTiles[0]);
+constexpr int kProgTileLds = 2 * (32 + 64) * 64 * 4;        // the largest tile image (bytes): 32x64x64, two stages
+constexpr int kProgLdsCtrlFloats = 16;
+constexpr int kProgLdsBytes = kProgTileLds + kProgLdsCtrlFloats * 4;
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ unsigned ld_relaxed(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// input row (position index of the tensor a conv reads) under the centre tap of output row m
+__device__ __forceinline__ int prog_in_row(int m, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int sT, int sH, int sW) {
+    const int wo = m % Wo;
+    int t = m / Wo;
+    const int ho = t % Ho;
+    t /= Ho;
+    const int to = t % To;
+    const int n = t / To;
+    return ((n * Ti + to * sT) * Hi + ho * sH) * Wi + wo * sW;
+}
+
+// last arriver of a split-K tile: y = epilogue(sum of the partial tiles in split order)
+__device__ __forceinline__ void prog_reduce_tile(const ConvArgs& p, int BM, int BN, int tile, int tid) {
+    constexpr unsigned kOOB = 0x80000000u;
+    const int m0 = (tile / p.n_tiles) * BM, n0 = (tile % p.n_tiles) * BN;
+    const size_t slab = (size_t)p.M * p.ncol;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((size_t)p.M * p.ldy * 4), 0x00020000);
+    const bool has_res = (p.flags & PTX_EPI_RES_ADD) != 0;
+    const __amdgpu_buffer_rsrc_t rs_r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, has_res ? p.r_bytes : 0u, 0x00020000);
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+#pragma unroll 1
+    for (int e = tid * 4; e < BM * BN; e += 256 * 4) {
+        const int m = m0 + e / BN, co = n0 + e % BN;
+        const bool ok = co < p.ncol && m < p.M;
+        const unsigned poff = ok ? (unsigned)(((size_t)m * p.ncol + co) * 4) : kOOB;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int z = 0; z < p.split_k; ++z) {
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)z * slab, 0, p.y_bytes, 0x00020000);
+            const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, poff, 0, kCoh));
+            v = z == 0 ? u : v + u;
+        }
+        if (p.bias && ok) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+        const f32x4 r = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (ok && has_res) ? (unsigned)(((size_t)m * p.ldr + co) * 4) : kOOB, 0, kCoh));
+        v += r;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_y,
+                                               ok ? (unsigned)(((size_t)m * p.ldy + co) * 4) : kOOB, 0, kCoh);
+    }
+}
+
+#define PTX_PROG_TILE(BM, BN, BK) \
+    conv_igemm_tile<BM, BN, BK, 2, 2, 16, true, false, true, 2, false, false, 0, false, true, kCoh>
+
+__global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __restrict__ stages, const int* __restrict__ item_begin,
+                                                          const int n_stages, const int total_items, unsigned* ctrl,
+                                                          const unsigned spin_limit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    volatile int* lc = reinterpret_cast<volatile int*>(smem + kProgTileLds / 4);      // [0] item, [1] stage, [2] flag
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* const head = ctrl;
+    unsigned* const err = ctrl + 1;
+    for (;;) {
+        if (tid == 0) lc[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(lc[0]);
+        if (item >= total_items) break;
+        if (tid < n_stages) {
+            if (item >= item_begin[tid] && item < item_begin[tid + 1]) lc[1] = tid;
+        }
+        __syncthreads();
+        const int s = __builtin_amdgcn_readfirstlane(lc[1]);
+        const ProgStage* const S = stages + s;
+        const ConvArgs p = S->a;                          // by value: registers, immune to the stores below
+        const int li = item - S->item_begin;
+        const int split = p.split_k;
+        const int zs = li % split, tile = li / split;
+        const int m_tile = tile / p.n_tiles;
+        const int bm = S->bm;
+        // ---- wait for the producers' row tiles this tile reads (one wave polls, relaxed)
+        if (wave == 0) {
+            const int m0 = m_tile * bm, m1 = min(m0 + bm, p.M) - 1;
+            int bad = 0;
+            const int nd = S->ndeps;
+            for (int d = 0; d < nd && !bad; ++d) {
+                const ProgDep dep = S->deps[d];
+                int lo, hi;
+                if (dep.kind == 0) {
+                    lo = prog_in_row(m0, p.To, p.Ho, p.Wo, p.Ti, p.Hi, p.Wi, p.sT, p.sH, p.sW) - S->halo_lo;
+                    hi = prog_in_row(m1, p.To, p.Ho, p.Wo, p.Ti, p.Hi, p.Wi, p.sT, p.sH, p.sW) + S->halo_hi;
+                } else if (dep.kind == 1) {
+                    lo = m0;
+                    hi = m1;
+                } else {
+                    lo = prog_in_row(m0, p.To, p.Ho, p.Wo, p.T2, p.H2, p.W2, p.s2T, p.s2H, p.s2W);
+                    hi = prog_in_row(m1, p.To, p.Ho, p.Wo, p.T2, p.H2, p.W2, p.s2T, p.s2H, p.s2W);
+                }
+                const int t_lo = max(lo, 0) / dep.bm, t_hi = min(hi / dep.bm, dep.mtiles - 1);
+                const unsigned* cnt = ctrl + dep.done_off;
+                for (int base = t_lo; base <= t_hi && !bad; base += 64) {
+                    const int idx = base + lane;
+                    unsigned spins = 0;
+                    for (;;) {
+                        const unsigned v = idx <= t_hi ? ld_relaxed(cnt + idx) : (unsigned)dep.target;
+                        if (__all(v >= (unsigned)dep.target)) break;
+                        ++spins;
+                        if ((spins & 63u) == 0u && ld_relaxed(err) != 0u) { bad = 1; break; }
+                        if (spins > spin_limit) {
+                            if (lane == 0) {
+                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(ctrl + 2, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(ctrl + 3, (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(ctrl + 4, (unsigned)dep.stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            bad = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+            if (lane == 0) lc[2] = bad;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(lc[2])) break;
+        // ---- the tile
+        switch (S->cfg) {
+            case 0: PTX_PROG_TILE(32, 64, 64)(p, tile, 0, zs, smem); break;
+            case 1: PTX_PROG_TILE(32, 128, 32)(p, tile, 0, zs, smem); break;
+            default: PTX_PROG_TILE(32, 64, 32)(p, tile, 0, zs, smem); break;
+        }
+        // ---- publish: every storing wave drains its write-through stores, then one lane counts
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (split > 1) {
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(ctrl + S->tick_off + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lc[2] = t == (unsigned)split - 1u ? 1 : 0;
+            }
+            __syncthreads();
+            if (!__builtin_amdgcn_readfirstlane(lc[2])) continue;
+            prog_reduce_tile(p, bm, S->bn, tile, tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (tid == 0) __hip_atomic_fetch_add(ctrl + S->done_off + m_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static bool overlaps(const void* a, size_t na, const void* b, size_t nb) {
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a && b && na && nb && a0 < b0 + nb && b0 < a0 + na;
+}
+
+struct HostStage {
+    ConvArgs a;
+    int cfg, split;
+    size_t x_span, x2_span, res_span, y_span;      // bytes
+};
+
+// Shared front end of plan / build: arguments of every stage, tile + split choices, dependencies, the queue.
+static int prog_prepare(const ptx_conv_stage* st, int n, std::vector<ProgStage>& out, std::vector<int>& item_begin,
+                        ptx_conv_program_info* info, size_t* slab_bytes_out) {
+    if (!st || n <= 0 || n > kProgMaxStages) return fail(PTX_ERR_INVALID, "conv_program: 1..%d stages", kProgMaxStages);
+    std::vector<HostStage> hs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const ptx_conv3d_desc* d = &st[i].desc;
+        const unsigned allowed = PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_SPLITK_FUSED;
+        if (d->flags & ~allowed)
+            return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d: only fp32 convs with bias / ReLU / same-shape residual (flags 0x%x)", i, d->flags);
+        if (d->groups > 1) return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d: grouped convs keep their own launch", i);
+        ptx_conv3d_desc dd = *d;
+        dd.flags &= ~PTX_SPLITK_FUSED;
+        HostStage& h = hs[(size_t)i];
+        int s = make_conv_args(&dd, st[i].x, st[i].x2, st[i].w_packed, st[i].bias, st[i].res, st[i].y, nullptr, h.a);
+        if (s != PTX_OK) return s;
+        h.cfg = st[i].tile;
+        if (h.cfg >= kNumProgTiles) return fail(PTX_ERR_INVALID, "conv_program: stage %d: tile %d out of range", i, h.cfg);
+        const int ncol = (d->Co + 3) / 4 * 4;
+        const int K = std::max(h.a.kA, h.a.kB);
+        if (h.cfg < 0) {
+            // defaults (the tuner's picks on the small-M problems of layer3 / layer4): 64-deep K steps for long K, 128-wide
+            // N tiles when that still leaves a round of tiles, 32-deep steps for short K tails
+            const int mt = cdiv(h.a.M, 32);
+            if (K % 64 && K < 256) h.cfg = 2;
+            else if (ncol % 128 == 0 && mt * (ncol / 128) >= kNumCU) h.cfg = 1;
+            else h.cfg = 0;
+        }
+        const ProgTileShape& t = kProgTiles[h.cfg];
+        int split = st[i].split_k;
+        const int tiles = cdiv(h.a.M, t.BM) * cdiv(ncol, t.BN);
+        const int steps = d->kT * d->kH * d->kW * (cdiv(h.a.kA, t.BK) + (h.a.dual ? cdiv(h.a.kA2, t.BK) : 0));
+        if (split <= 0) {
+            // enough queue items per stage to keep `target` workgroups per CU busy while the stage is the frontier, as long
+            // as a split keeps `min_steps` k-steps (PTX_PROG_TARGET_ITEMS / PTX_PROG_MIN_STEPS: tuning knobs, read per plan)
+            const char* e1 = getenv("PTX_PROG_TARGET_ITEMS");
+            const char* e2 = getenv("PTX_PROG_MIN_STEPS");
+            const int target = e1 ? std::max(1, atoi(e1)) : 2 * kNumCU;
+            const int min_steps = e2 ? std::max(1, atoi(e2)) : 8;
+            split = 1;
+            if (tiles < target) {
+                split = cdiv(target, tiles);
+                if (split > 8) split = 8;
+                while (split > 1 && steps / split < min_steps) --split;
+            }
+        }
+        s = finalize_conv_args(h.a, t.BM, t.BN, t.BK, 0, false, split, 1);
+        if (s != PTX_OK) return s;
+        h.split = h.a.split_k;
+        h.a.tiles_per_plane = 0;
+        h.x_span = (size_t)h.a.x_bytes;
+        h.x2_span = h.a.dual ? (size_t)h.a.x2_bytes : 0;
+        h.res_span = (h.a.flags & PTX_EPI_RES_ADD) ? (size_t)h.a.M * h.a.ldr * 4 : 0;
+        h.y_span = (size_t)h.a.M * h.a.ldy * 4;
+        if ((int64_t)h.a.m_tiles * h.a.n_tiles * h.split > (1 << 24)) return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d is not a small-M conv", i);
+    }
+    // ---- dependencies: the latest earlier stage(s) whose output a stage reads.  A stage that would overwrite what an
+    // earlier stage reads or writes (buffer reuse inside one program) cannot be ordered by read-after-write counters alone.
+    out.assign((size_t)n, ProgStage{});
+    item_begin.assign((size_t)n + 1, 0);
+    int done_words = 0, tick_words = 0;
+    size_t slab_bytes = 0;
+    for (int j = 0; j < n; ++j) {
+        HostStage& h = hs[(size_t)j];
+        ProgStage& P = out[(size_t)j];
+        const ProgTileShape& t = kProgTiles[h.cfg];
+        P.a = h.a;
+        P.cfg = h.cfg;
+        P.bm = t.BM;
+        P.bn = t.BN;
+        P.items = h.a.m_tiles * h.a.n_tiles * h.split;
+        item_begin[(size_t)j + 1] = item_begin[(size_t)j] + P.items;
+        P.item_begin = item_begin[(size_t)j];
+        P.done_off = kProgCtrlHead + done_words;
+        done_words += h.a.m_tiles;
+        P.halo_lo = (h.a.pT * h.a.Hi + h.a.pH) * h.a.Wi + h.a.pW;
+        P.halo_hi = ((h.a.kT - 1 - h.a.pT) * h.a.Hi + (h.a.kH - 1 - h.a.pH)) * h.a.Wi + (h.a.kW - 1 - h.a.pW);
+        if (P.halo_lo < 0) P.halo_lo = 0;
+        if (P.halo_hi < 0) P.halo_hi = 0;
+        P.rows_in = h.a.N * h.a.Ti * h.a.Hi * h.a.Wi;
+        P.ndeps = 0;
+        for (int i = 0; i < j; ++i) {
+            const HostStage& e = hs[(size_t)i];
+            if (overlaps(h.a.y, h.y_span, e.a.y, e.y_span) || overlaps(h.a.y, h.y_span, e.a.x, e.x_span) ||
+                overlaps(h.a.y, h.y_span, e.a.x2, e.x2_span) || overlaps(h.a.y, h.y_span, e.a.res, e.res_span))
+                return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d writes a buffer stage %d reads or writes (every stage needs its own output)", j, i);
+        }
+        struct Src { const float* p; size_t span; int kind; int ld; };
+        const Src srcs[3] = {{h.a.x, h.x_span, 0, h.a.ldx}, {h.a.res, h.res_span, 1, h.a.ldr}, {h.a.x2, h.x2_span, 2, h.a.ldx2}};
+        for (const Src& sc : srcs) {
+            if (!sc.p || !sc.span) continue;
+            for (int i = j - 1; i >= 0; --i) {
+                const HostStage& e = hs[(size_t)i];
+                if (!overlaps(sc.p, sc.span, e.a.y, e.y_span)) continue;
+                // the consumer must index the producer's rows as the producer wrote them: same row stride, starting inside row 0
+                const ptrdiff_t off = (const char*)sc.p - (const char*)e.a.y;
+                if (sc.ld != e.a.ldy || off < 0 || off >= (ptrdiff_t)e.a.ldy * 4)
+                    return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d reads stage %d's output through another row layout", j, i);
+                if (P.ndeps == kProgMaxDeps) return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d has more than %d producers", j, kProgMaxDeps);
+                const int rows = sc.kind == 0 ? P.rows_in : sc.kind == 1 ? h.a.M : h.a.N * h.a.T2 * h.a.H2 * h.a.W2;
+                if (rows != e.a.M)
+                    return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d reads %d rows of stage %d's %d", j, rows, i, e.a.M);
+                ProgDep& dp = P.deps[P.ndeps++];
+                dp.stage = i;
+                dp.kind = sc.kind;
+                dp.bm = kProgTiles[e.cfg].BM;
+                dp.mtiles = e.a.m_tiles;
+                dp.done_off = out[(size_t)i].done_off;
+                dp.target = e.a.n_tiles;
+                // keep looking: a channel-concatenated tensor has several producers
+            }
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        HostStage& h = hs[(size_t)j];
+        ProgStage& P = out[(size_t)j];
+        P.tick_off = -1;
+        if (h.split > 1) {
+            P.tick_off = kProgCtrlHead + done_words + tick_words;
+            tick_words += h.a.m_tiles * h.a.n_tiles;
+            slab_bytes += (((size_t)h.split * h.a.M * h.a.ncol * 4) + 255) / 256 * 256;
+        }
+    }
+    if (info) {
+        info->n_stages = n;
+        info->total_items = item_begin[(size_t)n];
+        info->ctrl_words = (kProgCtrlHead + done_words + tick_words + 63) / 64 * 64;
+        info->lds_bytes = kProgLdsBytes;
+        info->image_bytes = (uint64_t)n * sizeof(ProgStage) + ((uint64_t)n + 1) * sizeof(int);
+        info->image_bytes = (info->image_bytes + 15) / 16 * 16;
+        info->workspace_bytes = (uint64_t)info->ctrl_words * 4 + slab_bytes;
+        int split_stages = 0;
+        for (int j = 0; j < n; ++j) split_stages += hs[(size_t)j].split > 1;
+        info->launches_replaced = n + split_stages;
+    }
+    if (slab_bytes_out) *slab_bytes_out = slab_bytes;
+    return PTX_OK;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_conv_program_num_tiles(void) { return kNumProgTiles; }
+
+extern "C" const char* ptx_conv_program_tile_name(int tile) {
+    return (tile >= 0 && tile < kNumProgTiles) ? kProgTiles[tile].name : "";
+}
+
+extern "C" int ptx_conv_program_plan(const ptx_conv_stage* stages, int32_t n, ptx_conv_program_info* info) {
+    if (!info) return fail(PTX_ERR_INVALID, "conv_program: info == NULL");
+    std::vector<ProgStage> ps;
+    std::vector<int> ib;
+    return prog_prepare(stages, n, ps, ib, info, nullptr);
+}
+
+extern "C" int ptx_conv_program_describe(const ptx_conv_stage* stages, int32_t n, char* text, size_t text_bytes) {
+    if (!text || !text_bytes) return fail(PTX_ERR_INVALID, "conv_program_describe: no buffer");
+    std::vector<ProgStage> ps;
+    std::vector<int> ib;
+    ptx_conv_program_info info{};
+    const int s = prog_prepare(stages, n, ps, ib, &info, nullptr);
+    if (s != PTX_OK) return s;
+    size_t pos = 0;
+    auto put = [&](const char* fmt, auto... a) {
+        if (pos < text_bytes) {
+            const int k = snprintf(text + pos, text_bytes - pos, fmt, a...);
+            if (k > 0) pos += (size_t)k;
+        }
+    };
+    put("items %d ctrl_words %d workspace %llu\n", info.total_items, info.ctrl_words, (unsigned long long)info.workspace_bytes);
+    for (int j = 0; j < n; ++j) {
+        const ProgStage& P = ps[(size_t)j];
+        put("stage %d tile %s split %d m_tiles %d n_tiles %d items %d halo %d %d deps", j, kProgTiles[P.cfg].name, P.a.split_k,
+            P.a.m_tiles, P.a.n_tiles, P.items, P.halo_lo, P.halo_hi);
+        for (int d = 0; d < P.ndeps; ++d) put(" %d:%s", P.deps[d].stage, P.deps[d].kind == 0 ? "x" : P.deps[d].kind == 1 ? "res" : "x2");
+        put("%s", "\n");
+    }
+    if (pos >= text_bytes) return fail(PTX_ERR_INVALID, "conv_program_describe: %zu bytes do not hold the description", text_bytes);
+    return PTX_OK;
+}
+
+extern "C" int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, void* workspace, size_t workspace_bytes,
+                                      void* image_host, size_t image_bytes, ptx_conv_program_info* info) {
+    if (!info || !image_host) return fail(PTX_ERR_INVALID, "conv_program: null info / image");
+    std::vector<ProgStage> ps;
+    std::vector<int> ib;
+    size_t slab = 0;
+    int s = prog_prepare(stages, n, ps, ib, info, &slab);
+    if (s != PTX_OK) return s;
+    if (image_bytes < info->image_bytes) return fail(PTX_ERR_INVALID, "conv_program: image buffer of %zu bytes, need %llu", image_bytes, (unsigned long long)info->image_bytes);
+    if (!workspace || ((uintptr_t)workspace & 255) || workspace_bytes < info->workspace_bytes)
+        return fail(PTX_ERR_WORKSPACE, "conv_program: needs %llu bytes of 256-byte aligned workspace, got %zu",
+                    (unsigned long long)info->workspace_bytes, workspace_bytes);
+    char* slabs = static_cast<char*>(workspace) + (size_t)info->ctrl_words * 4;
+    for (int j = 0; j < n; ++j) {
+        ProgStage& P = ps[(size_t)j];
+        if (P.a.split_k > 1) {
+            P.a.partial = reinterpret_cast<float*>(slabs);
+            slabs += (((size_t)P.a.split_k * P.a.M * P.a.ncol * 4) + 255) / 256 * 256;
+        }
+    }
+    std::memset(image_host, 0, (size_t)info->image_bytes);
+    std::memcpy(image_host, ps.data(), (size_t)n * sizeof(ProgStage));
+    std::memcpy(static_cast<char*>(image_host) + (size_t)n * sizeof(ProgStage), ib.data(), ((size_t)n + 1) * sizeof(int));
+    return PTX_OK;
+}
+
+extern "C" int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace,
+                                    int32_t wgs_per_cu, ptx_stream_t stream) {
+    if (!info || !image_dev || !workspace) return fail(PTX_ERR_INVALID, "conv_program: null argument");
+    if (info->n_stages <= 0 || info->n_stages > kProgMaxStages || info->total_items <= 0)
+        return fail(PTX_ERR_INVALID, "conv_program: info does not describe a built program");
+    if (wgs_per_cu <= 0) wgs_per_cu = 2;
+    if (wgs_per_cu > 3) wgs_per_cu = 3;
+    hipStream_t st = (hipStream_t)stream;
+    static unsigned spin_limit = 0;
+    if (!spin_limit) {
+        const char* e = getenv("PTX_PROG_SPIN_LIMIT");
+        spin_limit = e ? (unsigned)strtoul(e, nullptr, 10) : 4000000u;
+        if (!spin_limit) spin_limit = 1;
+    }
+    auto kern = conv_program_kernel;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kProgLdsBytes));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    PTX_HIP(hipMemsetAsync(workspace, 0, (size_t)info->ctrl_words * 4, st));
+    const ProgStage* stages = static_cast<const ProgStage*>(image_dev);
+    const int* item_begin = reinterpret_cast<const int*>(static_cast<const char*>(image_dev) + (size_t)info->n_stages * sizeof(ProgStage));
+    int grid = wgs_per_cu * kNumCU;
+    if (grid > info->total_items) grid = info->total_items;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), kProgLdsBytes, st, stages, item_begin, (int)info->n_stages,
+                       (int)info->total_items, static_cast<unsigned*>(workspace), spin_limit);
+    return hip_check(hipGetLastError(), "conv_program launch");
+}
+
+extern "C" int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream) {
+    if (!workspace || !code4) return fail(PTX_ERR_INVALID, "conv_program_error: null argument");
+    unsigned w[8] = {};
+    PTX_HIP(hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PTX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    code4[0] = (int32_t)w[1];      // 0 = ok, 1 = a dependency wait ran out of polls
+    code4[1] = (int32_t)w[2];      // waiting stage
+    code4[2] = (int32_t)w[3];      // its queue index
+    code4[3] = (int32_t)w[4];      // the producing stage it waited for
+    return PTX_OK;
+}

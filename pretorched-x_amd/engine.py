@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ConvDesc, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
+from ._lib import (ConvDesc, ConvStage, ConvProgramInfo, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
                    PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_F16X3_OPERANDS, PTX_SPLITK_FUSED, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
 _TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
@@ -388,10 +388,55 @@ class PackedDual:
                   "ptx_pack_conv_weight (dual)")
 
 
+def _tile_dims(name):
+    """(BM, BN, BK) of an MFMA tile configuration name ("32x64x64/2x2/m16/dma/re"), or None for the direct (VALU) tiles."""
+    import re
+    m = re.match(r"^(\d+)x(\d+)x(\d+)/", name)
+    return None if (m is None or "direct" in name) else tuple(int(v) for v in m.groups())
+
+
+def issued_conv_flop(d, tile, words=1):
+    """FLOP of the MFMA instructions one implicit-GEMM launch ISSUES (what SQ_INSTS_MFMA counts), as opposed to the
+    algorithmic 2 x MACs that price every padding tap as work: per M tile the kernel walks the (kt, kh)
+    planes that are inside the image for AT LEAST ONE of its rows (conv_igemm_kernel.h "block-uniform tap pruning": the
+    contiguous span kt_lo..kt_hi x kh_lo..kh_hi), every kw, every BK-wide channel chunk, on full BM x BN x BK tiles
+    (row / column / K padding of edge tiles included).  Host-side twin of the kernel's own loop bounds."""
+    import numpy as np
+    BM, BN, BK = tile
+    M = d.N * d.To * d.Ho * d.Wo
+    ncol = _r4(d.Co)
+    n_tiles = -(-ncol // BN)
+    kch = -(-max(d.ldx, d.Kc) // BK)
+    if d.x2_C > 0 and d.x2_ld > 0:
+        kch = -(-d.ldx // BK) + -(-d.x2_ld // BK)
+    m = np.arange(M, dtype=np.int64)
+    t = m // d.Wo
+    ho = t % d.Ho
+    to = (t // d.Ho) % d.To
+
+    def span(c, pad, k, extent):
+        lo = np.maximum(0, pad - c)
+        hi = np.minimum(k - 1, extent - 1 + pad - c)
+        return lo, hi
+    edges = np.arange(0, M, BM)
+    steps = np.ones(len(edges), dtype=np.int64)
+    for (c, pad, k, ext) in ((to * d.sT, d.pT, d.kT, d.Ti), (ho * d.sH, d.pH, d.kH, d.Hi)):
+        lo, hi = span(c, pad, k, ext)
+        ok = hi >= lo
+        lo_t = np.minimum.reduceat(np.where(ok, lo, k), edges)
+        hi_t = np.maximum.reduceat(np.where(ok, hi, -1), edges)
+        steps *= np.maximum(hi_t - lo_t + 1, 0)
+    return float(steps.sum()) * d.kW * kch * n_tiles * 2.0 * BM * BN * BK * words
+
+
 class ConvStep:
     """One ptx_conv3d_fwd (or, with a second source, ptx_conv3d_dual_fwd) launch with everything but
     the stream frozen."""
     __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused", "from_table")
+
+    def issued_flop(self):
+        tile = _tile_dims(_lib.lib().ptx_conv3d_config_name(self.cfg).decode())
+        return 2.0 * self.macs if tile is None else issued_conv_flop(self.d, tile)
 
     def __call__(self, st):
         try:
@@ -438,6 +483,15 @@ class ChainStep:
     def kernel(self):
         return _lib.lib().ptx_conv3d_chain_config_name(self.cfg).decode()
 
+    def issued_flop(self):
+        tile = _tile_dims(self.kernel)
+        if tile is None:
+            return 2.0 * self.macs
+        BM, BN, BK = tile
+        m_tiles = -(-(self.d.N * self.d.To * self.d.Ho * self.d.Wo) // BM)
+        tail = m_tiles * -(-_r4(self.d2.Co) // BN) * -(-min(_r4(self.d.Co), BN) // BK) * 2.0 * BM * BN * BK
+        return issued_conv_flop(self.d, tile) + tail
+
     def __call__(self, st):
         check(_lib.lib().ptx_conv3d_chain_fwd(C.byref(self.d), C.byref(self.d2), self.x, self.w, self.b, self.w2, self.b2,
                                               self.res, self.y, self.cfg, st), self.label)
@@ -471,6 +525,39 @@ def alt_store(key, use_chain):
     table = _tuned_table()
     with _tuned_lock:
         table["alt:" + key] = ("chain" if use_chain else "pair", 1)
+
+
+class ProgramStep:
+    """A run of consecutive small-M ConvSteps as ONE persistent launch (ptx_conv_program_fwd, csrc/conv_program.hip): the
+    tiles of all its convs on one queue, per-row-tile dependencies instead of kernel boundaries.  `convs` are the launches it
+    stands for -- still complete ConvSteps, run instead when `use_program` is off (PTX_PROGRAM=0, or the tuner measured the
+    launches faster)."""
+    __slots__ = ("convs", "use_program", "label", "macs", "hbm_bytes", "info", "image", "ws", "wgs", "plan", "stages", "kernel")
+
+    def __call__(self, st):
+        if self.use_program:
+            check(_lib.lib().ptx_conv_program_fwd(C.byref(self.info), _ptr(self.image), _ptr(self.ws), self.wgs, st), self.label)
+        else:
+            for s in self.convs:
+                s(st)
+
+    def active(self):
+        return [self] if self.use_program else list(self.convs)
+
+    def issued_flop(self):
+        # every stage runs a conv_igemm tile body: its own plan line names the tile
+        buf = C.create_string_buffer(1 << 16)
+        check(_lib.lib().ptx_conv_program_describe(self.stages, len(self.convs), buf, len(buf)), "conv program describe")
+        tot = 0.0
+        for c, line in zip(self.convs, buf.value.decode().splitlines()[1:]):
+            tot += issued_conv_flop(c.d, _tile_dims(line.split()[3]))
+        return tot
+
+    def error(self):
+        """Synchronise and read the program's error word: None, or (code, waiting stage, queue index, producer stage)."""
+        code = (C.c_int32 * 4)()
+        check(_lib.lib().ptx_conv_program_error(_ptr(self.ws), code, _stream()), self.label)
+        return None if code[0] == 0 else tuple(code)
 
 
 class StemStep:
@@ -558,8 +645,10 @@ class Plan:
         # qualified names of the model's modules: everything the plan keeps from the model is a _Ref
         self._names = {id(m): n for n, m in model.named_modules()}
         self._cur = model                # the model (or DataParallel replica) whose tensors are valid right now
+        self.program_steps = []  # ProgramStep: runs of small-M convs as one persistent launch
         with _device_ctx(dev):
             self._build(model)
+            self._fuse_programs()
             if self.ws_bytes:
                 self.ws = torch.zeros(self.ws_bytes // 4, device=dev, dtype=torch.float32)
                 self.ws_ptr = _ptr(self.ws)
@@ -1372,6 +1461,79 @@ class Plan:
             return self.conv_bn(o, blk.conv3, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv3")
         return self.conv_bn(o, blk.conv2, None, res=res, res_kind=kind, res_stride=s, label=name + ".conv2")
 
+    def _fuse_programs(self):
+        """Replace every run of >= PTX_PROGRAM_MIN_STAGES consecutive plain fp32 ConvSteps with at most PTX_PROGRAM_MAX_M
+        output rows by ONE ProgramStep (conv_program.hip).  A run ends at anything that is not such a conv (attention,
+        pooling, chained pairs, fp16 / split-operand stages) and at a conv the library refuses (its message names the
+        rule); the replaced ConvSteps stay inside the ProgramStep as its fallback and as the record of what it computes."""
+        if os.environ.get("PTX_PROGRAM", "1") == "0" or torch.device(self.dev).type != "cuda" or self.x3:
+            return
+        max_m = int(os.environ.get("PTX_PROGRAM_MAX_M", "4096"))
+        min_n = int(os.environ.get("PTX_PROGRAM_MIN_STAGES", "2"))
+        wgs = int(os.environ.get("PTX_PROGRAM_WGS", "2"))
+        lib = self.lib
+        tile_ids = {lib.ptx_conv_program_tile_name(i).decode(): i for i in range(lib.ptx_conv_program_num_tiles())}
+        use_tuned = os.environ.get("PTX_PROGRAM_TILES", "auto") == "tuned"
+
+        def eligible(st):
+            if not isinstance(st, ConvStep) or st.fused:
+                return False
+            d = st.d
+            ok_flags = PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_SPLITK_FUSED
+            return (d.flags & ~ok_flags) == 0 and d.groups <= 1 and d.N * d.To * d.Ho * d.Wo <= max_m
+
+        def make(run):
+            arr = (ConvStage * len(run))()
+            for i, st in enumerate(run):
+                e = arr[i]
+                C.memmove(C.byref(e.desc), C.byref(st.d), C.sizeof(ConvDesc))
+                e.x, e.x2, e.w_packed, e.bias, e.res, e.y = st.x, st.x2, st.w, st.b, st.res, st.y
+                name = lib.ptx_conv3d_config_name(st.cfg).decode()
+                e.tile = tile_ids.get(name, -1) if use_tuned else -1
+                e.split_k = st.split if (use_tuned and e.tile >= 0) else 0
+            info = ConvProgramInfo()
+            if lib.ptx_conv_program_plan(arr, len(run), C.byref(info)) != 0:
+                return None
+            ps = ProgramStep()
+            ps.ws = torch.zeros((int(info.workspace_bytes) + 255) // 4 + 64, device=self.dev, dtype=torch.float32)
+            off = (-ps.ws.data_ptr()) % 256 // 4
+            ps.ws = ps.ws[off:]
+            host = (C.c_char * int(info.image_bytes))()
+            check(lib.ptx_conv_program_build(arr, len(run), _ptr(ps.ws), int(info.workspace_bytes), host, int(info.image_bytes),
+                                             C.byref(info)), "conv program build")
+            ps.image = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
+            ps.info, ps.stages, ps.convs, ps.plan, ps.wgs = info, arr, list(run), self, wgs
+            ps.label = "%s..%s" % (run[0].label, run[-1].label)
+            ps.macs, ps.hbm_bytes = sum(c.macs for c in run), 0
+            ps.kernel = "conv_program/%dstages/%dtiles" % (len(run), info.total_items)
+            ps.use_program = True
+            return ps
+
+        out, run = [], []
+
+        def flush():
+            # the library may refuse a run as a whole (buffer reuse, a foreign row layout): retry without its first conv
+            # until something sticks or the run is too short
+            r = list(run)
+            del run[:]
+            while len(r) >= min_n:
+                ps = make(r)
+                if ps is not None:
+                    out.append(ps)
+                    self.program_steps.append(ps)
+                    return
+                out.append(r.pop(0))
+            out.extend(r)
+
+        for st in self.steps:
+            if eligible(st):
+                run.append(st)
+            else:
+                flush()
+                out.append(st)
+        flush()
+        self.steps = out
+
     # ---------------------------------------------------------------- running
     def run_head(self, engine, model):
         """feature map -> logits: the default global-average-pool + classifier, or the plan's own tail."""
@@ -1392,8 +1554,8 @@ class Plan:
         autotuner owns) and the direct stem kernels."""
         out = []
         for s in self.steps:
-            for t in (s.active() if isinstance(s, AltStep) else [s]):
-                if isinstance(t, (ConvStep, ChainStep, StemStep, StemF32Step, PatchConvStep)):
+            for t in (s.active() if isinstance(s, (AltStep, ProgramStep)) else [s]):
+                if isinstance(t, (ConvStep, ChainStep, StemStep, StemF32Step, PatchConvStep, ProgramStep)):
                     out.append(t)
         return out
 
@@ -2065,7 +2227,8 @@ class Engine:
             for r in self.profile_steps(plan, iters):
                 if r[1] in ("conv", "stem", "chain"):
                     rows.append((r[0], r[3], r[4], r[5], r[6].split if r[1] == "conv" else 1))
-            assert len(rows) == len(live)
+            if len(rows) != len(live):
+                raise PtxError("profile_convs: %d timed launches for %d live conv steps" % (len(rows), len(live)))
         return rows
 
 
@@ -2075,7 +2238,7 @@ class Engine:
         implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
         rows = []
         st = _stream()
-        flat = [t for s in plan.steps for t in (s.active() if isinstance(s, AltStep) else [s])]
+        flat = [t for s in plan.steps for t in (s.active() if isinstance(s, (AltStep, ProgramStep)) else [s])]
         for stp in flat:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             stp(st)
@@ -2089,7 +2252,7 @@ class Engine:
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp))
             elif isinstance(stp, (StemStep, StemF32Step, PatchConvStep)):      # direct (patch) kernels are convs too
                 rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
-            elif isinstance(stp, ChainStep):                    # two convs in one launch, its own tile table
+            elif isinstance(stp, (ChainStep, ProgramStep)):     # several convs in one launch, their own tile tables
                 rows.append((stp.label, "chain", 0, stp.macs, ms, stp.kernel))
             else:
                 nb, macs = getattr(stp, "hbm_bytes", 0), getattr(stp, "macs", 0)

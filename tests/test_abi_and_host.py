@@ -26,6 +26,24 @@ def test_header_and_bindings_agree(ptx):
     assert len(L.binary_source_hash()) == 64 and L.binary_source_hash() == L.source_hash()
 
 
+def test_every_object_is_stamped_with_its_translation_unit(ptx):
+    """the global source hash lives in ONE object (pack_layout.o); a stale conv_igemm.o next to a
+    fresh stamp would have passed.  build.py now decides staleness by CONTENT -- every object carries the sha256 of its own
+    translation unit (source + every project header it includes + flags) in `<obj>.srchash`, the library the sha256 over
+    those -- and this test asserts all of them against the tree (the stamps travel to the GPU box with the objects)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("ptx_build", os.path.join(os.path.dirname(ptx._lib.LIB_PATH), "csrc", "build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    ok = build.stamps_match()
+    assert set(ok) == set(build.SOURCES) | {"libptx_amd.so"} and len(build.SOURCES) == 9
+    assert all(ok.values()), {k: v for k, v in ok.items() if not v}
+    # a header edit reaches exactly the translation units that include it
+    assert os.path.join(build.HERE, "conv_igemm_kernel.h") in build.tu_files("conv_program.hip")
+    assert os.path.join(build.HERE, "conv_igemm_kernel.h") not in build.tu_files("pool_head.hip")
+
+
 def test_struct_layouts_match_header(ptx):
     """ctypes mirrors of the POD descriptors must have the header's field order and size."""
     L = ptx._lib
@@ -49,6 +67,10 @@ def test_struct_layouts_match_header(ptx):
     assert fields_of("ptx_pool3d_desc") == [f for f, _ in L.PoolDesc._fields_]
     assert fields_of("ptx_norm_desc") == [f for f, _ in L.NormDesc._fields_]
     assert fields_of("ptx_rgb_conv_desc") == [f for f, _ in L.RgbConvDesc._fields_]
+    assert C.sizeof(L.ConvStage) == C.sizeof(L.ConvDesc) + 6 * 8 + 8 and C.sizeof(L.ConvDesc) % 8 == 0   # desc, six pointers, tile, split_k
+    assert [f for f, _ in L.ConvStage._fields_] == ["desc", "x", "x2", "w_packed", "bias", "res", "y", "tile", "split_k"]
+    assert [f for f, _ in L.ConvProgramInfo._fields_] == ["n_stages", "total_items", "ctrl_words", "lds_bytes", "launches_replaced",
+                                                         "reserved", "image_bytes", "workspace_bytes"] and C.sizeof(L.ConvProgramInfo) == 40
     assert C.sizeof(L.RgbConvDesc) == 4 * len(L.RgbConvDesc._fields_)
     assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
     assert C.sizeof(L.PoolDesc) == 4 * len(L.PoolDesc._fields_)

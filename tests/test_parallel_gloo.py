@@ -66,8 +66,11 @@ def _bench_worker(rank, world, port, total, q, corrupt):
         out = _fake_forward(local)
         return out + calls[0] if (corrupt and rank == 1) else out
 
-    elapsed, out, verify = bench.timed_steps(run, total, steps=3, warmup=1, dev=torch.device("cpu"),
-                                             sync=lambda: None)
+    elapsed, out, verify, rank_ms = bench.timed_steps(run, total, steps=3, warmup=1, dev=torch.device("cpu"),
+                                                      sync=lambda: None)
+    # every rank's own step time travels with the MAX (a straggler must be visible in the line)
+    assert len(rank_ms["ms_per_step"]) == world and rank_ms["max"] >= rank_ms["min"] > 0
+    assert rank_ms["ms_per_step"][rank_ms["argmax_rank"]] == rank_ms["max"] and abs(rank_ms["max"] - 1e3 * elapsed / 3) < 1e-3
     # rank 0 "tunes", everyone adopts its table
     if rank == 0:
         engine.tuned_merge({"[\"fake-problem\"]": ("64x64x16/2x2/m32/dma", 2)})
@@ -90,8 +93,8 @@ def _strong_worker(rank, world, port, total, q, workload):
     bench.GLOBAL_BATCH = dict(bench.GLOBAL_BATCH, **{workload: total})        # small stand-in batch sizes
     make = lambda n, seed: torch.randn(n, 3, 2, 4, 4, generator=torch.Generator().manual_seed(seed))     # noqa: E731
     local, tot = bench.local_batch(make, 8, workload, "strong", world, rank)
-    elapsed, out, verify = bench.timed_steps(lambda: _fake_forward(local), tot, steps=2, warmup=1, dev=torch.device("cpu"),
-                                             sync=lambda: None)
+    elapsed, out, verify, _rank_ms = bench.timed_steps(lambda: _fake_forward(local), tot, steps=2, warmup=1, dev=torch.device("cpu"),
+                                                       sync=lambda: None)
     want = _fake_forward(make(total, 99))
     q.put((rank, dict(verify), bool(torch.equal(out, want)), int(local.shape[0]), tot))
     dist.barrier()
@@ -178,6 +181,11 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=env, capture_output=True, text=True, timeout=300)
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert r.returncode == 0 and line["n_gpus"] == 1 and line["ranks_seen"]["world_size"] == 1, (r.stderr[-500:], line)
+    # no --gpus under a launcher: the launcher's WORLD_SIZE is taken (`torchrun ... bench.py` must keep working)
+    r = subprocess.run([sys.executable, bench], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r.returncode == 0 and line["n_gpus"] == 1, r.stderr[-500:]
     # a launcher's WORLD_SIZE that disagrees with --gpus is an error, not a warning
     r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
