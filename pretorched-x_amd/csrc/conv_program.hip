@@ -126,19 +126,20 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
                                                           const int n_stages, const int total_items, unsigned* ctrl,
                                                           const unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    volatile int* lc = reinterpret_cast<volatile int*>(smem + kProgTileLds / 4);      // [0] item, [1] stage, [2] flag
+    // workgroup control words behind the tile image: [0] queue index, [1] stage, [2] dependency wait ok, [3] last split arriver
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int* const lc = (lds_int*)(smem + kProgTileLds / 4);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned* const head = ctrl;
     unsigned* const err = ctrl + 1;
+    // Every loop-control decision below is made on a value that was broadcast through LDS and read back with
+    // readfirstlane: scalar branches, the same path for all four waves, so every wave meets every barrier.
     for (;;) {
-        if (tid == 0) lc[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) lc[0] = (int)__hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int item = __builtin_amdgcn_readfirstlane(lc[0]);
         if (item >= total_items) break;
-        if (tid < n_stages) {
-            if (item >= item_begin[tid] && item < item_begin[tid + 1]) lc[1] = tid;
-        }
+        if (tid < n_stages && item >= item_begin[tid] && item < item_begin[tid + 1]) lc[1] = tid;
         __syncthreads();
         const int s = __builtin_amdgcn_readfirstlane(lc[1]);
         const ProgStage* const S = stages + s;
@@ -151,9 +152,9 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         // ---- wait for the producers' row tiles this tile reads (one wave polls, relaxed)
         if (wave == 0) {
             const int m0 = m_tile * bm, m1 = min(m0 + bm, p.M) - 1;
-            int bad = 0;
+            int ok = 1;
             const int nd = S->ndeps;
-            for (int d = 0; d < nd && !bad; ++d) {
+            for (int d = 0; d < nd; ++d) {
                 const ProgDep dep = S->deps[d];
                 int lo, hi;
                 if (dep.kind == 0) {
@@ -168,32 +169,29 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
                 }
                 const int t_lo = max(lo, 0) / dep.bm, t_hi = min(hi / dep.bm, dep.mtiles - 1);
                 const unsigned* cnt = ctrl + dep.done_off;
-                for (int base = t_lo; base <= t_hi && !bad; base += 64) {
+                for (int base = t_lo; base <= t_hi; base += 64) {
                     const int idx = base + lane;
-                    unsigned spins = 0;
-                    for (;;) {
+                    for (unsigned spins = 0; ok; ++spins) {
                         const unsigned v = idx <= t_hi ? ld_relaxed(cnt + idx) : (unsigned)dep.target;
                         if (__all(v >= (unsigned)dep.target)) break;
-                        ++spins;
-                        if ((spins & 63u) == 0u && ld_relaxed(err) != 0u) { bad = 1; break; }
-                        if (spins > spin_limit) {
+                        if ((spins & 63u) == 63u && ld_relaxed(err) != 0u) ok = 0;            // somebody else gave up
+                        if (spins >= spin_limit) {
                             if (lane == 0) {
-                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store(ctrl + 2, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store(ctrl + 3, (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store(ctrl + 4, (unsigned)dep.stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
-                            bad = 1;
-                            break;
+                            ok = 0;
                         }
                         __builtin_amdgcn_s_sleep(8);
                     }
                 }
             }
-            if (lane == 0) lc[2] = bad;
+            if (lane == 0) lc[2] = ok;
         }
         __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(lc[2])) break;
+        if (!__builtin_amdgcn_readfirstlane(lc[2])) break;
         // ---- the tile
         switch (S->cfg) {
             case 0: PTX_PROG_TILE(32, 64, 64)(p, tile, 0, zs, smem); break;
@@ -203,18 +201,22 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         // ---- publish: every storing wave drains its write-through stores, then one lane counts
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        int publish = 1;
         if (split > 1) {
             if (tid == 0) {
                 const unsigned t = __hip_atomic_fetch_add(ctrl + S->tick_off + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lc[2] = t == (unsigned)split - 1u ? 1 : 0;
+                lc[3] = t == (unsigned)split - 1u ? 1 : 0;
             }
             __syncthreads();
-            if (!__builtin_amdgcn_readfirstlane(lc[2])) continue;
-            prog_reduce_tile(p, bm, S->bn, tile, tid);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish = __builtin_amdgcn_readfirstlane(lc[3]);
+            if (publish) {
+                prog_reduce_tile(p, bm, S->bn, tile, tid);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
         }
-        if (tid == 0) __hip_atomic_fetch_add(ctrl + S->done_off + m_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (publish && tid == 0)
+            __hip_atomic_fetch_add(ctrl + S->done_off + m_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -1,0 +1,142 @@
+"""Visibility probe for conv programs (csrc/conv_program.hip): runs progressively larger programs and WATCHES the
+program's control words (queue head, error word, completion counters) from a side stream while the launch is in flight, so
+a launch that does not finish reports where it stopped instead of timing out blind.  Exits (os._exit) after `limit` seconds.
+
+    python scripts/gpu_prog_probe.py [case ...]      cases: plain one two split block full layer4
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+torch.set_num_threads(16)
+
+import pretorched_x_amd as ptx  # noqa: E402
+import test_conv_program as T  # noqa: E402
+
+DEV = "cuda:0"
+L, lib = ptx._lib, ptx._lib.lib()
+
+
+def say(*a):
+    print(*a, flush=True)
+
+
+def watch_program(net, wgs=2, tiles=None, splits=None, limit=12.0):
+    arr = net.stage_array(tiles, splits)
+    info = L.ConvProgramInfo()
+    L.check(lib.ptx_conv_program_plan(arr, len(arr), C.byref(info)), "plan")
+    desc = T._describe(L, lib, arr)
+    for line in desc:
+        say("   ", line)
+    ws = torch.zeros(int(info.workspace_bytes) // 4 + 128, device=DEV)
+    ws = ws[(-ws.data_ptr()) % 256 // 4:]
+    host = (C.c_char * int(info.image_bytes))()
+    L.check(lib.ptx_conv_program_build(arr, len(arr), T._p(ws), int(info.workspace_bytes), host, int(info.image_bytes), C.byref(info)), "build")
+    image = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(DEV)
+    net.clear()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    done = torch.cuda.Event()
+    t0 = time.time()
+    L.check(lib.ptx_conv_program_fwd(C.byref(info), T._p(image), T._p(ws), wgs, T._st()), "program")
+    done.record()
+    nctrl = int(info.ctrl_words)
+    last = None
+    while not done.query():
+        with torch.cuda.stream(side):
+            snap = ws[:nctrl].view(torch.int32).to("cpu", non_blocking=False)
+        cur = (int(snap[0]), int(snap[1]), int(snap[16:].sum()))
+        if cur != last:
+            say("    t=%.2fs head=%d/%d err=%s done_sum=%d" % (time.time() - t0, cur[0], info.total_items, list(map(int, snap[1:5])), cur[2]))
+            last = cur
+        if time.time() - t0 > limit:
+            say("    NOT FINISHED after %.1fs: ctrl[0:8]=%s" % (limit, list(map(int, snap[:8]))))
+            say("    counters:", list(map(int, snap[16:16 + 96])))
+            sys.stdout.flush()
+            os._exit(3)
+        time.sleep(0.05)
+    torch.cuda.synchronize()
+    say("    finished in %.3fs (host wall, first launch)" % (time.time() - t0))
+    code = (C.c_int32 * 4)()
+    L.check(lib.ptx_conv_program_error(T._p(ws), code, T._st()), "err")
+    say("    error word:", list(code))
+    outs = [a.clone() for a in net.acts[1:]]
+    want = net.reference()
+    launches = net.run_launches(desc)
+    for i, (a, b) in enumerate(zip(outs, launches)):
+        eq = bool(torch.equal(a, b))
+        got, ref = net.to_ncdhw(i + 1, a), want[i + 1]
+        err = (got - ref).abs().max().item()
+        lerr = (net.to_ncdhw(i + 1, b) - ref).abs().max().item()
+        say("    stage %d: program==launches %s   |program-aten| %.3e   |launches-aten| %.3e   (max |ref| %.2f)" % (i, eq, err, lerr, ref.abs().max().item()))
+    # timing: 20 back-to-back launches vs the launches
+    for name, fn in (("program", lambda: L.check(lib.ptx_conv_program_fwd(C.byref(info), T._p(image), T._p(ws), wgs, T._st()), "p")),):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        e1.synchronize()
+        say("    %s: %.1f us per launch (wgs %d)" % (name, 1e3 * e0.elapsed_time(e1) / 20, wgs))
+
+
+def plain_sanity():
+    """The refactored tile body as a plain launch (library default tile) against ATen."""
+    net = T._bottlenecks(ptx, N=2, T=2, H=10, W=10, planes=64, blocks=1, seed=5)
+    net.clear()
+    null = C.c_void_p(0)
+    for s in net.stages:
+        d = s["d"]
+        nb = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
+        ws = torch.empty(max(nb // 4, 4), device=DEV)
+        x, y = T._p(net.acts[s["src"]]), T._p(net.acts[s["y"]])
+        if s["x2"] is not None:
+            L.check(lib.ptx_conv3d_dual_fwd(C.byref(d), x, T._p(net.acts[s["x2"]]), T._p(s["w"]), T._p(s["b"]), y, T._p(ws), nb, -1, 0, T._st()), "dual")
+        else:
+            L.check(lib.ptx_conv3d_fwd(C.byref(d), x, T._p(s["w"]), T._p(s["b"]), null, y, T._p(ws), nb, -1, 0, T._st()), "conv")
+    torch.cuda.synchronize()
+    want = net.reference()
+    for i, a in enumerate(net.acts[1:]):
+        say("    plain stage %d: |d| %.3e" % (i, (net.to_ncdhw(i + 1, a) - want[i + 1]).abs().max().item()))
+
+
+def case(name):
+    say("== %s" % name)
+    if name == "plain":
+        return plain_sanity()
+    if name == "one":          # one pointwise stage, no dependencies
+        net = T.Net(ptx, T._rnd(2, 64, 2, 8, 8, seed=1))
+        net.conv(0, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 2)
+        return watch_program(net, splits=[1])
+    if name == "two":          # two stages, one dependency
+        net = T.Net(ptx, T._rnd(2, 64, 2, 8, 8, seed=1))
+        o = net.conv(0, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 2)
+        net.conv(o, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 3)
+        return watch_program(net, splits=[1, 1])
+    if name == "split":        # the same with split-K seams
+        net = T.Net(ptx, T._rnd(2, 64, 2, 8, 8, seed=1))
+        o = net.conv(0, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 2)
+        net.conv(o, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 3)
+        return watch_program(net, splits=[2, 3])
+    if name == "block":
+        return watch_program(T._bottlenecks(ptx, N=2, T=2, H=10, W=10, planes=64, blocks=2, seed=40))
+    if name == "full":
+        return watch_program(T._bottlenecks(ptx))
+    if name == "layer3":       # resnet3d50 layer3 at config 2: M = 3136
+        return watch_program(T._bottlenecks(ptx, N=8, T=4, H=28, W=28, C0=512, planes=256, blocks=3, seed=90), limit=20)
+    if name == "layer4":
+        return watch_program(T._bottlenecks(ptx, N=8, T=2, H=14, W=14, C0=1024, planes=512, blocks=3, seed=90), limit=20)
+    raise SystemExit("unknown case " + name)
+
+
+if __name__ == "__main__":
+    say(torch.cuda.get_device_name(0), lib.ptx_version().decode())
+    for c in (sys.argv[1:] or ["plain", "one", "two", "split", "block", "full"]):
+        case(c)
+    say("probe done")
