@@ -237,6 +237,11 @@ int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, void* worksp
 int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
                          ptx_stream_t stream);
 int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream);
+/* diagnostic: the same launch with a phase clock -- 8 x uint64 per queue item written by the workgroup that ran it: the
+ * 100 MHz wall clock at [0] item taken, [1] dependencies complete, [2] tile computed and drained, [3] published;
+ * [4] CU id | workgroup << 32; [5] stage | tile << 32; [6] 1 + split slice | last-arriver << 32 (scripts/gpu_prog_probe.py) */
+int ptx_conv_program_trace_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
+                               void* trace, size_t trace_bytes, ptx_stream_t stream);
 
 /* Small-Cin STEM convolution with split operands (PTX_F16X3_OPERANDS), read straight from a channels-last input whose
  * positions are 16 bytes (Ci <= 4, ldx == 4) -- `conv1` of the ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D

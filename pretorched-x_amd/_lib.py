@@ -145,6 +145,7 @@ SIGNATURES = {
     "ptx_conv_program_describe": (C.c_int, [C.POINTER(ConvStage), _I, C.c_char_p, _Z]),
     "ptx_conv_program_build": (C.c_int, [C.POINTER(ConvStage), _I, _P, _Z, _P, _Z, C.POINTER(ConvProgramInfo)]),
     "ptx_conv_program_fwd": (C.c_int, [C.POINTER(ConvProgramInfo), _P, _P, _I, _P]),
+    "ptx_conv_program_trace_fwd": (C.c_int, [C.POINTER(ConvProgramInfo), _P, _P, _I, _P, _Z, _P]),
     "ptx_conv_program_error": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     "ptx_ncdhw_to_split4": (C.c_int, [_P, _P, _I, _I, _L, _P]),
     "ptx_conv_stem_x3_supported": (C.c_int, [C.POINTER(ConvDesc)]),

@@ -124,8 +124,11 @@ __device__ __forceinline__ void prog_reduce_tile(const ConvArgs& p, int BM, int 
 
 __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __restrict__ stages, const int* __restrict__ item_begin,
                                                           const int n_stages, const int total_items, unsigned* ctrl,
-                                                          const unsigned spin_limit) {
+                                                          const unsigned spin_limit, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // `trace` (diagnostic launches only, ptx_conv_program_trace_fwd; NULL otherwise): 8 x u64 per queue item, written by
+    // thread 0 -- the 100 MHz wall clock when the item was [0] taken, [1] cleared to run, [2] computed and drained,
+    // [3] published; [4] CU id | workgroup << 32; [5] stage | tile << 32; [6] 1 + split slice, bit 32 = last arriver
     // workgroup control words behind the tile image: [0] queue index, [1] stage, [2] dependency wait ok, [3] last split arriver
     typedef __attribute__((address_space(3))) int lds_int;
     lds_int* const lc = (lds_int*)(smem + kProgTileLds / 4);
@@ -139,6 +142,8 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         __syncthreads();
         const int item = __builtin_amdgcn_readfirstlane(lc[0]);
         if (item >= total_items) break;
+        unsigned long long* const tr = trace ? trace + (size_t)item * 8 : nullptr;
+        if (tr && tid == 0) tr[0] = wall_clock64();
         if (tid < n_stages && item >= item_begin[tid] && item < item_begin[tid + 1]) lc[1] = tid;
         __syncthreads();
         const int s = __builtin_amdgcn_readfirstlane(lc[1]);
@@ -192,6 +197,11 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         }
         __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(lc[2])) break;
+        if (tr && tid == 0) {
+            tr[1] = wall_clock64();
+            tr[4] = (unsigned long long)__smid() | ((unsigned long long)blockIdx.x << 32);
+            tr[5] = (unsigned long long)(unsigned)s | ((unsigned long long)(unsigned)tile << 32);
+        }
         // ---- the tile
         switch (S->cfg) {
             case 0: PTX_PROG_TILE(32, 64, 64)(p, tile, 0, zs, smem); break;
@@ -201,6 +211,7 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         // ---- publish: every storing wave drains its write-through stores, then one lane counts
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (tr && tid == 0) tr[2] = wall_clock64();
         int publish = 1;
         if (split > 1) {
             if (tid == 0) {
@@ -217,6 +228,10 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         }
         if (publish && tid == 0)
             __hip_atomic_fetch_add(ctrl + S->done_off + m_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tr && tid == 0) {
+            tr[3] = wall_clock64();
+            tr[6] = (unsigned long long)(1 + zs) | ((unsigned long long)(split > 1 && publish) << 32);
+        }
     }
 }
 
@@ -439,8 +454,8 @@ extern "C" int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, v
     return PTX_OK;
 }
 
-extern "C" int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace,
-                                    int32_t wgs_per_cu, ptx_stream_t stream) {
+static int program_launch(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
+                          unsigned long long* trace, ptx_stream_t stream) {
     if (!info || !image_dev || !workspace) return fail(PTX_ERR_INVALID, "conv_program: null argument");
     if (info->n_stages <= 0 || info->n_stages > kProgMaxStages || info->total_items <= 0)
         return fail(PTX_ERR_INVALID, "conv_program: info does not describe a built program");
@@ -467,8 +482,20 @@ extern "C" int ptx_conv_program_fwd(const ptx_conv_program_info* info, const voi
     int grid = wgs_per_cu * kNumCU;
     if (grid > info->total_items) grid = info->total_items;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), kProgLdsBytes, st, stages, item_begin, (int)info->n_stages,
-                       (int)info->total_items, static_cast<unsigned*>(workspace), spin_limit);
+                       (int)info->total_items, static_cast<unsigned*>(workspace), spin_limit, trace);
     return hip_check(hipGetLastError(), "conv_program launch");
+}
+
+extern "C" int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace,
+                                    int32_t wgs_per_cu, ptx_stream_t stream) {
+    return program_launch(info, image_dev, workspace, wgs_per_cu, nullptr, stream);
+}
+
+extern "C" int ptx_conv_program_trace_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace,
+                                          int32_t wgs_per_cu, void* trace, size_t trace_bytes, ptx_stream_t stream) {
+    if (!info || !trace || ((uintptr_t)trace & 7) || trace_bytes < (size_t)info->total_items * 64)
+        return fail(PTX_ERR_INVALID, "conv_program_trace: needs an 8-byte aligned buffer of total_items x 64 bytes");
+    return program_launch(info, image_dev, workspace, wgs_per_cu, static_cast<unsigned long long*>(trace), stream);
 }
 
 extern "C" int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream) {

@@ -86,6 +86,127 @@ def watch_program(net, wgs=2, tiles=None, splits=None, limit=12.0):
         say("    %s: %.1f us per launch (wgs %d)" % (name, 1e3 * e0.elapsed_time(e1) / 20, wgs))
 
 
+def build_program(net, tiles=None, splits=None):
+    arr = net.stage_array(tiles, splits)
+    info = L.ConvProgramInfo()
+    L.check(lib.ptx_conv_program_plan(arr, len(arr), C.byref(info)), "plan")
+    ws = torch.zeros(int(info.workspace_bytes) // 4 + 128, device=DEV)
+    ws = ws[(-ws.data_ptr()) % 256 // 4:]
+    host = (C.c_char * int(info.image_bytes))()
+    L.check(lib.ptx_conv_program_build(arr, len(arr), T._p(ws), int(info.workspace_bytes), host, int(info.image_bytes), C.byref(info)), "build")
+    image = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(DEV)
+    return arr, info, ws, image, T._describe(L, lib, arr)
+
+
+def time_fn(fn, reps=30):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
+def launches_fn(net, desc):
+    """closure running the stages one launch each on the tiles / splits the plan names"""
+    names = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
+    null = C.c_void_p(0)
+    calls = []
+    keep = []
+    for s, line in zip(net.stages, desc[1:]):
+        f = line.split()
+        cfg, split = names[f[3]], int(f[5])
+        d = s["d"]
+        nb = lib.ptx_conv3d_workspace_bytes(C.byref(d), max(split, 1))
+        ws = torch.empty(max(nb // 4, 4), device=DEV)
+        keep.append(ws)
+        x, y = T._p(net.acts[s["src"]]), T._p(net.acts[s["y"]])
+        if s["x2"] is not None:
+            calls.append((lib.ptx_conv3d_dual_fwd, (C.byref(d), x, T._p(net.acts[s["x2"]]), T._p(s["w"]), T._p(s["b"]), y, T._p(ws), nb, cfg, split)))
+        else:
+            r = T._p(net.acts[s["res"]]) if s["res"] is not None else null
+            calls.append((lib.ptx_conv3d_fwd, (C.byref(d), x, T._p(s["w"]), T._p(s["b"]), r, y, T._p(ws), nb, cfg, split)))
+
+    def run():
+        st = T._st()
+        for f_, a in calls:
+            L.check(f_(*a, st), "launch")
+    run.keep = keep
+    return run
+
+
+def trace_program(net, wgs=2, tiles=None, splits=None, label=""):
+    """One traced launch: where the workgroups' time goes, per stage."""
+    arr, info, ws, image, desc = build_program(net, tiles, splits)
+    n = int(info.total_items)
+    fwd = lambda: L.check(lib.ptx_conv_program_fwd(C.byref(info), T._p(image), T._p(ws), wgs, T._st()), "p")   # noqa: E731
+    us = time_fn(fwd)
+    lus = time_fn(launches_fn(net, desc))
+    trace = torch.zeros(n * 8, dtype=torch.int64, device=DEV)
+    L.check(lib.ptx_conv_program_trace_fwd(C.byref(info), T._p(image), T._p(ws), wgs, C.c_void_p(trace.data_ptr()), n * 64, T._st()), "trace")
+    torch.cuda.synchronize()
+    t = trace.cpu().view(n, 8)
+    t0, t1, t2, t3 = [t[:, i].double() / 100.0 for i in range(4)]          # us
+    stage = (t[:, 5] & 0xffffffff).long()
+    base = t0.min()
+    span = (t3.max() - base).item()
+    grid = min(wgs * 256, n)
+    say("  %s program %.1f us | same tiles as launches %.1f us | traced span %.1f us, %d items on %d workgroups (%d per CU)" % (
+        label, us, lus, span, n, grid, wgs))
+    say("   stage tile                      split items   start    end   | per item: take->go   tile  publish (us) | sum tile us")
+    for sidx in range(int(info.n_stages)):
+        m = stage == sidx
+        f = desc[1 + sidx].split()
+        say("   %5d %-26s %5s %5d %7.1f %7.1f |           %7.2f %7.2f %7.2f        | %9.1f" % (
+            sidx, f[3], f[5], int(m.sum()), (t0[m].min() - base).item(), (t3[m].max() - base).item(),
+            (t1[m] - t0[m]).mean().item(), (t2[m] - t1[m]).mean().item(), (t3[m] - t2[m]).mean().item(), (t2[m] - t1[m]).sum().item()))
+    busy = (t2 - t1).sum().item()
+    wait = (t1 - t0).sum().item()
+    pub = (t3 - t2).sum().item()
+    say("   workgroup-time: tile %.0f us (%.0f%% of %d x span), waiting %.0f us (%.0f%%), publish/reduce %.0f us (%.0f%%)" % (
+        busy, 100 * busy / (grid * span), grid, wait, 100 * wait / (grid * span), pub, 100 * pub / (grid * span)))
+    return us, lus
+
+
+def sweep(net, label):
+    say("== sweep %s" % label)
+    for target in (256, 512, 768):
+        for min_steps in (8, 16, 32):
+            os.environ["PTX_PROG_TARGET_ITEMS"], os.environ["PTX_PROG_MIN_STEPS"] = str(target), str(min_steps)
+            arr, info, ws, image, desc = build_program(net)
+            row = []
+            for wgs in (1, 2, 3):
+                fwd = lambda: L.check(lib.ptx_conv_program_fwd(C.byref(info), T._p(image), T._p(ws), wgs, T._st()), "p")   # noqa: E731
+                row.append(time_fn(fwd, 20))
+            lus = time_fn(launches_fn(net, desc), 20)
+            say("   target %4d min_steps %2d: items %5d  program wgs1/2/3 %7.1f %7.1f %7.1f us | launches (same tiles) %7.1f us   splits %s" % (
+                target, min_steps, info.total_items, row[0], row[1], row[2], lus, [int(l.split()[5]) for l in desc[1:]]))
+    os.environ.pop("PTX_PROG_TARGET_ITEMS", None)
+    os.environ.pop("PTX_PROG_MIN_STEPS", None)
+
+
+def nets(name):
+    if name == "layer3":       # resnet3d50 layer3.1-3.3 at config 2: M = 3136, identity blocks only
+        return T._bottlenecks(ptx, N=8, T=2, H=14, W=14, C0=1024, planes=256, blocks=3, stride_first=False, seed=90, first_dual=False)
+    if name == "layer4":
+        return T._bottlenecks(ptx, N=8, T=1, H=7, W=7, C0=2048, planes=512, blocks=3, stride_first=False, seed=91, first_dual=False)
+    if name == "2p1d":         # config 3 layer3.1-3.2: (2+1)D bottlenecks at M = 1568
+        net = T.Net(ptx, T._rnd(8, 1024, 4, 7, 7, seed=70))
+        x = 0
+        for b in range(2):
+            o = net.conv(x, 204, (1, 1, 1), (1, 1, 1), (0, 0, 0), 71 + 10 * b)
+            o = net.conv(o, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), 72 + 10 * b)
+            o = net.conv(o, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1), 73 + 10 * b)
+            o = net.conv(o, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), 74 + 10 * b)
+            o = net.conv(o, 204, (1, 1, 1), (1, 1, 1), (0, 0, 0), 75 + 10 * b)
+            x = net.conv(o, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), 76 + 10 * b, res=x)
+        return net
+    raise SystemExit(name)
+
+
 def plain_sanity():
     """The refactored tile body as a plain launch (library default tile) against ATen."""
     net = T._bottlenecks(ptx, N=2, T=2, H=10, W=10, planes=64, blocks=1, seed=5)
@@ -132,6 +253,13 @@ def case(name):
         return watch_program(T._bottlenecks(ptx, N=8, T=4, H=28, W=28, C0=512, planes=256, blocks=3, seed=90), limit=20)
     if name == "layer4":
         return watch_program(T._bottlenecks(ptx, N=8, T=2, H=14, W=14, C0=1024, planes=512, blocks=3, seed=90), limit=20)
+    if name.startswith("trace:"):
+        net = nets(name[6:])
+        for wgs in (1, 2, 3):
+            trace_program(net, wgs, label=name[6:])
+        return
+    if name.startswith("sweep:"):
+        return sweep(nets(name[6:]), name[6:])
     raise SystemExit("unknown case " + name)
 
 

@@ -281,7 +281,7 @@ class Net:
         return t[..., :Cc].permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
-def _bottlenecks(ptx, N=4, T=2, H=14, W=14, C0=256, planes=64, blocks=3, stride_first=True, seed=10):
+def _bottlenecks(ptx, N=4, T=2, H=14, W=14, C0=256, planes=64, blocks=3, stride_first=True, seed=10, first_dual=True):
     """`blocks` ResNet3D bottlenecks: block 0 strided with shortcut B fused as a second K source (what the engine emits),
     the others with an identity residual.  resnet3D.py:125-143, :175-185."""
     net = Net(ptx, _rnd(N, C0, T, H, W, seed=seed))
@@ -290,7 +290,7 @@ def _bottlenecks(ptx, N=4, T=2, H=14, W=14, C0=256, planes=64, blocks=3, stride_
         s = (2, 2, 2) if (b == 0 and stride_first) else (1, 1, 1)
         o = net.conv(x, planes, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed + 10 * b + 1)
         o = net.conv(o, planes, (3, 3, 3), s, (1, 1, 1), seed + 10 * b + 2)
-        if b == 0:
+        if b == 0 and first_dual:
             x = net.conv(o, planes * 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed + 10 * b + 3, x2=x, x2_stride=s[0])
         else:
             x = net.conv(o, planes * 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed + 10 * b + 3, res=x)
