@@ -191,9 +191,10 @@ int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tai
  * quantisation on 256 CUs and per-launch ramps rather than by the matrix cores.  Replaces the op sequence of whole
  * bottlenecks:  conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu, block after block
  * (resnet3D.py:125-143 with shortcut B :175-185; the six factored GEMMs of a (2+1)D bottleneck, r2plus1d.py:68-88).
- * The tiles of all stages sit on one queue in stage order; persistent workgroups take them in order and a tile waits only for
- * the ROW TILES of the producing stages it reads (per-row-tile completion counters), so consecutive stages overlap and no grid
- * barrier exists -- the launch completes for any grid size (csrc/conv_program.hip).  Arithmetic and k-order are those of
+ * The tiles of all stages sit on one queue -- in wavefront order over (stage, clip group), so tiles of several stages are
+ * runnable at any time -- persistent workgroups take them in order and a tile waits only for the ROW TILES of the producing
+ * stages it reads (per-row-tile completion counters); no grid barrier exists, the launch completes for any grid size
+ * (csrc/conv_program.hip).  Arithmetic and k-order are those of
  * ptx_conv3d_fwd on the same tile and split: results are bit-identical to the stage-by-stage launches.
  *   stage.tile     index into ptx_conv_program_tile_name (the tile shapes compiled into the program kernel), < 0: library's pick
  *   stage.split_k  <= 0: library's pick.  Split-K stages reduce in-launch (last arriver, split order).
@@ -223,7 +224,7 @@ typedef struct ptx_conv_program_info {
     int32_t ctrl_words;              /* 32-bit words at the head of the workspace zeroed per launch   */
     int32_t lds_bytes;               /* dynamic LDS of the program kernel                             */
     int32_t launches_replaced;       /* conv + split-K reduce launches the program stands for         */
-    int32_t reserved;
+    int32_t n_chunks;                /* (stage, clip group) runs of the queue                         */
     uint64_t image_bytes, workspace_bytes;
 } ptx_conv_program_info;
 

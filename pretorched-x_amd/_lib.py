@@ -55,7 +55,7 @@ class ConvStage(C.Structure):
 class ConvProgramInfo(C.Structure):
     """ptx_conv_program_info: sizes of a planned / built conv program."""
     _fields_ = [("n_stages", C.c_int32), ("total_items", C.c_int32), ("ctrl_words", C.c_int32), ("lds_bytes", C.c_int32),
-                ("launches_replaced", C.c_int32), ("reserved", C.c_int32), ("image_bytes", C.c_uint64),
+                ("launches_replaced", C.c_int32), ("n_chunks", C.c_int32), ("image_bytes", C.c_uint64),
                 ("workspace_bytes", C.c_uint64)]
 
 

@@ -112,13 +112,12 @@ def time_fn(fn, reps=30):
 
 def launches_fn(net, desc):
     """closure running the stages one launch each on the tiles / splits the plan names"""
-    names = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
     null = C.c_void_p(0)
     calls = []
     keep = []
     for s, line in zip(net.stages, desc[1:]):
         f = line.split()
-        cfg, split = names[f[3]], int(f[5])
+        cfg, split = T.conv_config_for(lib, f[3]), int(f[5])
         d = s["d"]
         nb = lib.ptx_conv3d_workspace_bytes(C.byref(d), max(split, 1))
         ws = torch.empty(max(nb // 4, 4), device=DEV)
@@ -186,6 +185,60 @@ def sweep(net, label):
                 target, min_steps, info.total_items, row[0], row[1], row[2], lus, [int(l.split()[5]) for l in desc[1:]]))
     os.environ.pop("PTX_PROG_TARGET_ITEMS", None)
     os.environ.pop("PTX_PROG_MIN_STEPS", None)
+
+
+def tune(net, kinds, label, rounds=2):
+    """Coordinate descent over (tile, split) per stage KIND (stages of the same kind share the choice), program time as the
+    objective; then the groups / workgroups-per-CU grid on the winner.  Prints every improvement."""
+    say("== tune %s" % label)
+    ntiles = lib.ptx_conv_program_num_tiles()
+    names = [lib.ptx_conv_program_tile_name(i).decode() for i in range(ntiles)]
+    nk = max(kinds) + 1
+    choice = [(-1, 0)] * nk
+
+    def measure(ch, wgs_list=(2, 3), reps=10):
+        tiles = [ch[k][0] for k in kinds]
+        splits = [ch[k][1] for k in kinds]
+        try:
+            arr, info, ws, image, desc = build_program(net, tiles, splits)
+        except Exception as e:      # noqa: BLE001
+            return None, None, str(e)
+        best = None
+        for wgs in wgs_list:
+            fwd = lambda: L.check(lib.ptx_conv_program_fwd(C.byref(info), T._p(image), T._p(ws), wgs, T._st()), "p")   # noqa: E731
+            t = time_fn(fwd, reps)
+            if best is None or t < best[0]:
+                best = (t, wgs)
+        return best[0], best[1], desc
+
+    cur, wg, desc = measure(choice)
+    say("   start (library defaults): %.1f us (wgs %d)" % (cur, wg))
+    for r in range(rounds):
+        for k in range(nk):
+            for tile in range(ntiles):
+                for split in (1, 2, 3, 4, 6, 8):
+                    trial = list(choice)
+                    trial[k] = (tile, split)
+                    t, w, _ = measure(trial)
+                    if t is not None and t < cur * 0.995:
+                        cur, wg, choice = t, w, trial
+                        say("   round %d kind %d -> %-28s split %d : %.1f us (wgs %d)" % (r, k, names[tile], split, t, w))
+    say("   best per kind: %s" % [(names[t] if t >= 0 else "auto", sp) for t, sp in choice])
+    for groups in ("1", "2", "4", "8"):
+        os.environ["PTX_PROG_GROUPS"] = groups
+        row = []
+        for wgs in (1, 2, 3):
+            t, _, d = measure(choice, (wgs,), 20)
+            row.append(t)
+        say("   groups %s: wgs1/2/3 %7.1f %7.1f %7.1f us   %s" % (groups, row[0], row[1], row[2], d[0]))
+    os.environ.pop("PTX_PROG_GROUPS", None)
+    tiles = [choice[k][0] for k in kinds]
+    splits = [choice[k][1] for k in kinds]
+    arr, info, ws, image, desc = build_program(net, tiles, splits)
+    say("   launches on the same tiles / splits: %.1f us" % time_fn(launches_fn(net, desc), 20))
+    for wgs in (2, 3):
+        trace_program(net, wgs, tiles, splits, label=label + " tuned")
+    return choice
 
 
 def nets(name):
@@ -260,6 +313,10 @@ def case(name):
         return
     if name.startswith("sweep:"):
         return sweep(nets(name[6:]), name[6:])
+    if name.startswith("tune:"):
+        net = nets(name[5:])
+        per_block = 6 if name[5:] == "2p1d" else 3
+        return tune(net, [i % per_block for i in range(len(net.stages))], name[5:])
     raise SystemExit("unknown case " + name)
 
 

@@ -70,7 +70,7 @@ def test_struct_layouts_match_header(ptx):
     assert C.sizeof(L.ConvStage) == C.sizeof(L.ConvDesc) + 6 * 8 + 8 and C.sizeof(L.ConvDesc) % 8 == 0   # desc, six pointers, tile, split_k
     assert [f for f, _ in L.ConvStage._fields_] == ["desc", "x", "x2", "w_packed", "bias", "res", "y", "tile", "split_k"]
     assert [f for f, _ in L.ConvProgramInfo._fields_] == ["n_stages", "total_items", "ctrl_words", "lds_bytes", "launches_replaced",
-                                                         "reserved", "image_bytes", "workspace_bytes"] and C.sizeof(L.ConvProgramInfo) == 40
+                                                         "n_chunks", "image_bytes", "workspace_bytes"] and C.sizeof(L.ConvProgramInfo) == 40
     assert C.sizeof(L.RgbConvDesc) == 4 * len(L.RgbConvDesc._fields_)
     assert C.sizeof(L.ConvDesc) == 4 * len(L.ConvDesc._fields_)
     assert C.sizeof(L.PoolDesc) == 4 * len(L.PoolDesc._fields_)

@@ -46,9 +46,22 @@ def _arr(L, stages):
 
 
 def _describe(L, lib, arr):
+    """Plan as text: line 0 the totals, one "stage ..." line per stage, a last "queue <stage>.<group> ..." line."""
     buf = C.create_string_buffer(1 << 16)
     L.check(lib.ptx_conv_program_describe(arr, len(arr), buf, len(buf)), "describe")
     return buf.value.decode().splitlines()
+
+
+def conv_config_for(lib, tile_name):
+    """The ptx_conv3d_fwd tile configuration that computes what a program tile computes: same BM x BN x BK / waves / MFMA
+    shape, hence the same k-order and the same split-K boundaries -- the LDS ring depth (dma / dma3 / dma4) does not change
+    a single rounding (tests/test_gpu_kernels.py: test_conv_dma_bit_exact_vs_register_staged)."""
+    names = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
+    shape = "/".join(tile_name.split("/")[:3])
+    for cand in (tile_name, shape + "/dma/re", shape + "/dma"):
+        if cand in names:
+            return names[cand]
+    raise KeyError(tile_name)
 
 
 # ------------------------------------------------------------------------------------------ host-only planner tests
@@ -77,7 +90,7 @@ def test_planner_dependencies_and_sizes(ptx):
     # halo of the 3x3x3 stage: (1*7 + 1)*7 + 1 rows either side
     assert " halo 57 57 " in lines[2]
     # queue length = sum over stages of tiles x splits, as described per stage
-    assert info.total_items == sum(int(l.split(" items ")[1].split()[0]) for l in lines[1:])
+    assert info.total_items == sum(int(l.split(" items ")[1].split()[0]) for l in lines[1:] if l.startswith("stage"))
     # a second block whose residual IS stage 2's output: a "res" dependency on top of the input one
     d4 = _desc(L, 2, 2, 7, 7, 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     d5 = _desc(L, 2, 2, 7, 7, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), res=True)
@@ -85,6 +98,36 @@ def test_planner_dependencies_and_sizes(ptx):
     lines = _describe(L, lib, _arr(L, more))
     assert lines[4].split("deps")[1].split() == ["2:x"]
     assert sorted(lines[5].split("deps")[1].split()) == ["2:res", "3:x"]
+
+
+def test_planner_wavefront_queue(ptx, monkeypatch):
+    """The queue is a topological order of (stage, clip group) chunks: diagonal stage + group ascending, higher group first
+    within a diagonal; PTX_PROG_GROUPS=1 gives plain stage order; every stage's tiles are queued exactly once."""
+    L, lib = ptx._lib, ptx._lib.lib()
+    N, T, H, W = 8, 2, 7, 7                      # 98 rows per clip: 32-row tiles straddle clips
+    A = [0x10000000 + i * 0x1000000 for i in range(12)]
+    d1 = _desc(L, N, T, H, W, 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    d2 = _desc(L, N, T, H, W, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    d3 = _desc(L, N, T, H, W, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), res=True)
+    arr = _arr(L, [_stage(L, d1, A[0], A[4], A[5], A[1]), _stage(L, d2, A[1], A[6], A[7], A[2]),
+                   _stage(L, d3, A[2], A[8], A[9], A[3], res=A[0])])
+    lines = _describe(L, lib, arr)
+    head = dict(zip(lines[0].split()[0::2], lines[0].split()[1::2]))
+    groups = int(head["groups"])
+    assert groups == 4 and int(head["clips_per_group"]) == 2            # 98-row clips: two per group hold a 112-row tile
+    q = [tuple(int(v) for v in c.split(".")) for c in lines[-1].split()[1:]]
+    assert len(q) == int(head["chunks"]) == 3 * groups and len(set(q)) == len(q)
+    diag = [s + g for s, g in q]
+    assert diag == sorted(diag)
+    for a, b in zip(q, q[1:]):
+        if a[0] + a[1] == b[0] + b[1]:
+            assert a[1] > b[1]
+    info = L.ConvProgramInfo()
+    L.check(lib.ptx_conv_program_plan(arr, 3, C.byref(info)), "plan")
+    assert info.n_chunks == len(q)
+    monkeypatch.setenv("PTX_PROG_GROUPS", "1")
+    lines = _describe(L, lib, arr)
+    assert lines[-1].split()[1:] == ["0.0", "1.0", "2.0"]
 
 
 def test_planner_refusals(ptx):
@@ -117,9 +160,10 @@ def test_planner_refusals(ptx):
 def test_planner_tile_names_are_conv_tiles(ptx):
     """Every tile shape of the program kernel is a tile configuration of ptx_conv3d_fwd: the bit-exactness contract names it."""
     lib = ptx._lib.lib()
-    conv_names = {lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())}
     names = [lib.ptx_conv_program_tile_name(i).decode() for i in range(lib.ptx_conv_program_num_tiles())]
-    assert names and all(n in conv_names for n in names)
+    assert names and len(set(names)) == len(names)
+    for n in names:
+        assert lib.ptx_conv3d_config_name(conv_config_for(lib, n)).decode().split("/")[:3] == n.split("/")[:3]
 
 
 # ------------------------------------------------------------------------------------------ GPU parity
@@ -258,12 +302,11 @@ class Net:
     def run_launches(self, desc_lines):
         """The same convs one launch each, on the tile / split the program's plan reports."""
         L, lib = self.L, self.lib
-        names = {lib.ptx_conv3d_config_name(i).decode(): i for i in range(lib.ptx_conv3d_num_configs())}
         self.clear()
         null = C.c_void_p(0)
         for s, line in zip(self.stages, desc_lines[1:]):
             f = line.split()
-            cfg, split = names[f[3]], int(f[5])
+            cfg, split = conv_config_for(lib, f[3]), int(f[5])
             d = s["d"]
             nb = lib.ptx_conv3d_workspace_bytes(C.byref(d), max(split, 1))
             ws = torch.empty(max(nb // 4, 4), device=DEV)
