@@ -149,11 +149,15 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
     unsigned* const err = ctrl + 1;
     // Every loop-control decision below is made on a value that was broadcast through LDS and read back with
     // readfirstlane: scalar branches, the same path for all four waves, so every wave meets every barrier.
-    if (tid == 0) lc[0] = (int)__hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    int item = __builtin_amdgcn_readfirstlane(lc[0]);
     int c = 0;                                             // chunk of the last item: queue indices only grow
-    while (item < total_items) {
+    for (;;) {
+        // One queue index at a time, taken when the workgroup is free.  (Taking the next index early, to hide the atomic's
+        // round trip under the tile, was measured 1.5-2.7x SLOWER: an index held by a busy workgroup is a tile nobody
+        // else may run, and its consumers wait for it -- profiles/r05_program_probe.txt.)
+        if (tid == 0) lc[0] = (int)__hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(lc[0]);
+        if (item >= total_items) break;
         unsigned long long* const tr = trace ? trace + (size_t)item * 8 : nullptr;
         if (tr && tid == 0) tr[0] = wall_clock64();
         while (item >= chunk_begin[c + 1]) ++c;
@@ -167,10 +171,6 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         const int tile = ch.mt_begin * p.n_tiles + li / split;
         const int m_tile = tile / p.n_tiles;
         const int bm = S->bm;
-        // ---- take the NEXT queue index now: its round trip hides under this tile (indices are still handed out in
-        // order, and this workgroup runs them in order, so the progress argument of the file header holds)
-        int next_v = 0;
-        if (tid == 0) next_v = (int)__hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- wait for the producers' row tiles this tile reads (one wave polls, relaxed, backing off)
         if (wave == 0) {
             const int m0 = m_tile * bm, m1 = min(m0 + bm, p.M) - 1;
@@ -209,9 +209,8 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
                             ok = 0;
                         }
                         // a waiting workgroup shares its CU with working ones: poll rarely (polling-cost, MI355X_MICROARCH.md)
-                        if (spins < 4u) __builtin_amdgcn_s_sleep(8);
-                        else if (spins < 16u) __builtin_amdgcn_s_sleep(32);
-                        else __builtin_amdgcn_s_sleep(96);
+                        if (spins < 8u) __builtin_amdgcn_s_sleep(8);
+                        else __builtin_amdgcn_s_sleep(32);
                     }
                 }
             }
@@ -236,9 +235,7 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         }
         // ---- publish: every storing wave drains its write-through stores, then one lane counts
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) lc[0] = next_v;
         __syncthreads();
-        item = __builtin_amdgcn_readfirstlane(lc[0]);
         if (tr && tid == 0) tr[2] = wall_clock64();
         int publish = 1;
         if (split > 1) {
