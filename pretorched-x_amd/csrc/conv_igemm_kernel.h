@@ -72,7 +72,8 @@ inline void fastdiv_make(unsigned d, unsigned (&out)[2]) {
     out[0] = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
     out[1] = l - 1;
 }
-__device__ __forceinline__ unsigned fastdiv(unsigned n, const unsigned (&dv)[2]) {
+template <class DV>      // unsigned[2] in any address space (kernel argument, or a constant-address-space stage table)
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const DV& dv) {
     return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
 }
 
@@ -504,9 +505,12 @@ static __device__ unsigned long long* g_ig_tl = nullptr;
 // loads, write-through on stores) inside a conv program, whose stages hand tensors to each other without a kernel boundary
 // (cdna_hip_programming.md Guideline 16: sc1 stores + drained flag on the producer, sc1 loads on the consumer).
 // Filters and biases are read-only for the whole launch and keep the default policy.
+// Args: ConvArgs as a kernel argument (plain launch), or the same struct read through a constant-address-space reference
+// (conv program: the stage table in global memory is never written during the launch, so its fields are scalar loads the
+// compiler may repeat instead of keeping ~120 SGPRs alive across the k-loop -- a by-value copy spilled 269 of them).
 template <int BM, int BN, int BK, int WM, int WN, int MT, bool KTAIL, bool K22, bool DMA, int NSTAGE, bool F16 = false,
-          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false, int COH = 0>
-__device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const int tile, const int zb, const int zs, float* smem) {
+          bool X3 = false, int KWR = 0, bool CHAIN = false, bool REPI = false, int COH = 0, class Args = ConvArgs>
+__device__ __forceinline__ void conv_igemm_tile(const Args& p, const int tile, const int zb, const int zs, float* smem) {
     PTX_IG_TL(0);
     PTX_IG_TL(6);
     static_assert(!CHAIN || (DMA && NSTAGE == 2 && !F16 && !K22), "chained tail: fp32 / split-operand 2-stage LDS-DMA tiles");
@@ -1461,6 +1465,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const int til
     // which block happens to be last -- applies the epilogue and writes y.  No second launch.  Release / acquire:
     // device-scope fences around one atomic arrival counter per tile; the last block leaves the counter at zero.
     PTX_IG_TL_END();
+    if constexpr (COH == 0)
     if (to_partial && p.counters) {
         __threadfence();
         __syncthreads();

@@ -71,10 +71,8 @@ static const ProgTileShape kProgTiles[] = {
     {32, 64, 64, 2, 2, 2, "32x64x64/2x2/m16/dma/re"},
     {32, 128, 32, 2, 2, 2, "32x128x32/2x2/m16/dma/re"},
     {32, 64, 32, 2, 2, 2, "32x64x32/2x2/m16/dma/re"},
-    {32, 64, 32, 2, 2, 4, "32x64x32/2x2/m16/dma4/re"},
     {32, 128, 32, 2, 2, 3, "32x128x32/2x2/m16/dma3/re"},
     {32, 64, 64, 2, 2, 3, "32x64x64/2x2/m16/dma3/re"},
-    {112, 64, 32, 1, 4, 2, "112x64x32/1x4/m16/dma/re"},
 };
 constexpr int kNumProgTiles = sizeof(kProgTiles) / sizeof(kProgTiles[0]);
 constexpr int kProgLdsCtrlBytes = 64;
@@ -83,6 +81,8 @@ static int prog_tile_lds(const ProgTileShape& t) {
     const int epi = t.WM * t.WN * 16 * (t.BN / t.WN + 4) * 4;         // the row-major epilogue parks one 16-row block per wave
     return tiles > epi ? tiles : epi;
 }
+
+typedef const __attribute__((address_space(4))) ConvArgs ProgArgs;       // the stage table, read as constant memory
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -100,7 +100,7 @@ __device__ __forceinline__ int prog_in_row(int m, int To, int Ho, int Wo, int Ti
 }
 
 // last arriver of a split-K tile: y = epilogue(sum of the partial tiles in split order)
-__device__ __forceinline__ void prog_reduce_tile(const ConvArgs& p, int BM, int BN, int tile, int tid) {
+__device__ __forceinline__ void prog_reduce_tile(const ProgArgs& p, int BM, int BN, int tile, int tid) {
     constexpr unsigned kOOB = 0x80000000u;
     const int m0 = (tile / p.n_tiles) * BM, n0 = (tile % p.n_tiles) * BN;
     const size_t slab = (size_t)p.M * p.ncol;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void prog_reduce_tile(const ConvArgs& p, int BM, int 
 }
 
 #define PTX_PROG_TILE(BM, BN, BK, WM, WN, NS) \
-    conv_igemm_tile<BM, BN, BK, WM, WN, 16, true, false, true, NS, false, false, 0, false, true, kCoh>
+    conv_igemm_tile<BM, BN, BK, WM, WN, 16, true, false, true, NS, false, false, 0, false, true, kCoh, ProgArgs>
 
 __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __restrict__ stages, const ProgChunk* __restrict__ chunks,
                                                           const int* __restrict__ chunk_begin, const int total_items, unsigned* ctrl,
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
         const ProgChunk ch = chunks[c];
         const int s = ch.stage;
         const ProgStage* const S = stages + s;
-        const ConvArgs p = S->a;                          // by value: registers, immune to the stores below
+        const ProgArgs& p = *(ProgArgs*)(&S->a);           // constant address space: scalar loads, nothing to keep alive
         const int li = item - chunk_begin[c];
         const int split = p.split_k;
         const int zs = li % split;
@@ -228,10 +228,8 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
             case 0: PTX_PROG_TILE(32, 64, 64, 2, 2, 2)(p, tile, 0, zs, smem); break;
             case 1: PTX_PROG_TILE(32, 128, 32, 2, 2, 2)(p, tile, 0, zs, smem); break;
             case 2: PTX_PROG_TILE(32, 64, 32, 2, 2, 2)(p, tile, 0, zs, smem); break;
-            case 3: PTX_PROG_TILE(32, 64, 32, 2, 2, 4)(p, tile, 0, zs, smem); break;
-            case 4: PTX_PROG_TILE(32, 128, 32, 2, 2, 3)(p, tile, 0, zs, smem); break;
-            case 5: PTX_PROG_TILE(32, 64, 64, 2, 2, 3)(p, tile, 0, zs, smem); break;
-            default: PTX_PROG_TILE(112, 64, 32, 1, 4, 2)(p, tile, 0, zs, smem); break;
+            case 3: PTX_PROG_TILE(32, 128, 32, 2, 2, 3)(p, tile, 0, zs, smem); break;
+            default: PTX_PROG_TILE(32, 64, 64, 2, 2, 3)(p, tile, 0, zs, smem); break;
         }
         // ---- publish: every storing wave drains its write-through stores, then one lane counts
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
