@@ -516,6 +516,17 @@ class AltStep:
         return [self.chain] if self.use_chain else list(self.pair)
 
 
+def prog_lookup(key):
+    ent = _tuned_table().get("prog:" + key)
+    return None if ent is None else ent[0] == "program"
+
+
+def prog_store(key, use_program):
+    table = _tuned_table()
+    with _tuned_lock:
+        table["prog:" + key] = ("program" if use_program else "launches", 1)
+
+
 def alt_lookup(key):
     ent = _tuned_table().get("alt:" + key)
     return None if ent is None else ent[0] == "chain"
@@ -532,7 +543,7 @@ class ProgramStep:
     tiles of all its convs on one queue, per-row-tile dependencies instead of kernel boundaries.  `convs` are the launches it
     stands for -- still complete ConvSteps, run instead when `use_program` is off (PTX_PROGRAM=0, or the tuner measured the
     launches faster)."""
-    __slots__ = ("convs", "use_program", "label", "macs", "hbm_bytes", "info", "image", "ws", "wgs", "plan", "stages", "kernel")
+    __slots__ = ("convs", "use_program", "label", "macs", "hbm_bytes", "info", "image", "ws", "wgs", "plan", "stages", "kernel", "key")
 
     def __call__(self, st):
         if self.use_program:
@@ -1466,7 +1477,10 @@ class Plan:
         output rows by ONE ProgramStep (conv_program.hip).  A run ends at anything that is not such a conv (attention,
         pooling, chained pairs, fp16 / split-operand stages) and at a conv the library refuses (its message names the
         rule); the replaced ConvSteps stay inside the ProgramStep as its fallback and as the record of what it computes."""
-        if os.environ.get("PTX_PROGRAM", "1") == "0" or torch.device(self.dev).type != "cuda" or self.x3:
+        # PTX_PROGRAM: "0" never build programs; "auto" (default) build them and run whichever of {program, its launches} the
+        # tuner measured faster (tuned table "prog:" keys; the launches until measured); "1" / "force" always the program
+        mode = os.environ.get("PTX_PROGRAM", "auto")
+        if mode == "0" or torch.device(self.dev).type != "cuda" or self.x3:
             return
         max_m = int(os.environ.get("PTX_PROGRAM_MAX_M", "4096"))
         min_n = int(os.environ.get("PTX_PROGRAM_MIN_STAGES", "2"))
@@ -1506,7 +1520,10 @@ class Plan:
             ps.label = "%s..%s" % (run[0].label, run[-1].label)
             ps.macs, ps.hbm_bytes = sum(c.macs for c in run), 0
             ps.kernel = "conv_program/%dstages/%dtiles" % (len(run), info.total_items)
-            ps.use_program = True
+            import hashlib
+            ps.key = hashlib.sha1(json.dumps([list(c.d.key()) for c in run]).encode()).hexdigest()[:20]
+            known = prog_lookup(ps.key)
+            ps.use_program = mode in ("1", "force") or (known is True)
             return ps
 
         out, run = [], []
@@ -1908,7 +1925,8 @@ class Engine:
                 return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
                    for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
-                    or any(alt_lookup(a.key) is None for a in plan.alt_steps):
+                    or any(alt_lookup(a.key) is None for a in plan.alt_steps) \
+                    or (os.environ.get("PTX_PROGRAM", "auto") == "auto" and any(prog_lookup(p.key) is None for p in plan.program_steps)):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
 
@@ -2203,6 +2221,31 @@ class Engine:
                     log.write("%s\tchain %.4f ms\tpair %.4f ms\t-> %s\n" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
                 if verbose:
                     print("tune %-34s chain %.4f ms | pair %.4f ms -> %s" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
+            # conv program vs the launches it replaces: time both executions of every run, keep the faster (same margin rule)
+            pmode = os.environ.get("PTX_PROGRAM", "auto")
+            for ps in plan.program_steps:
+                if pmode != "auto" or (only_untuned and prog_lookup(ps.key) is not None):
+                    continue
+                ms2 = []
+                for flag in (True, False):
+                    ps.use_program = flag
+                    ps(_stream())
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(max(iters, 5)):
+                        ps(_stream())
+                    e1.record()
+                    e1.synchronize()
+                    ms2.append(e0.elapsed_time(e1) / max(iters, 5))
+                ps.use_program = ms2[0] < 0.97 * ms2[1]
+                if ps.error() is not None:
+                    ps.use_program = False
+                prog_store(ps.key, ps.use_program)
+                if log is not None:
+                    log.write("%s\tprogram %.4f ms\tlaunches %.4f ms\t-> %s\n" % (ps.label, ms2[0], ms2[1], "program" if ps.use_program else "launches"))
+                if verbose:
+                    print("tune %-44s program %.4f ms | %d launches %.4f ms -> %s" % (ps.label, ms2[0], len(ps.convs), ms2[1],
+                                                                                      "program" if ps.use_program else "launches"))
             plan.run_features(_dense16(x))
             plan.tuned = True
             if log is not None:

@@ -241,6 +241,64 @@ def tune(net, kinds, label, rounds=2):
     return choice
 
 
+def auto_launches(net, stream_ptr_fn):
+    """the stages one launch each on the library's own tile pick (what a plan without a tuned-table hit runs)"""
+    null = C.c_void_p(0)
+    calls, keep = [], []
+    for s in net.stages:
+        d = s["d"]
+        sk = C.c_int(1)
+        cfg = lib.ptx_conv3d_pick_config(C.byref(d), C.byref(sk))
+        nb = lib.ptx_conv3d_workspace_bytes(C.byref(d), max(sk.value, 1))
+        ws = torch.empty(max(nb // 4, 4), device=DEV)
+        keep.append(ws)
+        x, y = T._p(net.acts[s["src"]]), T._p(net.acts[s["y"]])
+        if s["x2"] is not None:
+            calls.append((lib.ptx_conv3d_dual_fwd, (C.byref(d), x, T._p(net.acts[s["x2"]]), T._p(s["w"]), T._p(s["b"]), y, T._p(ws), nb, cfg, sk.value)))
+        else:
+            r = T._p(net.acts[s["res"]]) if s["res"] is not None else null
+            calls.append((lib.ptx_conv3d_fwd, (C.byref(d), x, T._p(s["w"]), T._p(s["b"]), r, y, T._p(ws), nb, cfg, sk.value)))
+
+    def run():
+        st = stream_ptr_fn()
+        for f_, a in calls:
+            L.check(f_(*a, st), "launch")
+    run.keep = keep
+    return run
+
+
+def streams_case(make_net, label):
+    """One full-batch chain on one stream vs the same work as two half-batch chains on two streams (clips are independent):
+    does the hardware's own scheduler overlap the small launches of different stages?"""
+    say("== streams %s" % label)
+    full = make_net(8)
+    halves = [make_net(4), make_net(4)]
+    main = torch.cuda.current_stream()
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    f_full = auto_launches(full, lambda: C.c_void_p(main.cuda_stream))
+    f_half = [auto_launches(h, (lambda s_: (lambda: C.c_void_p(s_.cuda_stream)))(s_)) for h, s_ in zip(halves, side)]
+    ev0, ev = torch.cuda.Event(), [torch.cuda.Event(), torch.cuda.Event()]
+
+    def two_streams():
+        ev0.record(main)
+        for i in range(2):
+            side[i].wait_event(ev0)
+            f_half[i]()
+            ev[i].record(side[i])
+        for i in range(2):
+            main.wait_event(ev[i])
+
+    def one_stream_halves():
+        for i in range(2):
+            auto_main[i]()
+    auto_main = [auto_launches(h, lambda: C.c_void_p(main.cuda_stream)) for h in halves]
+    t_full = time_fn(f_full, 30)
+    t_two = time_fn(two_streams, 30)
+    t_seq = time_fn(one_stream_halves, 30)
+    say("   full batch, one stream: %.1f us | two half-batch chains on two streams: %.1f us (%.2fx) | the halves back to back on one stream: %.1f us" % (
+        t_full, t_two, t_full / t_two, t_seq))
+
+
 def nets(name):
     if name == "layer3":       # resnet3d50 layer3.1-3.3 at config 2: M = 3136, identity blocks only
         return T._bottlenecks(ptx, N=8, T=2, H=14, W=14, C0=1024, planes=256, blocks=3, stride_first=False, seed=90, first_dual=False)
@@ -313,6 +371,25 @@ def case(name):
         return
     if name.startswith("sweep:"):
         return sweep(nets(name[6:]), name[6:])
+    if name.startswith("streams:"):
+        kind = name[8:]
+        if kind == "layer3":
+            mk = lambda n: T._bottlenecks(ptx, N=n, T=2, H=14, W=14, C0=1024, planes=256, blocks=3, stride_first=False, seed=90, first_dual=False)   # noqa: E731
+        elif kind == "layer4":
+            mk = lambda n: T._bottlenecks(ptx, N=n, T=1, H=7, W=7, C0=2048, planes=512, blocks=3, stride_first=False, seed=91, first_dual=False)   # noqa: E731
+        else:
+            def mk(n):
+                net = T.Net(ptx, T._rnd(n, 1024, 4, 7, 7, seed=70))
+                x = 0
+                for b in range(2):
+                    o = net.conv(x, 204, (1, 1, 1), (1, 1, 1), (0, 0, 0), 71 + 10 * b)
+                    o = net.conv(o, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), 72 + 10 * b)
+                    o = net.conv(o, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1), 73 + 10 * b)
+                    o = net.conv(o, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), 74 + 10 * b)
+                    o = net.conv(o, 204, (1, 1, 1), (1, 1, 1), (0, 0, 0), 75 + 10 * b)
+                    x = net.conv(o, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), 76 + 10 * b, res=x)
+                return net
+        return streams_case(mk, kind)
     if name.startswith("tune:"):
         net = nets(name[5:])
         per_block = 6 if name[5:] == "2p1d" else 3

@@ -407,20 +407,29 @@ def test_program_full_size_layer4_and_stress(ptx):
 
 
 @gpu
-def test_engine_runs_the_tail_as_programs(ptx, monkeypatch):
-    """resnet3d50's layer3 / layer4 run as conv programs by default; logits agree with the launch-per-conv plan to fp32
-    summation-order noise (the program picks its own tiles / splits; same-tile bit-exactness is tested above)."""
+def test_engine_runs_the_tail_as_programs(ptx):
+    """resnet3d50's layer3 / layer4 compile to conv programs; which of {program, its launches} runs is the tuner's call
+    (PTX_PROGRAM=auto).  Forced either way the logits agree to fp32 summation-order noise (the program picks its own tiles /
+    splits; same-tile bit-exactness is tested above), and the program's error word stays clear."""
     import pretorched_x_amd as P
     torch.manual_seed(0)
     m = P.resnet3d50(num_classes=17, pretrained=None).eval().to(DEV)
     x = torch.randn(2, 3, 8, 112, 112, generator=torch.Generator().manual_seed(1)).to(DEV)
     with torch.no_grad():
-        y1 = m(x).clone()
+        m(x)
         plan = list(m.engine()._plans.values())[-1]
-        assert plan.program_steps and all(p.error() is None for p in plan.program_steps)
+        assert plan.program_steps
         n_prog = sum(len(p.convs) for p in plan.program_steps)
         assert n_prog >= 15, n_prog
+        outs = []
+        for flag in (True, False):
+            for p in plan.program_steps:
+                p.use_program = flag
+            outs.append(m(x).clone())
+            assert all(p.error() is None for p in plan.program_steps)
+        launches = len(plan.all_convs())
         for p in plan.program_steps:
-            p.use_program = False
-        y0 = m(x).clone()
+            p.use_program = True
+        assert len(plan.all_convs()) == launches - n_prog + len(plan.program_steps)
+    y1, y0 = outs
     assert (y0 - y1).abs().max().item() <= 1e-4 * max(1.0, y0.abs().max().item())
