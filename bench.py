@@ -369,7 +369,7 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
         # host-side twin of SQ_INSTS_MFMA x 4096 from the committed PMC pass
         issued_by_kernel = {}
         for stp in plan.steps:
-            if hasattr(stp, "issued_flop"):
+            if type(stp).__name__ == "StemF32Step":
                 issued_by_kernel[stp.kernel] = issued_by_kernel.get(stp.kernel, 0.0) + stp.issued_flop()
 
         def roof(name, ms, flop, launches):

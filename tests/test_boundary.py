@@ -202,7 +202,9 @@ def test_accelerate_golden_weights_through_a_foreign_instance(ptx):
         out2 = m.logits(feats)
     ref = torch.from_numpy(blob["logits"])
     assert (out.cpu() - ref).abs().max().item() <= 1e-3 and torch.equal(out.cpu().argmax(1), ref.argmax(1))
-    assert torch.equal(out, out2)
+    # forward() pools the channels-last feature map in the plan; features() -> logits() pools the NCDHW copy it returned:
+    # the same numbers in another summation order
+    assert (out - out2).abs().max().item() <= 1e-5 * max(1.0, out.abs().max().item())
     assert m.engine().plan_builds >= 1
     m.last_linear = ptx.utils.Identity()
     with torch.no_grad():
