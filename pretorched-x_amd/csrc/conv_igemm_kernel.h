@@ -479,6 +479,43 @@ __device__ __forceinline__ void rowmajor_store_tile(typename MF::acc_t (&acc)[TM
 // -DPTX_IGEMM_TIMELINE into a SEPARATE library; the product library carries none of it).  Thread 0 writes the 100 MHz wall clock
 // at: 0 entry, 1 operand tables built, 2 first tile landed, 3 last k-step done, 4 row-major epilogue past its wait, 5 stores
 // retired; 6 = __smid().
+// Last arriver of a split-K tile: y = epilogue(sum of the tile's partial slabs in SPLIT ORDER -- the order of
+// splitk_reduce_kernel, so fused and separate reductions are bit-identical).  The slabs were written write-through (sc1) by
+// other workgroups of this launch, possibly on other XCDs: read them (and a residual another stage of a conv program may
+// just have produced) with sc1 loads -- no fence (cdna_hip_programming.md Guideline 16, R1).
+template <class Args>
+__device__ __forceinline__ void splitk_reduce_tile(const Args& p, int BM, int BN, int tile, int tid, int nthreads) {
+    constexpr unsigned kOOB = 0x80000000u;
+    constexpr int kSc1 = 16;
+    const int m0 = (tile / p.n_tiles) * BM, n0 = (tile % p.n_tiles) * BN;
+    const size_t slab = (size_t)p.M * p.ncol;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((size_t)p.M * p.ldy * 4), 0x00020000);
+    const bool has_res = (p.flags & PTX_EPI_RES_ADD) != 0;
+    const __amdgpu_buffer_rsrc_t rs_r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, has_res ? p.r_bytes : 0u, 0x00020000);
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+#pragma unroll 1
+    for (int e = tid * 4; e < BM * BN; e += nthreads * 4) {
+        const int m = m0 + e / BN, co = n0 + e % BN;
+        const bool ok = co < p.ncol && m < p.M;
+        const unsigned poff = ok ? (unsigned)(((size_t)m * p.ncol + co) * 4) : kOOB;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int z = 0; z < p.split_k; ++z) {
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)z * slab, 0, p.y_bytes, 0x00020000);
+            const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, poff, 0, kSc1));
+            v = z == 0 ? u : v + u;
+        }
+        if (p.bias && ok) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+        const f32x4 r = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (ok && has_res) ? (unsigned)(((size_t)m * p.ldr + co) * 4) : kOOB, 0, kSc1));
+        v += r;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_y,
+                                               ok ? (unsigned)(((size_t)m * p.ldy + co) * 4) : kOOB, 0, kSc1);
+    }
+}
+
 #ifdef PTX_IGEMM_TIMELINE
 static __device__ unsigned long long* g_ig_tl = nullptr;
 #define PTX_IG_TL(k)                                                                                                   \
@@ -1422,6 +1459,27 @@ __device__ __forceinline__ void conv_igemm_tile(const Args& p, const int tile, c
             return;
         }
     }
+    bool partial_stored = false;
+    if constexpr (REPI && !CHAIN) {
+        if (to_partial) {
+            // split-K partial tile: the same row-major path, no bias / residual / ReLU, into this split's dense [M][ncol]
+            // slab -- 16-byte WRITE-THROUGH stores (sc1): the slab is read once, by another workgroup (the reduce kernel or
+            // the last arriver below), so it need not stay in this XCD's L2, and 4-byte sc1 stores would cost one fabric
+            // write each (MI355X_MICROARCH.md, stores of each flavour)
+            using RE = RowEpi<WTN, MT>;
+            const __amdgpu_buffer_rsrc_t rs_p =
+                __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)zs * p.M * p.ncol, 0, p.y_bytes, 0x00020000);
+            f32x4 res4[TM * RE::NP];
+#pragma unroll
+            for (int i = 0; i < TM * RE::NP; ++i) res4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            rowmajor_store_tile<MF, TM, TN, WTM, WTN, MT, 16>(acc, res4, smem + wave_u * RE::FLOATS, nullptr, rs_p, false,
+                                                              m0 + wm * WTM, n0 + wn * WTN, p.M, p.ncol, p.ncol, lane);
+            partial_stored = true;
+        }
+    }
+    if (!partial_stored) {
     float* ybase = to_partial ? p.partial + (size_t)zs * p.M * p.ncol : p.y + (size_t)zb * p.bs_y;
     const unsigned ldo = to_partial ? (unsigned)p.ncol : (unsigned)p.ldy;
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, p.y_bytes, 0x00020000);
@@ -1460,35 +1518,49 @@ __device__ __forceinline__ void conv_igemm_tile(const Args& p, const int tile, c
             }
         }
     }
+    }   // !partial_stored
     // ---- split-K, fused reduction (PTX_SPLITK_FUSED): the LAST split block to finish a tile sums the partial tiles of
     // all splits -- in split order, so the result is bit-identical to the separate reduce kernel and independent of
-    // which block happens to be last -- applies the epilogue and writes y.  No second launch.  Release / acquire:
-    // device-scope fences around one atomic arrival counter per tile; the last block leaves the counter at zero.
+    // which block happens to be last -- applies the epilogue and writes y.  No second launch.  Hand-off: write-through
+    // partial stores (above; the column-wise path of non-REPI tiles is followed by a release fence instead), every wave
+    // drains, the workgroup meets, ONE returning agent-scope atomic per workgroup on the tile's arrival counter; the last
+    // arriver reads the slabs with sc1 loads and leaves the counter at zero.  (Round 2's version bracketed the counter with
+    // two __threadfence() -- buffer_wbl2 + buffer_inv across 8 XCD L2s per workgroup -- and measured SLOWER than the
+    // reduce launch: 33 -> 54 us on layer4's 3x3x3.)
     PTX_IG_TL_END();
     if constexpr (COH == 0)
     if (to_partial && p.counters) {
-        __threadfence();
+        if (!partial_stored) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // plain b32 stores: write the L2 back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
         if (tid == 0) {
-            const unsigned prev = atomicAdd(p.counters + tile, 1u);
+            const unsigned prev = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = prev == (unsigned)p.split_k - 1u ? 1u : 0u;
-            if (last) atomicExch(p.counters + tile, 0u);
+            if (last) __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag[0] = last;
         }
         __syncthreads();
         if (!flag[0]) return;
-        __threadfence();
+        if (!(p.flags & PTX_EPI_RES_PADA)) {
+            splitk_reduce_tile(p, BM, BN, tile, tid, NT);
+            return;
+        }
+        // shortcut-A residual (a strided gather with zero channels above res_C): the element-wise epilogue of the reduce kernel
+        constexpr unsigned kOOBr = 0x80000000u;
         const size_t slab = (size_t)p.M * p.ncol;
-        // a plain loop over the tile's elements, 4 columns per thread (tiny code: this tail is instantiated per tile shape)
 #pragma unroll 1
         for (int e = tid * 4; e < BM * BN; e += NT * 4) {
             const int m = m0 + e / BN, co = n0 + e % BN;
             if (co < p.ncol && m < p.M) {
-                const float* src = p.partial + (size_t)m * p.ncol + co;
-                f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                const unsigned poff = (unsigned)(((size_t)m * p.ncol + co) * 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-                for (int z = 1; z < p.split_k; ++z) v += *reinterpret_cast<const f32x4*>(src + z * slab);
+                for (int z = 0; z < p.split_k; ++z) {
+                    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)z * slab, 0, p.y_bytes, 0x00020000);
+                    const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, poff < kOOBr ? poff : kOOBr, 0, 16));
+                    v = z == 0 ? u : v + u;
+                }
                 f32x4 o;
                 o.x = conv_epilogue(p, v.x, m, co);
                 o.y = conv_epilogue(p, v.y, m, co + 1);

@@ -99,38 +99,6 @@ __device__ __forceinline__ int prog_in_row(int m, int To, int Ho, int Wo, int Ti
     return ((n * Ti + to * sT) * Hi + ho * sH) * Wi + wo * sW;
 }
 
-// last arriver of a split-K tile: y = epilogue(sum of the partial tiles in split order)
-__device__ __forceinline__ void prog_reduce_tile(const ProgArgs& p, int BM, int BN, int tile, int tid) {
-    constexpr unsigned kOOB = 0x80000000u;
-    const int m0 = (tile / p.n_tiles) * BM, n0 = (tile % p.n_tiles) * BN;
-    const size_t slab = (size_t)p.M * p.ncol;
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((size_t)p.M * p.ldy * 4), 0x00020000);
-    const bool has_res = (p.flags & PTX_EPI_RES_ADD) != 0;
-    const __amdgpu_buffer_rsrc_t rs_r =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, has_res ? p.r_bytes : 0u, 0x00020000);
-    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
-#pragma unroll 1
-    for (int e = tid * 4; e < BM * BN; e += 256 * 4) {
-        const int m = m0 + e / BN, co = n0 + e % BN;
-        const bool ok = co < p.ncol && m < p.M;
-        const unsigned poff = ok ? (unsigned)(((size_t)m * p.ncol + co) * 4) : kOOB;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int z = 0; z < p.split_k; ++z) {
-            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)z * slab, 0, p.y_bytes, 0x00020000);
-            const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, poff, 0, kCoh));
-            v = z == 0 ? u : v + u;
-        }
-        if (p.bias && ok) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-        const f32x4 r = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (ok && has_res) ? (unsigned)(((size_t)m * p.ldr + co) * 4) : kOOB, 0, kCoh));
-        v += r;
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_y,
-                                               ok ? (unsigned)(((size_t)m * p.ldy + co) * 4) : kOOB, 0, kCoh);
-    }
-}
-
 #define PTX_PROG_TILE(BM, BN, BK, WM, WN, NS) \
     conv_igemm_tile<BM, BN, BK, WM, WN, 16, true, false, true, NS, false, false, 0, false, true, kCoh, ProgArgs>
 
@@ -244,7 +212,7 @@ __global__ void __launch_bounds__(256) conv_program_kernel(const ProgStage* __re
             __syncthreads();
             publish = __builtin_amdgcn_readfirstlane(lc[3]);
             if (publish) {
-                prog_reduce_tile(p, bm, S->bn, tile, tid);
+                splitk_reduce_tile(p, bm, S->bn, tile, tid, 256);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();

@@ -1497,6 +1497,10 @@ class Plan:
             return (d.flags & ~ok_flags) == 0 and d.groups <= 1 and d.N * d.To * d.Ho * d.Wo <= max_m
 
         def make(run):
+            import hashlib
+            key = hashlib.sha1(json.dumps([list(c.d.key()) for c in run]).encode()).hexdigest()[:20]
+            if mode == "auto" and prog_lookup(key) is False:
+                return False                 # measured before: the launches win -- no program, no workspace
             arr = (ConvStage * len(run))()
             for i, st in enumerate(run):
                 e = arr[i]
@@ -1520,8 +1524,7 @@ class Plan:
             ps.label = "%s..%s" % (run[0].label, run[-1].label)
             ps.macs, ps.hbm_bytes = sum(c.macs for c in run), 0
             ps.kernel = "conv_program/%dstages/%dtiles" % (len(run), info.total_items)
-            import hashlib
-            ps.key = hashlib.sha1(json.dumps([list(c.d.key()) for c in run]).encode()).hexdigest()[:20]
+            ps.key = key
             known = prog_lookup(ps.key)
             ps.use_program = mode in ("1", "force") or (known is True)
             return ps
@@ -1535,6 +1538,8 @@ class Plan:
             del run[:]
             while len(r) >= min_n:
                 ps = make(r)
+                if ps is False:
+                    break
                 if ps is not None:
                     out.append(ps)
                     self.program_steps.append(ps)
@@ -2086,6 +2091,23 @@ class Engine:
                 cands = [c for c in os.environ.get("PTX_TUNE_CANDIDATES", "").split(",") if c]
                 inc = tuned_lookup(key, kind) if cands else None
                 inc_ms = None
+                if inc is not None:
+                    # the incumbent is timed EXPLICITLY, up front: its split need not be among the splits the sweep below
+                    # tries for that tile, and without its time the 2 % rule would be skipped silently
+                    keep_cfg = (stp.cfg, stp.split, getattr(stp, "from_table", False))
+                    stp.cfg, stp.split, stp.from_table = inc[0], inc[1], False
+                    try:
+                        stp(_stream())
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(iters):
+                            stp(_stream())
+                        e1.record()
+                        e1.synchronize()
+                        inc_ms = e0.elapsed_time(e1) / iters
+                    except PtxError:
+                        inc = None                       # a stale entry this build refuses: nothing to defend
+                    stp.cfg, stp.split, stp.from_table = keep_cfg
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
                 M = stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo
                 ncol = _r4(stp.d.Co)                          # columns written (ldy is only the row stride)
@@ -2223,7 +2245,8 @@ class Engine:
                     print("tune %-34s chain %.4f ms | pair %.4f ms -> %s" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
             # conv program vs the launches it replaces: time both executions of every run, keep the faster (same margin rule)
             pmode = os.environ.get("PTX_PROGRAM", "auto")
-            for ps in plan.program_steps:
+            dissolved = []
+            for ps in list(plan.program_steps):
                 if pmode != "auto" or (only_untuned and prog_lookup(ps.key) is not None):
                     continue
                 ms2 = []
@@ -2241,11 +2264,16 @@ class Engine:
                 if ps.error() is not None:
                     ps.use_program = False
                 prog_store(ps.key, ps.use_program)
+                if not ps.use_program:       # the launches it stood for take its place; its workspace and image are freed
+                    i = plan.steps.index(ps)
+                    plan.steps[i:i + 1] = ps.convs
+                    dissolved.append(ps)
                 if log is not None:
                     log.write("%s\tprogram %.4f ms\tlaunches %.4f ms\t-> %s\n" % (ps.label, ms2[0], ms2[1], "program" if ps.use_program else "launches"))
                 if verbose:
                     print("tune %-44s program %.4f ms | %d launches %.4f ms -> %s" % (ps.label, ms2[0], len(ps.convs), ms2[1],
                                                                                       "program" if ps.use_program else "launches"))
+            plan.program_steps = [p_ for p_ in plan.program_steps if p_ not in dissolved]
             plan.run_features(_dense16(x))
             plan.tuned = True
             if log is not None:
