@@ -307,7 +307,7 @@ using namespace ptx;
 #ifndef PTX_SOURCE_SHA256
 #define PTX_SOURCE_SHA256 "unstamped"
 #endif
-extern "C" const char* ptx_version(void) { return "ptx_amd 0.4.0 (gfx950, fp32 MFMA) src:" PTX_SOURCE_SHA256; }
+extern "C" const char* ptx_version(void) { return "ptx_amd 0.5.0 (gfx950, fp32 MFMA) src:" PTX_SOURCE_SHA256; }
 extern "C" const char* ptx_last_error(void) { return last_error_buf(); }
 
 extern "C" size_t ptx_packed_weight_elems(const ptx_pack_desc* d) {

@@ -1477,9 +1477,10 @@ class Plan:
         output rows by ONE ProgramStep (conv_program.hip).  A run ends at anything that is not such a conv (attention,
         pooling, chained pairs, fp16 / split-operand stages) and at a conv the library refuses (its message names the
         rule); the replaced ConvSteps stay inside the ProgramStep as its fallback and as the record of what it computes."""
-        # PTX_PROGRAM: "0" never build programs; "auto" (default) build them and run whichever of {program, its launches} the
-        # tuner measured faster (tuned table "prog:" keys; the launches until measured); "1" / "force" always the program
-        mode = os.environ.get("PTX_PROGRAM", "auto")
+        # PTX_PROGRAM: "0" (default) never build programs -- every measurement of round 5 has the launches ahead (configs 2 / 3 at
+        # 8 clips: -3.7 % / -13 %; 1-4 clips: -7 % .. -24 %; DESIGN.md 3.14); "auto" build them and run whichever of {program,
+        # its launches} the tuner measured faster (tuned table "prog:" keys); "1" / "force" always the program
+        mode = os.environ.get("PTX_PROGRAM", "0")
         if mode == "0" or torch.device(self.dev).type != "cuda" or self.x3:
             return
         max_m = int(os.environ.get("PTX_PROGRAM_MAX_M", "4096"))
@@ -1931,7 +1932,7 @@ class Engine:
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
                    for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
                     or any(alt_lookup(a.key) is None for a in plan.alt_steps) \
-                    or (os.environ.get("PTX_PROGRAM", "auto") == "auto" and any(prog_lookup(p.key) is None for p in plan.program_steps)):
+                    or (os.environ.get("PTX_PROGRAM", "0") == "auto" and any(prog_lookup(p.key) is None for p in plan.program_steps)):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
             plan.tuned = True
 
@@ -2244,7 +2245,7 @@ class Engine:
                 if verbose:
                     print("tune %-34s chain %.4f ms | pair %.4f ms -> %s" % (a.label, ms2[0], ms2[1], "chain" if a.use_chain else "pair"))
             # conv program vs the launches it replaces: time both executions of every run, keep the faster (same margin rule)
-            pmode = os.environ.get("PTX_PROGRAM", "auto")
+            pmode = os.environ.get("PTX_PROGRAM", "0")
             dissolved = []
             for ps in list(plan.program_steps):
                 if pmode != "auto" or (only_untuned and prog_lookup(ps.key) is not None):
