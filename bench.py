@@ -600,13 +600,17 @@ def main():
     # PTX_BENCH_BACKEND=gloo: a functional check of the N > 1 branches on a box with FEWER GPUs than ranks (ranks share
     # devices round-robin, collectives go through gloo) -- never a scaling figure; the line says so in `config.parallelism`
     backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("PTX_BENCH_TIMEOUT", "1800")))
+    scalings = ["weak", "strong"] if args.scaling == "both" else [args.scaling]
     if os.environ.get("PTX_BENCH_LAUNCH_CHECK") == "1":
         # launcher check (runs without GPUs, tests/test_parallel_gloo.py): the ranks `--gpus N` started rendezvous over gloo,
-        # report who they are, rank 0 prints the line's launch-related fields, nothing is measured
+        # report who they are, rank 0 prints the launch-related fields of the line(s) a real run would print -- one per
+        # scaling, in the order they would be measured -- nothing is measured
         if args.gpus != world:
             raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s); they must agree" % (args.gpus, world))
         if world > 1:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         seen = [None] * world
         me = {"rank": rank, "local_rank": local, "pid": os.getpid()}
         if world > 1:
@@ -615,16 +619,16 @@ def main():
         else:
             seen = [me]
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": {
-                "world_size": dist.get_world_size() if world > 1 else 1, "distinct_pids": len({r["pid"] for r in seen}),
-                "local_ranks": sorted(r["local_rank"] for r in seen)}}))
+            for sc in scalings:
+                print(json.dumps({"launch_check": True, "n_gpus": world, "scaling": sc, "process_group_timeout_s": pg_timeout.total_seconds(),
+                                  "ranks_seen": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                                 "distinct_pids": len({r["pid"] for r in seen}),
+                                                 "local_ranks": sorted(r["local_rank"] for r in seen)}}))
         if world > 1:
             dist.destroy_process_group()
         return
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
-    import datetime
-    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("PTX_BENCH_TIMEOUT", "1800")))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -638,7 +642,7 @@ def main():
     torch.cuda.set_device(dev)
 
     results = []
-    for i, scaling in enumerate(["weak", "strong"] if args.scaling == "both" else [args.scaling]):
+    for i, scaling in enumerate(scalings):
         # --scaling both: the weak line (the headline), then the strong one, from the same ranks in one invocation; the
         # second pass reuses the first's tuned tiles and skips the N = 1 extras (CPU baseline timing, split-operand leg)
         results.append(measure(args, scaling, world, rank, local, dev, backend, first=(i == 0)))

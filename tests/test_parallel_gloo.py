@@ -177,6 +177,13 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == {"world_size": 2, "distinct_pids": 2, "local_ranks": [0, 1]}, line
+    # --scaling both: the weak line, then the strong line, from ONE invocation; PTX_BENCH_TIMEOUT bounds every collective
+    # wait (the other ranks sit in the tuned-table broadcast while rank 0 tunes)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--scaling", "both"], env=dict(env, PTX_BENCH_TIMEOUT="77"),
+                       capture_output=True, text=True, timeout=300)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and [ln["scaling"] for ln in lines] == ["weak", "strong"], (r.stderr[-800:], lines)
+    assert all(ln["process_group_timeout_s"] == 77.0 and ln["ranks_seen"]["world_size"] == 2 for ln in lines)
     # N = 1: no launcher, no process group
     r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=env, capture_output=True, text=True, timeout=300)
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
