@@ -344,7 +344,20 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
             return False
         K, Co = nb.conv1.in_channels, nb.conv1.out_channels
         # (16 x 16 maps stay on the two-output flow: 64 workgroups of 16 serial chunks measured 0.031 vs 0.020 ms)
-        return K % 128 == 0 and 128 <= K <= 2048 and Co in (64, 128, 256, 512) and (H * W) % 256 == 0 and H * W >= 1024
+        if not (K % 128 == 0 and 128 <= K <= 2048 and Co in (64, 128, 256, 512) and (H * W) % 256 == 0 and H * W >= 1024):
+            return False
+        # the PRODUCER of this map stores the raw sum only on a "yes", so the answer must be the consumer's own: ask the
+        # library with the descriptor Plan.conv will build for that conv1 (extents, strides, 2 GiB limits included)
+        from ._lib import ConvDesc, PTX_EPI_AFFINE, PTX_EPI_OUT_F16, PTX_EPI_RELU, PTX_F16_OPERANDS
+        pk_ = self.pack(nb.conv1, None, f16=True)
+        d = ConvDesc()
+        ld_in, ld_out = (K + 7) // 8 * 8, (Co + 7) // 8 * 8
+        d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = h.N, 1, H, W, K // 2, ld_in // 2
+        d.To, d.Ho, d.Wo, d.Co, d.ldy = 1, H, W, Co, ld_out
+        d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
+        d.Kc, d.Co_pad, d.groups = pk_.Kc // 2, pk_.Co_pad, 1
+        d.flags = PTX_F16_OPERANDS | PTX_EPI_OUT_F16 | PTX_EPI_AFFINE | PTX_EPI_RELU
+        return bool(self.lib.ptx_conv1x1_pro_f16_supported(C.byref(d)))
 
     xa, xr = cbn(h, flat[0][2].bn1), h          # activated input of the first block (halfs), its skip operand (fp32)
     for k, (si, bi, blk) in enumerate(flat):
@@ -372,7 +385,7 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         t = self.conv(t, pk(blk.conv3), one, (0, 1, 1), relu=True, affine=tab(blk.bn4), out_f16=True, label=name + ".conv3")
         skip = dict(res=xr) if (not up and blk.in_channels == blk.out_channels) else \
             dict(res=xr, res_kind="up", res_stride=(0, int(up), int(up)))
-        if nxt is None and _rgb_conv_ok(self, blk.conv4.out_channels):
+        if nxt is None and _rgb_conv_ok(self, blk.conv4.out_channels, t, model.output_layer[2], obn.channels):
             # last block, image conv on its own kernel (round 4): the output layer's BN + ReLU runs on that kernel's A
             # fragments, so this conv stores the RAW sum only -- no activated copy of the last feature map exists
             xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)
@@ -405,11 +418,20 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
                           label="output_layer.2")
     self.pooled = None
 
-def _rgb_conv_ok(self, channels):
+def _rgb_conv_ok(self, channels, x=None, conv=None, ld_aff=0):
     """The generator's image conv has its own kernel for C in {32, 64, 128} (ptx_rgb_conv3x3_f16_fwd); PTX_RGB_CONV=0 keeps
-    the implicit-GEMM tile (A/B runs)."""
+    the implicit-GEMM tile (A/B runs).  `x` (the map the last block will produce), `conv`, `ld_aff`: the decision is then the
+    library's own answer for the descriptor _rgb_conv will pass -- the last block stores a raw-only map on a "yes"."""
     import os
-    return os.environ.get("PTX_RGB_CONV", "1") != "0" and channels in (32, 64, 128)
+    if os.environ.get("PTX_RGB_CONV", "1") == "0" or channels not in (32, 64, 128):
+        return False
+    if x is None:
+        return True
+    from ._lib import RgbConvDesc, PTX_EPI_TANH
+    if conv.out_channels != 3 or tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1):
+        return False
+    d = RgbConvDesc(x.N, x.H, x.W, channels, (channels + 7) // 8 * 8, 4, ld_aff, PTX_EPI_TANH)
+    return bool(self.lib.ptx_rgb_conv3x3_f16_supported(C.byref(d)))
 
 
 def _rgb_conv(self, x, conv, scale_ptr, shift_ptr, ld_aff):
