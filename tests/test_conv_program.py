@@ -434,3 +434,34 @@ def test_engine_runs_the_tail_as_programs(ptx, monkeypatch):
         assert len(plan.all_convs()) == launches - n_prog + len(plan.program_steps)
     y1, y0 = outs
     assert (y0 - y1).abs().max().item() <= 1e-4 * max(1.0, y0.abs().max().item())
+
+
+@gpu
+def test_engine_programs_on_the_2p1d_nonlocal_composite_and_auto_mode(ptx, monkeypatch):
+    """BASELINE config 3's network at a small input: forced programs ((2+1)D factored GEMMs through ragged widths, NL
+    projections, attention launches between the programs) agree with the launch-per-conv plan; under PTX_PROGRAM=auto the
+    tuner times both, records its choice ("prog:" keys of the tuned table) and dissolves the programs it rejects."""
+    import pretorched_x_amd as P
+    from pretorched_x_amd import engine as E
+    x = torch.randn(2, 3, 16, 64, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def run(mode):
+        monkeypatch.setenv("PTX_PROGRAM", mode)
+        torch.manual_seed(3)
+        m = P.nonlocal_r2plus1d50(num_classes=21).eval().to(DEV)
+        with torch.no_grad():
+            y = m(x).clone()
+        return y, list(m.engine()._plans.values())[-1]
+
+    y0, plan0 = run("0")
+    assert not plan0.program_steps
+    y1, plan1 = run("force")
+    assert plan1.program_steps and all(p.use_program and p.error() is None for p in plan1.program_steps)
+    assert len(plan1.all_convs()) < len(plan0.all_convs())
+    assert (y0 - y1).abs().max().item() <= 1e-4 * max(1.0, y0.abs().max().item())
+    before = {k for k in E.tuned_snapshot() if k.startswith("prog:")}
+    y2, plan2 = run("auto")
+    after = {k: v for k, v in E.tuned_snapshot().items() if k.startswith("prog:")}
+    assert len(after) > len(before)                                  # every run of convs got a measured verdict
+    assert all(p.use_program for p in plan2.program_steps)           # what is still a program won its A/B
+    assert (y0 - y2).abs().max().item() <= 1e-4 * max(1.0, y0.abs().max().item())
