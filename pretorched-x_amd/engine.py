@@ -2248,7 +2248,15 @@ class Engine:
             pmode = os.environ.get("PTX_PROGRAM", "0")
             dissolved = []
             for ps in list(plan.program_steps):
-                if pmode != "auto" or (only_untuned and prog_lookup(ps.key) is not None):
+                if pmode != "auto":
+                    continue
+                known = prog_lookup(ps.key)
+                if only_untuned and known is not None:      # an identical run of convs was measured a moment ago: same verdict
+                    ps.use_program = known
+                    if not known:
+                        i = plan.steps.index(ps)
+                        plan.steps[i:i + 1] = ps.convs
+                        dissolved.append(ps)
                     continue
                 ms2 = []
                 for flag in (True, False):
