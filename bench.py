@@ -227,7 +227,7 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
         # perturb each other's HIP-event timings, and every rank must launch the same kernels
         if rank == 0:
             if headline or (os.environ.get("PTX_FULL_TUNE") == "1" and fwd is None):
-                eng.autotune(model, x, iters=2, verbose=args.verbose)      # every candidate tile of every conv problem
+                eng.autotune(model, x, iters=int(os.environ.get("PTX_TUNE_ITERS", "2")), verbose=args.verbose)      # every candidate tile of every conv problem
             else:
                 run()                              # first call compiles the plan and times untuned tiles
             torch.cuda.synchronize()

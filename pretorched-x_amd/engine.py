@@ -27,7 +27,8 @@ from . import _lib
 from ._lib import (ConvDesc, ConvStage, ConvProgramInfo, NormDesc, PackDesc, PoolDesc, PTX_EPI_RELU, PTX_EPI_RES_ADD, PTX_EPI_RES_PADA,
                    PTX_EPI_RES_UP, PTX_F16_OPERANDS, PTX_F16X3_OPERANDS, PTX_SPLITK_FUSED, PTX_PRO_RELU, PTX_EPI_ACCUM, PTX_POOL_SAME, PTX_POOL_PAD_ZERO, PtxError, check)
 
-_TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+# PTX_TUNED_TABLE: another table file (tuning sessions: A/B a freshly dumped table against the shipped one on the same box)
+_TUNED_PATH = os.environ.get("PTX_TUNED_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _tuned = None                    # conv problem key -> (tile configuration NAME, split-K)
 _tuned_lock = threading.Lock()
 _cfg_index = None                # configuration name -> index into this build's kConfigs table
