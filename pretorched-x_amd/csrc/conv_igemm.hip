@@ -505,14 +505,6 @@ static const ConvConfig kConfigs[] = {
     PTX_CFG_X3RE(32, 64, 64, 2, 2, 16, 3),    // 150
     PTX_CFG_X3RE(32, 128, 64, 2, 2, 16, 2),   // 151
     PTX_CFG_X3RE(128, 64, 32, 2, 2, 32, 2),   // 152
-    // round 5: the (2+1)D mid widths (144 * 2^k, r2plus1d.py:68-69) on the 32x32x2 MFMA shape -- a wave owns a 32-row x
-    // {96, 160, 192}-column strip (3 / 5 / 6 accumulator tiles against ONE A fragment), four waves stacked along M.  144
-    // columns pad to 160 (10 % of the MFMAs multiply zeros); whether that beats the exact-fit 16x16x4 tiles (48 / 96 / 144
-    // wide) is the tuner's call
-    PTX_CFG_DMA(128, 96, 16, 4, 1, 32),       // 153
-    PTX_CFG_DMA(128, 160, 16, 4, 1, 32),      // 154
-    PTX_CFG_DMA(128, 192, 16, 4, 1, 32),      // 155
-    PTX_CFG_DMA3(128, 192, 16, 4, 1, 32),     // 156  (three-stage ring: tile images that are whole DMA rounds only)
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

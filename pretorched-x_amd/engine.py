@@ -2137,8 +2137,6 @@ class Engine:
                         continue
                     if bn_ % 48 == 0 and ncol % 48 != 0:          # 48/96-wide tiles: (2+1)D widths only
                         continue
-                    if bn_ == 160 and not (128 < ncol <= 160):    # the padded strip for the 144-wide mid width
-                        continue
                     if bm >= 128 and M < 8192:
                         continue
                     blocks = ((M + bm - 1) // bm) * ((ncol + bn_ - 1) // bn_)
