@@ -2313,22 +2313,44 @@ class Engine:
         return rows
 
 
-    def profile_steps(self, plan, iters=5):
+    def profile_steps(self, plan, iters=5, isolated=None):
         """HIP-event time of EVERY launch of a compiled (and run) plan on the current stream, convs and HBM-bound
         passes alike: rows of (label, kind, algorithmic bytes, MACs, ms, tile / kernel name).  kind is "conv" for the
-        implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest."""
-        rows = []
+        implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest.
+        Each launch is bracketed by its own event pair INSIDE `iters` ordinary passes over the plan (round 5), so it is timed in
+        the company it keeps in a forward -- the same caches, the same clock / power state.  `isolated=True` (or
+        PTX_PROFILE_ISOLATED=1) is the older method, every launch repeated `iters` times back to back on its own: on the round-5
+        boxes that over-states the MFMA-bound launches by 5-19 % (the stem 1.76 ms against 1.50-1.62 ms in a forward; the
+        rows then SUM to more than the step they are part of), because five identical matrix-bound launches in a row pull the
+        clock down."""
+        if isolated is None:
+            isolated = os.environ.get("PTX_PROFILE_ISOLATED", "0") == "1"
         st = _stream()
         flat = [t for s in plan.steps for t in (s.active() if isinstance(s, (AltStep, ProgramStep)) else [s])]
-        for stp in flat:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            stp(st)
-            e0.record()
-            for _ in range(iters):
+        ms_of = []
+        if isolated:
+            for stp in flat:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 stp(st)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) / iters
+                e0.record()
+                for _ in range(iters):
+                    stp(st)
+                e1.record()
+                e1.synchronize()
+                ms_of.append(e0.elapsed_time(e1) / iters)
+        else:
+            for stp in flat:                    # one untimed pass: every launch has run once in this order
+                stp(st)
+            ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in flat] for _ in range(iters)]
+            for it in range(iters):
+                for i, stp in enumerate(flat):
+                    ev[it][i][0].record()
+                    stp(st)
+                    ev[it][i][1].record()
+            torch.cuda.synchronize()
+            ms_of = [sum(ev[it][i][0].elapsed_time(ev[it][i][1]) for it in range(iters)) / iters for i in range(len(flat))]
+        rows = []
+        for stp, ms in zip(flat, ms_of):
             if isinstance(stp, ConvStep):
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp))
             elif isinstance(stp, (StemStep, StemF32Step, PatchConvStep)):      # direct (patch) kernels are convs too
