@@ -33,14 +33,14 @@ PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 SUSTAINED_F16_MFMA_TF = 1600.0     # measured: scripts/micro/mfma_f16_peak.hip, random operands (profiles/r03_mfma_f16_peak.txt)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md HBM3E peak
-def _newest_traffic_file():
-    """Newest committed PMC traffic table (profiles/rNN_pmc_traffic.json), replayed in roofline.traffic."""
+def _newest_traffic_file(workload="cfg2"):
+    """Newest committed PMC traffic table of `workload`, replayed in roofline.traffic: profiles/rNN_pmc_traffic_<workload>.json,
+    or -- config 2 only, the table's original name -- profiles/rNN_pmc_traffic.json.  None when the workload has no table:
+    another workload's launches of the same tile are a different problem, their counters are never replayed."""
     import glob
-    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
-    return names[-1] if names else "r02_pmc_traffic.json"
-
-
-TRAFFIC_FILE = _newest_traffic_file()
+    pats = ["r[0-9][0-9]_pmc_traffic_%s.json" % workload] + (["r[0-9][0-9]_pmc_traffic.json"] if workload == "cfg2" else [])
+    names = sorted(os.path.basename(f) for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat)))
+    return names[-1] if names else None
 
 
 def other_workload(name, rank):
@@ -320,7 +320,10 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
             """(bytes, source) of one kernel from the committed PMC table, or (None, None)."""
             try:
                 import re
-                tpath = os.path.join("profiles", TRAFFIC_FILE)
+                tfile = _newest_traffic_file(args.workload)
+                if tfile is None:
+                    return None, None
+                tpath = os.path.join("profiles", tfile)
                 tj = json.load(open(os.path.join(ROOT, tpath)))
 
                 meta = tj.get("_meta", {})
@@ -331,11 +334,15 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
                              "fetch_bytes": v["FETCH_SIZE_KiB"] * 1024.0, "write_bytes": v["WRITE_SIZE_KiB"] * 1024.0,
                              "fetch_correction": "none applied (guide: up to 2x under-report on streaming reads)",
                              "measured_in_this_run": False})
-                if name.startswith("conv_stem"):                # the direct stem kernels: one row per kernel name
-                    for k, v in tj.items():
-                        if k.startswith(name + "_kernel") and isinstance(v, dict) and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None:
-                            return hit(v)
-                    return None, None
+                if name.startswith(("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16")):   # own kernels: one row per name
+                    # every template instantiation of that kernel, weighted by its dispatch count: the bench groups them too
+                    inst = [v for k, v in tj.items() if k.startswith(name + "_kernel") and isinstance(v, dict)
+                            and v.get("WRITE_SIZE_KiB") is not None and v.get("FETCH_SIZE_KiB") is not None]
+                    if not inst:
+                        return None, None
+                    calls = [float(v.get("calls", 1)) for v in inst]
+                    mean = {c: sum(v[c] * n for v, n in zip(inst, calls)) / sum(calls) for c in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB")}
+                    return hit(mean)
                 parts = name.split("/")                   # "64x64x32/2x2/m32/dma[N][/chain][/re]"
                 tile, waves, mt = parts[:3]
                 rest = parts[3:]

@@ -23,7 +23,9 @@ for line in open(src):
     if sect in ("FETCH_SIZE", "WRITE_SIZE") and not line.startswith("kernel") and line.strip():
         m = re.match(r"(.{62})\s+(\d+)\s+([0-9.e+-]+)\s+([0-9.e+-]+)", line)
         if m:
-            out.setdefault(m.group(1).strip(), {})[sect + "_KiB"] = float(m.group(3))
+            row = out.setdefault(m.group(1).strip(), {})
+            row[sect + "_KiB"] = float(m.group(3))
+            row["calls"] = int(m.group(2))           # dispatches behind the mean (bench.py weights template instantiations by it)
 out["_meta"] = {"commit": sys.argv[3] if len(sys.argv) > 3 else os.environ.get("PTX_COMMIT"),
                 "command": sys.argv[4] if len(sys.argv) > 4 else None, "source": src}
 json.dump(out, open(dst, "w"), indent=1)

@@ -478,6 +478,15 @@ def test_bench_workload_table(ptx):
         bench.local_batch(mk2, 64, "cfg5", "strong", 2, 0)
     with pytest.raises(SystemExit):
         bench.other_workload("cfg9", 0)
+    # roofline.traffic replays the PMC table of the SAME workload (a tile's launches in another network are another problem):
+    # config 2 keeps the table's original name, the others carry their workload in the file name, no table -> null
+    t2, t3 = bench._newest_traffic_file("cfg2"), bench._newest_traffic_file("cfg3")
+    assert t2 and t2.endswith("_pmc_traffic.json") and t3 and t3.endswith("_pmc_traffic_cfg3.json")
+    assert bench._newest_traffic_file("cfg1") is None
+    for t in (t2, t3):
+        tj = json.load(open(os.path.join(os.path.dirname(GOLDEN), "..", "profiles", t)))
+        assert tj["_meta"]["command"] and tj["_meta"]["commit"]
+    assert ("--workload cfg3" in json.load(open(os.path.join(os.path.dirname(GOLDEN), "..", "profiles", t3)))["_meta"]["command"])
 
 
 def test_standin_models_match_literature_shapes(ptx):
