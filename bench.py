@@ -552,6 +552,38 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
                                    "tolerance": tolerance}
             eng.precision = "fp32"
 
+        # ---- secondary leg: the same batch as TWO clip lanes (Engine.lanes = 2: two half-batch plans on two HIP streams, the
+        # logits concatenated).  Opt-in in the product, so it is reported NEXT to the headline, which
+        # stays the single-plan path every per-kernel figure above describes.
+        lanes_leg = None
+        if world == 1 and first and fwd is None and not args.no_lanes and units_per_gpu % 2 == 0:
+            eng.lanes = 2
+            half = x[:units_per_gpu // 2]
+            if not args.no_autotune and (headline or os.environ.get("PTX_FULL_TUNE") == "1"):
+                eng.autotune(model, half, iters=int(os.environ.get("PTX_TUNE_ITERS", "2")), verbose=args.verbose)
+            for _ in range(max(args.warmup, 1)):
+                out_l = run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out_l = run()
+            torch.cuda.synchronize()
+            el_l = time.perf_counter() - t0
+            rate_l = units_per_gpu * args.steps / el_l
+            lanes_leg = {"lanes": 2, "value": round(rate_l, 2), "unit": "%s/s" % unit, "ms_per_step": round(1e3 * el_l / args.steps, 4),
+                         "speedup_vs_single_plan": round(rate_l / (clips_per_s / world), 4),
+                         "launch_shape": "%d %s per launch (two plans of %d-%s batches, own buffers, tiles tuned for that shape)" % (
+                             units_per_gpu // 2, unit, units_per_gpu // 2, unit[:-1]),
+                         "max_abs_d_vs_single_plan": float((out_l - out).abs().max().item()),
+                         "argmax_equal_single_plan": bool(torch.equal(out_l.argmax(1), out.argmax(1))) if out_l.dim() == 2 else None,
+                         "parity": None}
+            if parity is not None:
+                got_l = out_l.cpu()[idx]
+                lanes_leg["parity"] = {"max_abs_dlogits": float((got_l - want).abs().max().item()),
+                                       "argmax_equal": bool(torch.equal(got_l.argmax(1), want.argmax(1))) if got_l.dim() == 2 else None,
+                                       "tolerance": tolerance}
+            eng.lanes = 1
+
         result = {
             "metric": ("clips/sec, resnet3d50 forward 8x3x16x224x224 per GPU (+ max|dlogits| vs CPU)" if headline else
                        "%s/sec, %s (+ max|d output| vs CPU)" % (unit, args.workload)),
@@ -566,7 +598,7 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
                                            backend, torch.cuda.device_count()))},
             "roofline": roofline, "roofline_longest_launch": roofline_longest, "roofline_net": roofline_net, "roofline_hbm": roofline_hbm,
             "non_conv_ms": round(sum(v["ms"] for v in roofline_hbm.values()) + other_ms, 4),
-            "cpu_baseline": cpu, "parity": parity, "split_f16x3": split,
+            "cpu_baseline": cpu, "parity": parity, "split_f16x3": split, "clip_lanes": lanes_leg,
             "commit": os.environ.get("PTX_COMMIT"),
             # which sources the loaded libptx_amd.so was compiled from, and whether that is this tree (build.py stamps it)
             "binary": {"version": ptx._lib.lib().ptx_version().decode(), "source_sha256_matches_tree": ptx._lib.binary_source_hash() == ptx._lib.source_hash()},
@@ -586,6 +618,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-x3", action="store_true", help="skip the secondary split-precision (x3) leg")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the secondary clip-lanes (Engine.lanes = 2) leg")
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5-fp32"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
                     help="weak (default, the headline): a fixed batch PER GPU; strong: BASELINE's global batch (cfg2 / cfg3: 8 "

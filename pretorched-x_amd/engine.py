@@ -1717,6 +1717,31 @@ class Engine:
         # Off by default: every nn.Parameter requires grad, so plain inference without torch.no_grad() would leave
         # the HIP engine.
         self.autograd = os.environ.get("PTX_AUTOGRAD", "0") == "1"
+        # Opt-in clip lanes (forward() only): the batch is cut into `lanes` equal contiguous slices, each slice runs through
+        # ITS OWN plan (own activation buffers and split-K workspace) on its own HIP stream, and the logits are concatenated
+        # in clip order.  The slices are independent chains of launches, so one lane's launch gaps, tile tails and
+        # HBM-bound passes overlap the other's matrix-bound kernels: +2.0-2.5 % on configs 2 and 4 with two lanes on MI355X,
+        # nothing on config 3, a loss with four.  Off by default: per-clip results are those of the
+        # slice-sized batch (another tile / split-K choice than the full batch: same 1e-5 class, not the same bits).
+        self._lanes = 1
+        self._lane_streams = {}          # device index -> side streams of lanes 1 .. n-1 (lane 0 runs on the caller's stream)
+        self.lanes = int(os.environ.get("PTX_LANES", "1"))
+
+    @property
+    def lanes(self):
+        return self._lanes
+
+    @lanes.setter
+    def lanes(self, value):
+        if not isinstance(value, int) or isinstance(value, bool) or not 1 <= value <= 8:
+            raise PtxError("Engine.lanes must be an integer in 1..8 (got %r)" % (value,))
+        self._lanes = value
+
+    def lanes_for(self, batch):
+        """Lanes forward() uses for a batch of this size: `lanes` when it cuts the batch into equal non-empty slices and the
+        hipGraph replay is off, else 1 (the plain single-plan path -- never an error)."""
+        n = self._lanes
+        return n if (n > 1 and not self.use_graph and batch >= n and batch % n == 0) else 1
 
     @property
     def precision(self):
@@ -1817,11 +1842,12 @@ class Engine:
                   "ptx_checksum_f32")
             return int(out.item())
 
-    def plan_for(self, model, x, shape=None, norm=None):
-        """shape / norm: the NCDHW view and NormDesc of a uint8-frames input (forward_frames)."""
+    def plan_for(self, model, x, shape=None, norm=None, lane=0):
+        """shape / norm: the NCDHW view and NormDesc of a uint8-frames input (forward_frames).  lane: which of the
+        Engine.lanes concurrent slices this plan serves -- lanes of one shape are separate plans (separate buffers)."""
         shape = tuple(x.shape) if shape is None else tuple(shape)
         nkey = None if norm is None else (tuple(norm.mean), tuple(norm.std), norm.swap_rb, norm.to_255)
-        key = (shape, x.device.index, nkey)
+        key = (shape, x.device.index, nkey) + ((lane,) if lane else ())
         with self._lock:
             plan = self._plans.get(key)
             fresh = plan is None
@@ -1970,12 +1996,53 @@ class Engine:
             return big
         x = _dense16(x)
         with torch.cuda.device(x.device):
+            n = self.lanes_for(x.shape[0])
+            if n > 1:
+                return self._forward_lanes(model, x, n)
             plan = self.plan_for(model, x)
             self._maybe_tune(model, plan, x)
             if self.use_graph:
                 return self._forward_graph(model, plan, x)
             out = self._forward_eager(model, plan, x)
         return out
+
+    def lane_plans(self, model, x):
+        """The plans forward(model, x) runs, lane 0 first (one plan unless Engine.lanes cuts this batch)."""
+        x = _dense16(x)
+        n = self.lanes_for(x.shape[0])
+        per = x.shape[0] // n
+        with torch.cuda.device(x.device):
+            return [self.plan_for(model, _dense16(x[i * per:(i + 1) * per]), lane=i) for i in range(n)]
+
+    def _forward_lanes(self, model, x, n):
+        """forward() over `n` clip lanes: slice i of the batch on stream i (lane 0 on the caller's stream, the others on the
+        engine's side streams, which first wait for the caller's stream -- the input is ready there -- and which the caller's
+        stream waits for before the logits are concatenated).  Every lane is an ordinary eager forward of its own plan."""
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        side = self._lane_streams.get(dev.index)
+        if side is None or len(side) < n - 1:
+            side = self._lane_streams[dev.index] = [torch.cuda.Stream(dev) for _ in range(n - 1)]
+        per = x.shape[0] // n
+        parts = [_dense16(x[i * per:(i + 1) * per]) for i in range(n)]
+        plans = [self.plan_for(model, parts[i], lane=i) for i in range(n)]
+        for i in range(n):                       # first use: lane 0 times what the table lacks, the others find it filled
+            self._maybe_tune(model, plans[i], parts[i])
+        ready = cur.record_event()
+        outs = [None] * n
+        for i in range(1, n):
+            st = side[i - 1]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                outs[i] = self._forward_eager(model, plans[i], parts[i])
+        outs[0] = self._forward_eager(model, plans[0], parts[0])
+        for i in range(1, n):
+            cur.wait_stream(side[i - 1])
+        if not all(torch.is_tensor(o) for o in outs):
+            raise PtxError("Engine.lanes: the model's head must return one tensor per call (batch on dim 0) to be concatenated")
+        for o in outs[1:]:
+            o.record_stream(cur)                 # allocated under a side stream, consumed (and freed) under the caller's
+        return torch.cat(outs, 0)
 
     # ------------------------------------------------------------------------------------
     def generate(self, model, z, y):

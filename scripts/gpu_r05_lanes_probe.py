@@ -82,6 +82,11 @@ def main():
                 for i in range(lanes):
                     cur.wait_stream(streams[i])
 
+            def free_running():          # no per-step join: the upper bound of the overlap (the lanes drift apart)
+                for i in range(lanes):
+                    with torch.cuda.stream(streams[i]):
+                        outs[i] = models[i](parts[i])
+
             t_ser = timed(serial, steps)
             got = torch.cat(outs)
             t_ovl = timed(overlapped, steps)
@@ -90,6 +95,12 @@ def main():
                 workload, lanes, per, n / t_ser, 1e3 * t_ser, (got - ref).abs().max().item()), flush=True)
             print("%s %d x %d clips, %d streams               %8.1f clips/s  %.4f ms   max|d| vs full %.2e  (%.3fx the full batch)" % (
                 workload, lanes, per, lanes, n / t_ovl, 1e3 * t_ovl, (got2 - ref).abs().max().item(), t_full / t_ovl), flush=True)
+            for rep in range(2):
+                t_o = timed(overlapped, steps)
+                t_f = timed(free_running, steps)
+                t_1 = timed(lambda: model(x), steps)
+                print("   repeat %d: %d streams %8.1f | free-running %8.1f | full batch %8.1f clips/s   (%.3fx / %.3fx)" % (
+                    rep, lanes, n / t_o, n / t_f, n / t_1, t_1 / t_o, t_1 / t_f), flush=True)
         t_full2 = timed(lambda: model(x), steps)
         print("%s full batch again                      %8.1f clips/s  %.4f ms" % (workload, n / t_full2, 1e3 * t_full2), flush=True)
 

@@ -246,6 +246,28 @@ def test_dataparallel_replicas_share_engine_plans_and_signature(ptx):
     assert [r.name.rsplit(".", 1)[1] for r in nl.convs] == ["theta", "phi", "g"]
 
 
+def test_clip_lanes_knob(ptx, monkeypatch):
+    """Engine.lanes: opt-in, validated, read from PTX_LANES at construction; lanes_for() never errors -- a batch the lane
+    count does not divide (or the hipGraph mode) keeps the single-plan path."""
+    m = ptx.resnet3d10(num_classes=3)
+    e = m.engine()
+    assert e.lanes == 1 and e.lanes_for(8) == 1
+    e.lanes = 2
+    assert [e.lanes_for(b) for b in (1, 2, 3, 8)] == [1, 2, 1, 2]
+    e.use_graph = True
+    assert e.lanes_for(8) == 1
+    e.use_graph = False
+    for bad in (0, 9, -1, 2.0, "2", True):
+        with pytest.raises(ptx.PtxError):
+            e.lanes = bad
+    monkeypatch.setenv("PTX_LANES", "2")
+    assert ptx.resnet3d10(num_classes=3).engine().lanes == 2
+    import copy
+    assert copy.deepcopy(m).engine().lanes == 2          # a deep copy gets a fresh engine (environment defaults)
+    monkeypatch.setenv("PTX_LANES", "1")
+    assert copy.deepcopy(m).engine().lanes == 1
+
+
 def test_tuned_table_stores_config_names(ptx):
     from pretorched_x_amd import engine
     table = engine.tuned_snapshot()

@@ -238,6 +238,74 @@ def test_hipgraph_replay_matches_eager(ptx):
         eng.use_graph = False
 
 
+def test_clip_lanes_are_slice_forwards_on_their_own_streams(ptx):
+    """Engine.lanes = n (opt-in): forward() cuts the batch into n contiguous slices, one plan and one HIP stream each, and
+    concatenates the logits in clip order.  A lane IS an ordinary forward of its slice: bit-identical to calling the model on
+    that slice (same shape -> same tiles), 1e-3-bar identical to the single-plan forward and to the CPU oracle; batches the
+    lane count does not divide, and the hipGraph mode, keep the single-plan path; the caller's stream may be any stream."""
+    model, sd = _build(ptx, "resnet3d50", dict(num_classes=17, pretrained=None), 11)
+    x_cpu = synth_clips(4, 8, 64, 21)
+    x = x_cpu.to(DEV)
+    want = OF.forward(OF.ARCHS["resnet3d50"], sd, x_cpu)
+    eng = model.engine()
+    single = model(x).clone()
+    halves = torch.cat([model(x[:2]), model(x[2:])]).clone()
+    quarters = torch.cat([model(x[i:i + 1]) for i in range(4)]).clone()
+    builds = eng.plan_builds
+    try:
+        eng.lanes = 2
+        assert eng.lanes_for(4) == 2 and eng.lanes_for(3) == 1 and eng.lanes_for(1) == 1
+        got = model(x)
+        assert torch.equal(got, halves)
+        _check(got, want, "two lanes vs oracle")
+        assert (got - single).abs().max().item() <= 1e-4 and torch.equal(got.argmax(1), single.argmax(1))
+        assert eng.plan_builds == builds + 1                       # lane 0 reuses the 2-clip plan, lane 1 owns a second one
+        plans = eng.lane_plans(model, x)
+        assert len(plans) == 2 and plans[0] is not plans[1] and plans[0].shape == plans[1].shape == (2, 3, 8, 64, 64)
+        assert len({a.t.data_ptr() for p_ in plans for a in p_.acts}) == sum(len(p_.acts) for p_ in plans)   # no shared buffer
+        for _ in range(5):                                         # back-to-back calls: the lanes' buffers are reused safely
+            assert torch.equal(model(x), halves)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            on_side = model(x)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(on_side, halves)
+        odd = model(x[:3])                                         # 3 clips: the single-plan path, no error
+        assert odd.shape == (3, 17)
+        eng.lanes = 1
+        assert torch.equal(odd, model(x[:3]))
+        eng.lanes = 4
+        assert torch.equal(model(x), quarters)
+        eng.lanes = 2
+        with torch.no_grad():                                      # a weight update reaches BOTH lanes' packed filters
+            model.layer2[0].bn1.weight.mul_(1.5)
+        upd = model(x)
+        eng.lanes = 1
+        assert not torch.equal(upd, halves) and torch.equal(upd, torch.cat([model(x[:2]), model(x[2:])]))
+        eng.lanes = 2
+        eng.use_graph = True
+        assert eng.lanes_for(4) == 1
+        eng.use_graph = False
+        with pytest.raises(ptx.PtxError):
+            eng.lanes = 0
+        with pytest.raises(ptx.PtxError):
+            eng.lanes = 2.0
+    finally:
+        eng.use_graph = False
+        eng.lanes = 1
+    # the non-local composite: attention is per clip, so a lane changes nothing but the batch its clips arrive in
+    nl, sd2 = _build(ptx, "nonlocal_r2plus1d50", dict(num_classes=11), 5, inner_bn_damp=0.9, nl_bn_damp=0.05)
+    xn = synth_clips(2, 8, 56, 3).to(DEV)
+    a = nl(xn).clone()
+    nl.engine().lanes = 2
+    try:
+        b = nl(xn)
+    finally:
+        nl.engine().lanes = 1
+    assert torch.equal(b, torch.cat([nl(xn[:1]), nl(xn[1:])])) and (a - b).abs().max().item() <= 1e-4
+
+
 def test_autotune_keeps_parity(ptx):
     blob = load_golden("resnet3d50_small")
     model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), int(blob["w_seed"]))
