@@ -556,7 +556,7 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
         # logits concatenated).  Opt-in in the product, so it is reported NEXT to the headline, which
         # stays the single-plan path every per-kernel figure above describes.
         lanes_leg = None
-        if world == 1 and first and fwd is None and not args.no_lanes and units_per_gpu % 2 == 0:
+        if world == 1 and first and not args.no_lanes and units_per_gpu % 2 == 0:
             eng.lanes = 2
             half = x[:units_per_gpu // 2]
             if not args.no_autotune and (headline or os.environ.get("PTX_FULL_TUNE") == "1"):

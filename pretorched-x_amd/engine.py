@@ -2011,8 +2011,13 @@ class Engine:
         x = _dense16(x)
         n = self.lanes_for(x.shape[0])
         per = x.shape[0] // n
+        plans = []
         with torch.cuda.device(x.device):
-            return [self.plan_for(model, _dense16(x[i * per:(i + 1) * per]), lane=i) for i in range(n)]
+            for i in range(n):
+                part = _dense16(x[i * per:(i + 1) * per])
+                plans.append(self.plan_for(model, part, lane=i))
+                self._maybe_tune(model, plans[i], part)
+        return plans
 
     def _forward_lanes(self, model, x, n):
         """forward() over `n` clip lanes: slice i of the batch on stream i (lane 0 on the caller's stream, the others on the
@@ -2025,8 +2030,11 @@ class Engine:
             side = self._lane_streams[dev.index] = [torch.cuda.Stream(dev) for _ in range(n - 1)]
         per = x.shape[0] // n
         parts = [_dense16(x[i * per:(i + 1) * per]) for i in range(n)]
-        plans = [self.plan_for(model, parts[i], lane=i) for i in range(n)]
-        for i in range(n):                       # first use: lane 0 times what the table lacks, the others find it filled
+        plans = []
+        for i in range(n):
+            # first use: lane 0 is compiled and times what the tuned table lacks BEFORE the next lane is compiled -- a plan
+            # picks its tiles at compile time, so every lane ends up on the same (tuned) tiles and computes the same bits
+            plans.append(self.plan_for(model, parts[i], lane=i))
             self._maybe_tune(model, plans[i], parts[i])
         ready = cur.record_event()
         outs = [None] * n
@@ -2066,9 +2074,38 @@ class Engine:
                 mb = self._sig[key] = max(1, int(self.LIMIT_BYTES // max(a.t.numel() * a.t.element_size() for a in one.acts)))
         if N > mb:      # balanced chunks (64 -> 32 + 32, not 63 + 1): every chunk keeps the GEMMs' M large
             size = -(-N // (-(-N // mb)))
-            return torch.cat([self.generate(model, z[i:i + size], y[i:i + size]) for i in range(0, N, size)], 0)
+            starts = list(range(0, N, size))
+            n = min(self._lanes, len(starts)) if not self.use_graph else 1
+            if n > 1:
+                # clip lanes (Engine.lanes): chunk k through plan k % n on stream k % n -- the chunks are
+                # independent chains of launches and the generator mixes HBM-bound and matrix-bound kernels
+                dev = z.device
+                with torch.cuda.device(dev):
+                    cur = torch.cuda.current_stream(dev)
+                    side = self._lane_streams.get(dev.index)
+                    if side is None or len(side) < n - 1:
+                        side = self._lane_streams[dev.index] = [torch.cuda.Stream(dev) for _ in range(n - 1)]
+                    ready = cur.record_event()
+                    for st in side[:n - 1]:
+                        st.wait_event(ready)
+                    outs = []
+                    for k, i in enumerate(starts):
+                        lane = k % n
+                        with torch.cuda.stream(cur if lane == 0 else side[lane - 1]):
+                            outs.append(self._generate_one(model, z[i:i + size], y[i:i + size], lane))
+                    for st in side[:n - 1]:
+                        cur.wait_stream(st)
+                    for k, o in enumerate(outs):
+                        if k % n:
+                            o.record_stream(cur)
+                    return torch.cat(outs, 0)
+            return torch.cat([self._generate_one(model, z[i:i + size], y[i:i + size]) for i in starts], 0)
+        return self._generate_one(model, z, y)
+
+    def _generate_one(self, model, z, y, lane=0):
+        N = z.shape[0]
         with torch.cuda.device(z.device):
-            plan = self.plan_for(model, z)
+            plan = self.plan_for(model, z, lane=lane)
             plan.in_ptr2 = _ptr(y)
             self._maybe_tune(model, plan, z)
             with plan.exclusive():
