@@ -26,6 +26,7 @@ try:
 except Exception as e:
     print("gloo parse failed", e)
 E
+timeout 300 python scripts/gpu_r05_lane_rows.py 2>/dev/null | tee $O/lane_rows.txt | tail -9 | tee -a $O/summary.txt
 if [ -z "$SKIP_PROF" ]; then
 W=cfg2 ENVS="PTX_PROGRAM=0" TAG=_fp32 STEPS=15 bash scripts/gpu_prof_pmc.sh 2>&1 | tail -7 | tee -a $O/summary.txt
 W=cfg3 ENVS="PTX_PROGRAM=0" TAG=_fp32 STEPS=15 bash scripts/gpu_prof_pmc.sh 2>&1 | tail -7 | tee -a $O/summary.txt
