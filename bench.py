@@ -582,6 +582,30 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
                 lanes_leg["parity"] = {"max_abs_dlogits": float((got_l - want).abs().max().item()),
                                        "argmax_equal": bool(torch.equal(got_l.argmax(1), want.argmax(1))) if got_l.dim() == 2 else None,
                                        "tolerance": tolerance}
+            if split is not None:
+                # ... and the split-operand arithmetic through the same two lanes (its shorter matrix work leaves more of a
+                # launch to gaps and HBM-bound passes, so the overlap pays more)
+                eng.precision = "x3"
+                if not args.no_autotune and (headline or os.environ.get("PTX_FULL_TUNE") == "1"):
+                    eng.autotune(model, half, iters=int(os.environ.get("PTX_TUNE_ITERS", "2")), verbose=args.verbose)
+                for _ in range(max(args.warmup, 1)):
+                    out_l3 = run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    out_l3 = run()
+                torch.cuda.synchronize()
+                el_l3 = time.perf_counter() - t0
+                rate_l3 = units_per_gpu * args.steps / el_l3
+                lanes_leg["split_f16x3"] = {"value": round(rate_l3, 2), "unit": "%s/s" % unit, "ms_per_step": round(1e3 * el_l3 / args.steps, 4),
+                                            "speedup_vs_single_plan_x3": round(rate_l3 / split["value"], 4), "parity": None}
+                if parity is not None:
+                    got_l3 = out_l3.cpu()[idx]
+                    lanes_leg["split_f16x3"]["parity"] = {
+                        "max_abs_dlogits": float((got_l3 - want).abs().max().item()),
+                        "argmax_equal": bool(torch.equal(got_l3.argmax(1), want.argmax(1))) if got_l3.dim() == 2 else None,
+                        "tolerance": tolerance}
+                eng.precision = "fp32"
             eng.lanes = 1
 
         result = {
