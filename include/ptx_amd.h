@@ -526,6 +526,16 @@ typedef struct ptx_nonlocal_desc {
 int ptx_nonlocal_supported(const ptx_nonlocal_desc* desc);
 int ptx_nonlocal_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
                      ptx_stream_t stream);
+/* The same operator over a caller-provided scratch buffer, which unlocks the STREAM-K form for long sequences whose
+ * 64-query tiles do not fill the chip evenly (nonlocalnet.py:143-166 at N = 1568: 25 tiles x 8 clips = 200 workgroups on 256
+ * CUs): the (query tile, key tile) units of one clip are cut into 32 (<= 32 query tiles) or 64 equal chunks, one workgroup
+ * each; partial (O, max, sum) blocks meet in the workspace and a second launch folds them in chunk order.  The split is a
+ * function of the per-sample extents only -- a clip's bits do not depend on the batch it arrives in.
+ * ptx_nonlocal_workspace_bytes: bytes this descriptor's stream-K form needs (0: the plain kernels cover it).  With
+ * workspace == NULL, too small or not 16-byte aligned, ptx_nonlocal_ws_fwd runs exactly what ptx_nonlocal_fwd runs. */
+size_t ptx_nonlocal_workspace_bytes(const ptx_nonlocal_desc* desc);
+int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
+                        void* workspace, size_t workspace_bytes, ptx_stream_t stream);
 /* Batched C[b] = op(A[b] x B[b]^T): A [batch][M][lda] (row-major, K contiguous),
  * B [batch][Nn][ldb] (row-major, K contiguous), C [batch][M][ldc]; fp32 MFMA.
  * Used for f = theta^T phi  (nonlocalnet.py:156) and y = softmax(f) g  (:160). */

@@ -181,6 +181,8 @@ SIGNATURES = {
     "ptx_linear_setsum_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P]),
     "ptx_nonlocal_supported": (C.c_int, [C.POINTER(NonlocalDesc)]),
     "ptx_nonlocal_fwd": (C.c_int, [C.POINTER(NonlocalDesc), _P, _P, _P, _P, _P]),
+    "ptx_nonlocal_workspace_bytes": (C.c_size_t, [C.POINTER(NonlocalDesc)]),
+    "ptx_nonlocal_ws_fwd": (C.c_int, [C.POINTER(NonlocalDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "ptx_bgemm_nt": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _P]),
     "ptx_softmax_rows": (C.c_int, [_P, _L, _I, _I, _I, _P]),
     "ptx_transpose_last2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

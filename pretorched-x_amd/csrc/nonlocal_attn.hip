@@ -39,6 +39,11 @@ struct NlArgs {
     int relu;               // PTX_NL_RELU: P = relu(S) / Nk (the 'concatenation' affinity, nonlocalnet.py:213-243)
     int out_f16;            // PTX_NL_OUT_F16: y holds halfs (ld_y / bs_y count halfs): the generator's fp16 plan feeds it to a half conv
     unsigned p_bytes, g_bytes, t_bytes;
+    // stream-K (SK kernels): chunks per clip, the partial slots ([batch][sk_chunks][2] x ws_slot floats: a [64][DV] block of
+    // unnormalised outputs, then 64 running maxima and 64 running sums)
+    int sk_chunks;
+    float* ws;
+    long long ws_slot;
 };
 
 // (inline asm with AMDGPU register constraints must live in a __device__ function: inside the __global__
@@ -86,11 +91,19 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, half4
 // serial chain of Nk / 16 tiles x 128 MFMAs, and config 3's layer2 blocks launch only batch x ceil(1568 / 64) = 200
 // workgroups -- 800 waves on 1024 SIMDs, one wave per SIMD, nothing to cover its softmax / LDS / barrier bubbles (measured:
 // MFMA pipe 57 % busy, 53 % of the fp32 peak).  Split, every active SIMD holds two waves of half the length.
-template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false, int KS = 1>
+// SK ("stream-K", with KS = 2): the (query tile, key tile) units of ONE clip -- q_tiles x n_tiles of them, query tile major --
+// are cut into p.sk_chunks equal contiguous chunks, one workgroup each, WHATEVER the batch (a clip's split points are a
+// function of its own extents: its bits do not change with the batch it arrives in).  Why: config 3's layer2 blocks are 25
+// query tiles x 8 clips = 200 workgroups at one per CU (128 KiB of LDS) on 256 CUs; 32 chunks per clip are 256 workgroups of
+// 38.3 units instead of 200 of 49.  A chunk covers at most two query tiles (q_tiles <= sk_chunks): per segment the
+// workgroup runs the ordinary loop over its key range and parks (unnormalised O, m, l) of its 64 queries in a workspace slot;
+// nl_sk_combine_kernel folds the 2-3 pieces of every query tile in chunk order (a fixed order: deterministic).
+template <int D, int DV, bool SOFTMAX, int MODE = 0, bool TG = false, int KS = 1, bool SK = false>
 __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) {
     constexpr bool F16 = MODE == 1, X3 = MODE == 2;
     static_assert(!TG || MODE == 0, "theta-from-global is an fp32 variant");
     static_assert(KS == 1 || (KS == 2 && !TG), "key split: two wave groups");
+    static_assert(!SK || (KS == 2 && SOFTMAX && !F16), "stream-K: the key-split softmax kernel (fp32 / split operands)");
     constexpr int TK = 16 * KS;              // keys per tile
     constexpr int NW = 4 * KS;               // waves per workgroup
     constexpr int QJ = D / 16;               // 16-wide d steps (one ds_read_b128 + 4 MFMAs each)
@@ -106,12 +119,23 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_remap(blockIdx.x, p.q_tiles * p.batch);     // one clip's tiles share an XCD's L2
-    const int b = tile / p.q_tiles, qt = tile - b * p.q_tiles;
+    const int n_tiles = (p.Nk + TK - 1) / TK;
+    const int tile = xcd_remap(blockIdx.x, (SK ? p.sk_chunks : p.q_tiles) * p.batch);     // one clip's tiles share an XCD's L2
+    const int b = tile / (SK ? p.sk_chunks : p.q_tiles);
+    int qt = tile - b * p.q_tiles;           // (SK: set per segment)
+    // SK: this workgroup's units [u, u_end) of the clip's q_tiles x n_tiles stream; seg counts its segments (query tiles)
+    const int chunk = SK ? tile - b * p.sk_chunks : 0;
+    int u = 0, u_end = 0, seg = 0, t_lo = 0, t_hi = n_tiles;
+    if constexpr (SK) {
+        const long long U = (long long)p.q_tiles * n_tiles;
+        u = (int)((chunk * U) / p.sk_chunks);
+        u_end = (int)(((chunk + 1) * U) / p.sk_chunks);
+        if (u >= u_end) return;              // (more chunks than units: nothing to do, nothing the combine pass reads)
+    }
     const int c0 = blockIdx.y * DV;          // output-channel chunk of this workgroup
     const int n = lane & 15, gq = lane >> 4;
     const int grp = wave >> 2, wq = wave & 3;                        // key group (KS == 2), query sub-tile of the wave
-    const int q = qt * 64 + wq * 16 + n;     // this lane's query (as MFMA column / A row)
+    int q = qt * 64 + wq * 16 + n;           // this lane's query (as MFMA column / A row)
 
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.theta + (size_t)b * p.bs_t), 0, p.t_bytes, 0x00020000);
@@ -120,6 +144,13 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.g + (size_t)b * p.bs_g), 0, p.g_bytes, 0x00020000);
 
+    do {      // SK: one pass per segment (a query tile and this chunk's key range of it); otherwise exactly one pass
+    if constexpr (SK) {
+        qt = u / n_tiles;
+        t_lo = u - qt * n_tiles;
+        t_hi = min(n_tiles, t_lo + (u_end - u));
+        q = qt * 64 + wq * 16 + n;
+    }
     // ---- theta rows of this wave's 16 queries -> registers (the B operand of S^T = phi . theta^T) ----
     auto load_theta = [&](int j) -> f32x4 {
         const int col = 16 * j + 4 * gq;
@@ -181,19 +212,18 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
     float m_run = -INFINITY, l_run = 0.f;
     const float inv_nk = 1.0f / (float)p.Nk;
 
-    const int n_tiles = (p.Nk + TK - 1) / TK;
-    issue_tile(0, 0);
+    issue_tile(t_lo, 0);
     // fragment read offsets (floats): phi row = n, slot (4j + gq) ^ swizzle;  g row = 4*gq + r, slot cb*16 + n
     const int k_row_off = (16 * grp + n) * D;                     // (16 * grp is a multiple of every swizzle period)
     const int v_row_off = (16 * grp + 4 * gq) * DV + n * 4;
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int buf = (t - t_lo) & 1;
         // tile t landed: every wave waits for its own DMA pieces, then the barrier; buffer buf^1 is free (its last
         // readers passed this barrier too).  The fragment offsets go through an asm the compiler cannot move
         // above the barrier, so no ds_read of the new tile is scheduled early (cdna_hip_programming.md 5.7).
         int ko = k_row_off, vo = v_row_off;
         tile_barrier(ko, vo);
-        if (t + 1 < n_tiles) issue_tile(t + 1, buf ^ 1);
+        if (t + 1 < t_hi) issue_tile(t + 1, buf ^ 1);
         const float* Kb = Ks + buf * TK * D + ko;
         const float* Vb = Vs + buf * TK * DV + vo;
 
@@ -328,24 +358,54 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
             Mx[(CB * 16 + 1) * 64 + lane] = l_run;
         }
         __syncthreads();
-        if (grp == 1) return;
-        const float m1 = Mx[(CB * 16) * 64 + lane], l1 = Mx[(CB * 16 + 1) * 64 + lane];
-        float a0 = 1.f, a1 = 1.f;
-        if constexpr (SOFTMAX) {
-            const float M = fmaxf(m_run, m1);             // finite: group 0 always owns at least one valid key
-            a0 = __expf(m_run - M);
-            a1 = __expf(m1 - M);                          // exp(-inf) = 0 when group 1 saw no key (its O and l are 0)
-            l_run = l_run * a0 + l1 * a1;
+        if constexpr (!SK) {
+            if (grp == 1) return;
         }
+        if (!SK || grp == 0) {
+            const float m1 = Mx[(CB * 16) * 64 + lane], l1 = Mx[(CB * 16 + 1) * 64 + lane];
+            float a0 = 1.f, a1 = 1.f;
+            if constexpr (SOFTMAX) {
+                const float M = fmaxf(m_run, m1);         // finite: group 0 always owns at least one valid key
+                a0 = __expf(m_run - M);
+                a1 = __expf(m1 - M);                      // exp(-inf) = 0 when group 1 saw no key (its O and l are 0)
+                l_run = l_run * a0 + l1 * a1;
+                m_run = M;
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float b0 = SOFTMAX ? __shfl(a0, 4 * gq + r, 64) : 1.f, b1 = SOFTMAX ? __shfl(a1, 4 * gq + r, 64) : 1.f;
+            for (int r = 0; r < 4; ++r) {
+                const float b0 = SOFTMAX ? __shfl(a0, 4 * gq + r, 64) : 1.f, b1 = SOFTMAX ? __shfl(a1, 4 * gq + r, 64) : 1.f;
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    O[cb][e][r] = O[cb][e][r] * b0 + Mx[((cb * 4 + e) * 4 + r) * 64 + lane] * b1;
+                    for (int e = 0; e < 4; ++e)
+                        O[cb][e][r] = O[cb][e][r] * b0 + Mx[((cb * 4 + e) * 4 + r) * 64 + lane] * b1;
+            }
         }
+    }
+    if constexpr (SK) {
+        // ---- park this segment's (O, m, l): slot (clip, chunk, segment), rows = the tile's 64 queries ----
+        if (grp == 0) {
+            l_run += __shfl_xor(l_run, 16, 64);
+            l_run += __shfl_xor(l_run, 32, 64);
+            float* slot = p.ws + ((size_t)(b * p.sk_chunks + chunk) * 2 + seg) * (size_t)p.ws_slot;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql_ = wq * 16 + 4 * gq + r;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const f32x4 o = {O[cb][0][r], O[cb][1][r], O[cb][2][r], O[cb][3][r]};
+                    *reinterpret_cast<f32x4*>(slot + (size_t)ql_ * DV + cb * 64 + 4 * n) = o;
+                }
+            }
+            if (gq == 0) {
+                slot[64 * DV + wq * 16 + n] = m_run;
+                slot[64 * DV + 64 + wq * 16 + n] = l_run;
+            }
+        }
+        u += t_hi - t_lo;
+        ++seg;
+        __syncthreads();                                  // the merge buffer aliases the tile stages of the next segment
+        continue;
     }
     // ---- epilogue: 1 / l per query, 16-byte stores (lane: query 4*gq + r, channels cb*64 + 4*n .. +3) ----
     float inv = 1.f;
@@ -374,6 +434,59 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
             }
         }
     }
+    } while (SK && u < u_end);
+}
+
+// Stream-K combine: query tile (b, qt) <- its pieces, in chunk order.  Piece k holds unnormalised rows O_k, running maxima m_k
+// and running sums l_k of its key range:  M = max_k m_k,  y = (sum_k O_k e^(m_k - M)) / (sum_k l_k e^(m_k - M)) * scale
+// (scale = 2^-12 under split operands: the factor their softmax weights carry).  One workgroup per query tile, 16-byte items.
+template <int DV>
+__global__ void __launch_bounds__(256) nl_sk_combine_kernel(const NlArgs p, const int n_tiles, const float scale) {
+    // a workgroup = 256 / (DV / 4) query rows of one tile, one 16-byte item per thread: every load of a thread is independent
+    // of the others (one memory round trip), and a clip's 25 tiles x 16 row groups fill the chip
+    constexpr int F4 = DV / 4, ROWS = 256 / F4, PARTS = 64 / ROWS;
+    constexpr int kMaxPieces = 6;            // <= sk_chunks / q_tiles + 2 with q_tiles >= 8 (nl_sk_chunks)
+    const int tile = xcd_remap(blockIdx.x / PARTS, p.q_tiles * p.batch), part = blockIdx.x % PARTS;
+    const int b = tile / p.q_tiles, qt = tile - b * p.q_tiles;
+    const long long U = (long long)p.q_tiles * n_tiles;
+    const int u_lo = qt * n_tiles, u_hi = u_lo + n_tiles;
+    // the pieces of a query tile are consecutive chunks (U >= sk_chunks: no empty chunk in between)
+    int c_first = -1, np = 0;
+    for (int c = 0; c < p.sk_chunks; ++c) {
+        const int lo = (int)((c * U) / p.sk_chunks), hi = (int)(((c + 1) * U) / p.sk_chunks);
+        if (hi <= lo || lo >= u_hi || hi <= u_lo) continue;
+        if (c_first < 0) c_first = c;
+        ++np;
+    }
+    np = min(np, kMaxPieces);
+    const int row = part * ROWS + (int)threadIdx.x / F4, ch = ((int)threadIdx.x % F4) * 4;
+    const int qo = qt * 64 + row;
+    if (qo >= p.Nq || ch >= p.dv || np == 0) return;
+    float m[kMaxPieces], l[kMaxPieces];
+    f32x4 o[kMaxPieces];
+#pragma unroll
+    for (int k = 0; k < kMaxPieces; ++k) {
+        const int c = c_first + min(k, np - 1);
+        const int lo = (int)((c * U) / p.sk_chunks);
+        const int seg = (lo / n_tiles == qt) ? 0 : 1;     // the chunk's first segment is the query tile it starts in
+        const float* pc = p.ws + ((size_t)(b * p.sk_chunks + c) * 2 + seg) * (size_t)p.ws_slot;
+        m[k] = k < np ? pc[64 * DV + row] : -INFINITY;
+        l[k] = pc[64 * DV + 64 + row];
+        o[k] = *reinterpret_cast<const f32x4*>(pc + (size_t)row * DV + ch);
+    }
+    float M = m[0];
+#pragma unroll
+    for (int k = 1; k < kMaxPieces; ++k) M = fmaxf(M, m[k]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxPieces; ++k) {            // chunk order: a fixed summation order
+        const float w = k < np ? __expf(m[k] - M) : 0.f;
+        acc += o[k] * w;
+        lsum += l[k] * w;
+    }
+    const float iv = scale / lsum;
+    *reinterpret_cast<f32x4*>(p.y + (size_t)b * p.bs_y + (size_t)qo * p.ld_y + ch) = acc * iv;
 }
 
 // DS ("d split"): short sequences (Nq <= 512: the layer3 blocks of the video nets, N = 196 / 392 at C = 1024).  There the
@@ -605,9 +718,60 @@ static int launch_nl_x3(const NlArgs& a, hipStream_t st) {
     return a.scale_only ? launch_nl_mode<D, DV, false, 2>(a, st) : launch_nl_mode<D, DV, true, 2>(a, st);
 }
 
+// stream-K launch pair: the chunked attention kernel, then the combine pass (same stream)
+template <int D, int DV, int MODE>
+static int launch_nl_sk(const NlArgs& a, hipStream_t st) {
+    constexpr size_t lds_t = (size_t)2 * 32 * (D + DV) * sizeof(float);
+    constexpr size_t lds_m = (size_t)4 * 64 * ((DV / 64) * 16 + 2) * sizeof(float);
+    constexpr size_t lds = lds_t > lds_m ? lds_t : lds_m;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = nl_attention_kernel<D, DV, true, MODE, false, 2, true>;
+    static bool attr_set[64] = {};   // per device; benign race (idempotent call)
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.sk_chunks * a.batch)), dim3(512), lds, st, a);
+    int rc = hip_check(hipGetLastError(), "nonlocal attention (stream-K) launch");
+    if (rc != PTX_OK) return rc;
+    hipLaunchKernelGGL((nl_sk_combine_kernel<DV>), dim3((unsigned)(a.q_tiles * a.batch * (DV / 16))), dim3(256), 0, st, a,
+                       cdiv(a.Nk, 32), MODE == 2 ? 1.0f / 4096.0f : 1.0f);
+    return hip_check(hipGetLastError(), "nonlocal attention (stream-K combine) launch");
+}
+
+// Chunks per clip of the stream-K form, or 0 when the plain kernels run: a function of PER-SAMPLE extents and the mode only.
+// Covered: softmax attention on the key-split tiles (64 < d <= 256, dv <= 256, Nq > 512, Nk >= 512), 8 <= query tiles <= 64.
+// OFF unless PTX_NL_STREAMK=1 (read at every call): measured SLOWER than the plain key-split kernel on MI355X -- at 8 clips x
+// N = 1568 247 us against 233 (scripts/gpu_r05_attn_scaling.py, profiles/r05_attention_streamk.txt).  The plain kernel's 25
+// workgroups of a clip walk the key tiles in lock-step (the first one pulls a tile into the XCD's L2, 24 hit it); 32 chunks
+// start at 32 different key offsets, the clip's whole 3.2 MB of keys / values is live at once and a step's LDS-DMA no longer
+// returns within one tile of prefetch: 4.7 -> 5.7 us per 32-key step, more than the 22 % of steps the chunks save.
+static int nl_sk_chunks(const ptx_nonlocal_desc* d) {
+    const char* e = getenv("PTX_NL_STREAMK");
+    const int env = e ? atoi(e) : 0;
+    static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
+    static const int ds_env = getenv("PTX_NL_DS") ? atoi(getenv("PTX_NL_DS")) : 1;
+    if (!env || ks_env == 0) return 0;
+    if (d->mode & (PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_OUT_F16 | PTX_NL_RELU)) return 0;
+    if (!(d->d > 64 && d->d <= 256 && d->dv <= 256) || d->Nk < 512) return 0;
+    if (d->Nq <= 512 && ds_env) return 0;
+    const int q_tiles = cdiv(d->Nq, 64);
+    if (q_tiles < 8 || q_tiles > 64) return 0;
+    return q_tiles <= 32 ? 32 : 64;
+}
+static size_t nl_sk_slot_floats(const ptx_nonlocal_desc* d) { return (size_t)64 * (d->dv <= 128 ? 128 : 256) + 128; }
+
 }  // namespace ptx
 
 using namespace ptx;
+
+extern "C" size_t ptx_nonlocal_workspace_bytes(const ptx_nonlocal_desc* d) {
+    if (!d || !ptx_nonlocal_supported(d)) return 0;
+    const int chunks = nl_sk_chunks(d);
+    return chunks ? (size_t)d->batch * chunks * 2 * nl_sk_slot_floats(d) * sizeof(float) : 0;
+}
 
 extern "C" int ptx_nonlocal_supported(const ptx_nonlocal_desc* d) {
     if (!d) return 0;
@@ -617,6 +781,11 @@ extern "C" int ptx_nonlocal_supported(const ptx_nonlocal_desc* d) {
 
 extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, const float* phi, const float* g, float* y,
                                 ptx_stream_t stream) {
+    return ptx_nonlocal_ws_fwd(d, theta, phi, g, y, nullptr, 0, stream);
+}
+
+extern "C" int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* d, const float* theta, const float* phi, const float* g, float* y,
+                                   void* workspace, size_t workspace_bytes, ptx_stream_t stream) {
     if (!d || !theta || !phi || !g || !y) return fail(PTX_ERR_INVALID, "nonlocal: null pointer");
     if (!ptx_nonlocal_supported(d))
         return fail(PTX_ERR_UNSUPPORTED, "nonlocal: need d, dv multiples of 4 and d <= 1024 (d=%d dv=%d); use the "
@@ -668,6 +837,16 @@ extern "C" int ptx_nonlocal_fwd(const ptx_nonlocal_desc* d, const float* theta, 
     // 64 < d <= 256 and Nk >= 128.
     static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
     const bool ksplit = ks_env != 0 && a.Nk >= 128;
+    // stream-K over a caller-provided workspace (ptx_nonlocal_workspace_bytes): long sequences whose query tiles do not fill
+    // the chip evenly.  Without a (large enough, 16-byte aligned) workspace the plain key-split kernel below runs.
+    const int sk = nl_sk_chunks(d);
+    if (sk && workspace && workspace_bytes >= ptx_nonlocal_workspace_bytes(d) && !((uintptr_t)workspace & 15)) {
+        a.sk_chunks = sk;
+        a.ws = static_cast<float*>(workspace);
+        a.ws_slot = (long long)nl_sk_slot_floats(d);
+        if (d->mode & PTX_NL_X3) return d->dv <= 128 ? launch_nl_sk<256, 128, 2>(a, st) : launch_nl_sk<256, 256, 2>(a, st);
+        return d->dv <= 128 ? launch_nl_sk<256, 128, 0>(a, st) : launch_nl_sk<256, 256, 0>(a, st);
+    }
     if (ksplit && d->d > 64 && d->d <= 256) {
         if (d->mode & PTX_NL_X3) return d->dv <= 128 ? launch_nl_ks_x3<256, 128>(a, st) : launch_nl_ks_x3<256, 256>(a, st);
         return d->dv <= 128 ? launch_nl_ks<256, 128>(a, st) : launch_nl_ks<256, 256>(a, st);

@@ -648,6 +648,7 @@ class Plan:
         self.ws_bytes = 0
         self.ws = None
         self.ws_ptr = C.c_void_p(0)
+        self.nl_ws_bytes, self.nl_ws, self.nl_ws_ptr = 0, None, C.c_void_p(0)      # stream-K attention partials
         self.in_ptr = C.c_void_p(0)      # set per run
         self.keepalive = []
         self.tuned = False
@@ -664,6 +665,9 @@ class Plan:
             if self.ws_bytes:
                 self.ws = torch.zeros(self.ws_bytes // 4, device=dev, dtype=torch.float32)
                 self.ws_ptr = _ptr(self.ws)
+            if self.nl_ws_bytes:
+                self.nl_ws = torch.empty(self.nl_ws_bytes // 4, device=dev, dtype=torch.float32)
+                self.nl_ws_ptr = _ptr(self.nl_ws)
         self._cur = None
 
     # ---------------------------------------------------------------- model references
@@ -1223,9 +1227,12 @@ class Plan:
             return False
         lib, tp, pp, gp, yp = self.lib, _ptr(th.t), _ptr(ph.t), _ptr(g.t), _ptr(y.t)
         self.keepalive.append(d)
+        # long sequences run the stream-K form over a scratch buffer of the plan (one for all its attention launches: they
+        # follow each other on one stream; NOT the split-K workspace, whose head may hold arrival counters)
+        self.nl_ws_bytes = max(self.nl_ws_bytes, int(lib.ptx_nonlocal_workspace_bytes(C.byref(d))))
 
-        def step(st):
-            check(lib.ptx_nonlocal_fwd(C.byref(d), tp, pp, gp, yp, st), "ptx_nonlocal_fwd")
+        def step(st, self=self):
+            check(lib.ptx_nonlocal_ws_fwd(C.byref(d), tp, pp, gp, yp, self.nl_ws_ptr, self.nl_ws_bytes, st), "ptx_nonlocal_ws_fwd")
         self.steps.append(_tag(step, "nonlocal_attention", 4 * th.N * (th.S * th.C + ph.S * ph.C + g.S * g.C + th.S * g.C),
                                macs=th.N * th.S * ph.S * (th.C + g.C)))
         self.attn_steps = getattr(self, "attn_steps", 0) + 1

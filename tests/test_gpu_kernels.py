@@ -967,6 +967,82 @@ def test_fused_nonlocal_attention(ptx, case):
     assert lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(y), _st()) != 0
 
 
+@pytest.mark.parametrize("case", [
+    (2, 1568, 1568, 256, 256, "", "layer2 of config 3: 25 query tiles -> 32 chunks of 38.3 units per clip"),
+    (1, 3136, 3136, 128, 128, "", "the reference's usual N at 16 x 224 x 224: 49 query tiles -> 64 chunks; <256,128> tiles"),
+    (3, 530, 1000, 200, 136, "", "ragged everything: 9 query tiles (the last of 18 queries), 32 key tiles (the last of 8 keys)"),
+    (2, 1568, 784, 256, 256, "x3", "split operands, sub-sampled keys"),
+    (1, 600, 520, 96, 256, "x3", "split operands, ragged"),
+])
+def test_nonlocal_attention_stream_k(ptx, case, monkeypatch):
+    """(PTX_NL_STREAMK=1: the form is off by default -- measured slower than the plain kernel)
+    ptx_nonlocal_ws_fwd with the workspace ptx_nonlocal_workspace_bytes asks for: the stream-K form (the units of one clip
+    in 32 / 64 equal chunks, partial (O, max, sum) blocks folded by a combine launch) against the op sequence in torch fp32,
+    and against the plain kernel (same arithmetic, another summation order); per-clip results do not depend on the batch;
+    without (or with too small) a workspace the call runs exactly what ptx_nonlocal_fwd runs."""
+    L, lib = ptx._lib, _lib(ptx)
+    B, Nq, Nk, d, dv, flavour, _ = case
+    monkeypatch.setenv("PTX_NL_STREAMK", "1")
+    g_ = torch.Generator().manual_seed(2000 + Nq + d)
+    ld = _r4(2 * d + dv) + 4
+    tpg_q = torch.randn(B, Nq, ld, generator=g_)
+    tpg_k = torch.randn(B, Nk, ld, generator=g_)
+    tpg_q[..., :d] *= 3.0 / d ** 0.5
+    theta, phi, gv = tpg_q[..., :d], tpg_k[..., d:2 * d], tpg_k[..., 2 * d:2 * d + dv]
+    want = torch.matmul(F.softmax(torch.matmul(theta, phi.transpose(1, 2)), dim=-1), gv)
+    tq, tk = tpg_q.to(DEV), tpg_k.to(DEV)
+    ldy = _r4(dv) + 8
+
+    def desc_for(batch):
+        desc = L.NonlocalDesc()
+        desc.batch, desc.Nq, desc.Nk, desc.d, desc.dv = batch, Nq, Nk, d, dv
+        desc.ld_theta = desc.ld_phi = desc.ld_g = ld
+        desc.ld_y = ldy
+        desc.bs_theta, desc.bs_phi, desc.bs_g, desc.bs_y = Nq * ld, Nk * ld, Nk * ld, Nq * ldy
+        desc.mode = L.PTX_NL_SOFTMAX | (L.PTX_NL_X3 if flavour == "x3" else 0)
+        return desc
+    desc = desc_for(B)
+    need = lib.ptx_nonlocal_workspace_bytes(C.byref(desc))
+    chunks = 32 if (Nq + 63) // 64 <= 32 else 64
+    assert need == B * chunks * 2 * (64 * (128 if dv <= 128 else 256) + 128) * 4
+    ws = torch.full((need // 4 + 4,), float("nan"), device=DEV)
+
+    def run(desc, wsp, nbytes, tq_=tq, tk_=tk):
+        y = torch.full((desc.batch, Nq, ldy), float("nan"), device=DEV)
+        L.check(lib.ptx_nonlocal_ws_fwd(C.byref(desc), _p(tq_), _p(tk_, d), _p(tk_, 2 * d), _p(y), wsp, nbytes, _st()), "nonlocal ws")
+        torch.cuda.synchronize()
+        return y.cpu()
+    got = run(desc, _p(ws), need)
+    assert torch.isnan(got[..., dv:]).all() and torch.isnan(ws[need // 4:]).all()
+    bound = 2e-5 * max(1.0, want.abs().max().item())
+    assert (got[..., :dv] - want).abs().max().item() <= bound, case
+    plain = torch.full((B, Nq, ldy), float("nan"), device=DEV)
+    L.check(lib.ptx_nonlocal_fwd(C.byref(desc), _p(tq), _p(tk, d), _p(tk, 2 * d), _p(plain), _st()), "nonlocal")
+    torch.cuda.synchronize()
+    assert (got[..., :dv] - plain.cpu()[..., :dv]).abs().max().item() <= bound
+    # no workspace / a short one / a misaligned one: the plain kernels, bit for bit
+    for wsp, nb in ((None, 0), (_p(ws), need - 16), (C.c_void_p(ws.data_ptr() + 4), need)):
+        assert torch.equal(run(desc, wsp, nb)[..., :dv], plain.cpu()[..., :dv])
+    # repeatable, and a clip's bits do not depend on the batch it arrives in (the split is per clip)
+    assert torch.equal(run(desc, _p(ws), need)[..., :dv], got[..., :dv])
+    if B > 1:
+        d1 = desc_for(1)
+        for b in range(B):
+            one = run(d1, _p(ws), need, tq[b:b + 1].contiguous(), tk[b:b + 1].contiguous())
+            assert torch.equal(one[0, :, :dv], got[b, :, :dv]), (case, b)
+    # shapes the stream-K form does not cover ask for no workspace
+    short = desc_for(B)
+    short.Nq = 256
+    short.bs_theta, short.bs_y = 256 * ld, 256 * ldy
+    assert lib.ptx_nonlocal_workspace_bytes(C.byref(short)) == 0
+    sc = desc_for(B)
+    sc.mode = L.PTX_NL_SCALE
+    assert lib.ptx_nonlocal_workspace_bytes(C.byref(sc)) == 0
+    monkeypatch.delenv("PTX_NL_STREAMK")          # the default: no workspace asked for, the plain kernels whatever is passed
+    assert lib.ptx_nonlocal_workspace_bytes(C.byref(desc)) == 0
+    assert torch.equal(run(desc, _p(ws), need)[..., :dv], plain.cpu()[..., :dv])
+
+
 def _fused_stage_case(ptx, N, H, W, Ci, Co, k, up2, affine, relu, tanh, out16, dual, skip, cfgs):
     """One ptx_conv3d_fused_fwd launch per tile configuration against the op sequence it replaces, in torch fp32 on
     the CPU with the SAME half-rounded operands: [nearest x2] -> conv -> (+ skip) -> [raw] -> affine -> relu | tanh."""

@@ -112,6 +112,32 @@ def test_config3_full_size_parity(ptx, case):
     print("%s max|dlogits| = %.3e (max|logit| %.2f)" % (case, err, ref.abs().max().item()))
 
 
+def test_stream_k_attention_in_a_plan(ptx, monkeypatch):
+    """PTX_NL_STREAMK=1 (off by default: measured slower): the N = 1568 attention launches of config 3's
+    full-strength NL composite run the stream-K form over the plan's scratch buffer -- same golden logits at the 1e-3 bar,
+    1e-4-class equal to the plain kernels, and the plan asks for the scratch only then."""
+    case = "nonlocal_r2plus1d50_cfg3_fullnl"
+    arch, kw = GOLDEN_CASES[case]
+    blob = load_golden(case)
+    model, _ = _build(ptx, arch, kw, **golden_recipe(blob))
+    x = golden_input(blob).to(DEV)
+    ref = torch.from_numpy(blob["logits"])
+    plain = model(x).clone()
+    assert all(p_.nl_ws_bytes == 0 for p_ in model.engine()._plans.values())
+    monkeypatch.setenv("PTX_NL_STREAMK", "1")
+    model.engine().invalidate()
+    out = model(x)
+    plan = list(model.engine()._plans.values())[-1]
+    assert plan.nl_ws_bytes == x.shape[0] * 32 * 2 * (64 * 256 + 128) * 4 and plan.nl_ws is not None
+    _check(out, ref, case + " (stream-K attention) logits vs golden")
+    assert torch.equal(out.cpu().argmax(1), ref.argmax(1))
+    assert (out - plain).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.equal(model(x), out)
+    monkeypatch.delenv("PTX_NL_STREAMK")
+    model.engine().invalidate()
+    assert torch.equal(model(x), plain)
+
+
 def test_full_size_properties(ptx):
     """Size-independent properties at the full config-2 shape: determinism (bit-exact),
     batch-permutation equivariance (split-K slices the tile's *pruned* k-space, so the grouping of
