@@ -246,6 +246,38 @@ def test_dataparallel_replicas_share_engine_plans_and_signature(ptx):
     assert [r.name.rsplit(".", 1)[1] for r in nl.convs] == ["theta", "phi", "g"]
 
 
+def test_stream_k_attention_workspace_rule_is_per_sample(ptx, monkeypatch):
+    """ptx_nonlocal_workspace_bytes (host logic, no GPU): 0 unless PTX_NL_STREAMK=1; then a function of the per-sample extents
+    and the mode only -- 32 chunks per clip up to 32 query tiles, 64 up to 64, two slots of [64][DV] + 128 floats per chunk,
+    linear in the batch -- and 0 for everything the stream-K form does not cover (short sequences, few keys, scale-only /
+    fp16 modes, narrow or wide channel counts)."""
+    import ctypes as C_
+    L = ptx._lib
+    lib = L.lib()
+
+    def need(batch=8, Nq=1568, Nk=1568, d=256, dv=256, mode=0):
+        desc = L.NonlocalDesc()
+        desc.batch, desc.Nq, desc.Nk, desc.d, desc.dv = batch, Nq, Nk, d, dv
+        desc.ld_theta = desc.ld_phi = desc.ld_g = 768
+        desc.ld_y = 256
+        desc.bs_theta = desc.bs_phi = desc.bs_g = Nk * 768
+        desc.bs_y = Nq * 256
+        desc.mode = mode
+        return lib.ptx_nonlocal_workspace_bytes(C_.byref(desc))
+    monkeypatch.delenv("PTX_NL_STREAMK", raising=False)
+    assert need() == 0
+    monkeypatch.setenv("PTX_NL_STREAMK", "1")
+    slot = (64 * 256 + 128) * 4
+    assert need() == 8 * 32 * 2 * slot and need(batch=1) == 32 * 2 * slot and need(batch=3) == 3 * need(batch=1)
+    assert need(Nq=3136, Nk=3136) == 8 * 64 * 2 * slot                       # 49 query tiles -> 64 chunks
+    assert need(dv=128) == 8 * 32 * 2 * (64 * 128 + 128) * 4                 # the <256, 128> tiles
+    assert need(Nq=2048 + 1) == 8 * 64 * 2 * slot and need(Nq=64 * 64 + 1) == 0      # beyond 64 query tiles: plain kernel
+    for kw in (dict(Nq=512), dict(Nq=7 * 64), dict(Nk=500), dict(d=64), dict(d=260), dict(dv=260),
+               dict(mode=L.PTX_NL_SCALE), dict(mode=L.PTX_NL_F16, d=64, dv=64)):
+        assert need(**kw) == 0, kw
+    assert need(mode=L.PTX_NL_X3) == need()
+
+
 def test_clip_lanes_knob(ptx, monkeypatch):
     """Engine.lanes: opt-in, validated, read from PTX_LANES at construction; lanes_for() never errors -- a batch the lane
     count does not divide (or the hipGraph mode) keeps the single-plan path."""
