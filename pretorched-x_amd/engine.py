@@ -18,6 +18,7 @@ import ctypes as C
 import json
 import os
 import threading
+import time
 import weakref
 
 import torch
@@ -526,6 +527,24 @@ def prog_store(key, use_program):
     table = _tuned_table()
     with _tuned_lock:
         table["prog:" + key] = ("program" if use_program else "launches", 1)
+
+
+def lanes_key(model, shape, precision="fp32"):
+    """Tuned-table key of the clip-lanes decision: one per (architecture, input shape, arithmetic)."""
+    name = getattr(model, "arch_name", None) or type(model).__name__
+    return "lanes:" + json.dumps([str(name), [int(v) for v in shape], precision])
+
+
+def lanes_lookup(key):
+    """Lanes the tuner measured best for this (architecture, shape), or None when it was never measured."""
+    ent = _tuned_table().get(key)
+    return None if ent is None or ent[0] != "lanes" else int(ent[1])
+
+
+def lanes_store(key, n):
+    table = _tuned_table()
+    with _tuned_lock:
+        table[key] = ("lanes", int(n))
 
 
 def alt_lookup(key):
@@ -1692,6 +1711,7 @@ class Engine:
         self._tensors = None             # (epoch, flat list of the owner's parameters and buffers)
         self.plan_builds = 0             # diagnostics: plans compiled / filter re-packs so far
         self.weight_refreshes = 0
+        self.last_profile = None         # calibration record of the last profile_steps() call
         # How a forward decides whether the packed (BN-folded) filters are still current:
         #   True / "version"  (default) compare (data_ptr, _version) of every parameter and buffer of the owner
         #                     model -- catches load_state_dict, optimizer-style in-place updates, copy_();
@@ -1724,15 +1744,21 @@ class Engine:
         # Off by default: every nn.Parameter requires grad, so plain inference without torch.no_grad() would leave
         # the HIP engine.
         self.autograd = os.environ.get("PTX_AUTOGRAD", "0") == "1"
-        # Opt-in clip lanes (forward() only): the batch is cut into `lanes` equal contiguous slices, each slice runs through
+        # Clip lanes (forward() only): the batch is cut into `lanes` equal contiguous slices, each slice runs through
         # ITS OWN plan (own activation buffers and split-K workspace) on its own HIP stream, and the logits are concatenated
         # in clip order.  The slices are independent chains of launches, so one lane's launch gaps, tile tails and
         # HBM-bound passes overlap the other's matrix-bound kernels: +2.0-2.5 % on configs 2 and 4 with two lanes on MI355X,
-        # nothing on config 3, a loss with four.  Off by default: per-clip results are those of the
-        # slice-sized batch (another tile / split-K choice than the full batch: same 1e-5 class, not the same bits).
-        self._lanes = 1
+        # nothing on config 3, a loss with four.
+        #   "auto" (default, round 6)  what the tuned table holds for this (architecture, input shape): 2 where
+        #                              Engine.autotune measured two lanes >= 1.5 % faster than one ("lanes:" keys, the same
+        #                              kind of measured accept rule as the chained launches' "alt:" keys), else 1;
+        #   1 .. 8                     forced.
+        # Per-clip results with n lanes are those of the slice-sized batch (another tile / split-K choice than the full
+        # batch: same 1e-5 class, not the same bits).
+        self._lanes = "auto"
         self._lane_streams = {}          # device index -> side streams of lanes 1 .. n-1 (lane 0 runs on the caller's stream)
-        self.lanes = int(os.environ.get("PTX_LANES", "1"))
+        env = os.environ.get("PTX_LANES", "auto")
+        self.lanes = "auto" if env == "auto" else int(env)
 
     @property
     def lanes(self):
@@ -1740,15 +1766,51 @@ class Engine:
 
     @lanes.setter
     def lanes(self, value):
+        if value == "auto" and isinstance(value, str):
+            self._lanes = "auto"
+            return
         if not isinstance(value, int) or isinstance(value, bool) or not 1 <= value <= 8:
-            raise PtxError("Engine.lanes must be an integer in 1..8 (got %r)" % (value,))
+            raise PtxError("Engine.lanes must be \"auto\" or an integer in 1..8 (got %r)" % (value,))
         self._lanes = value
 
-    def lanes_for(self, batch):
-        """Lanes forward() uses for a batch of this size: `lanes` when it cuts the batch into equal non-empty slices and the
-        hipGraph replay is off, else 1 (the plain single-plan path -- never an error)."""
+    def lanes_for(self, batch, model=None, shape=None):
+        """Lanes forward() uses for a batch of this size: `lanes` ("auto": the tuned table's entry for this model and input
+        shape, 1 without one) when it cuts the batch into equal non-empty slices and the hipGraph replay is off, else 1
+        (the plain single-plan path -- never an error)."""
         n = self._lanes
+        if n == "auto":
+            n = 1
+            if model is not None and shape is not None and not self.use_graph:
+                n = lanes_lookup(lanes_key(model, shape, self._precision)) or 1
         return n if (n > 1 and not self.use_graph and batch >= n and batch % n == 0) else 1
+
+    def tune_lanes(self, model, x, iters=8, verbose=False):
+        """Measure forward(model, x) with one and with two clip lanes (each on its own tuned plans) and record the verdict in
+        the tuned table: two lanes must win by 1.5 % (the lanes double the activation buffers).  Returns the lanes kept."""
+        x = _dense16(x)
+        key = lanes_key(model, x.shape, self._precision)
+        if self.use_graph or x.shape[0] < 2 or x.shape[0] % 2:
+            return 1
+        keep = self._lanes
+        ms = {}
+        try:
+            for n in (1, 2):
+                self._lanes = n
+                for _ in range(2):
+                    self.forward(model, x)
+                torch.cuda.synchronize(x.device)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self.forward(model, x)
+                torch.cuda.synchronize(x.device)
+                ms[n] = 1e3 * (time.perf_counter() - t0) / iters
+        finally:
+            self._lanes = keep
+        best = 2 if ms[2] < 0.985 * ms[1] else 1
+        lanes_store(key, best)
+        if verbose:
+            print("tune clip lanes %s: 1 lane %.3f ms | 2 lanes %.3f ms -> %d" % (key, ms[1], ms[2], best))
+        return best
 
     @property
     def precision(self):
@@ -2003,7 +2065,7 @@ class Engine:
             return big
         x = _dense16(x)
         with torch.cuda.device(x.device):
-            n = self.lanes_for(x.shape[0])
+            n = self.lanes_for(x.shape[0], model, x.shape)
             if n > 1:
                 return self._forward_lanes(model, x, n)
             plan = self.plan_for(model, x)
@@ -2016,7 +2078,7 @@ class Engine:
     def lane_plans(self, model, x):
         """The plans forward(model, x) runs, lane 0 first (one plan unless Engine.lanes cuts this batch)."""
         x = _dense16(x)
-        n = self.lanes_for(x.shape[0])
+        n = self.lanes_for(x.shape[0], model, x.shape)
         per = x.shape[0] // n
         plans = []
         with torch.cuda.device(x.device):
@@ -2082,7 +2144,7 @@ class Engine:
         if N > mb:      # balanced chunks (64 -> 32 + 32, not 63 + 1): every chunk keeps the GEMMs' M large
             size = -(-N // (-(-N // mb)))
             starts = list(range(0, N, size))
-            n = min(self._lanes, len(starts)) if not self.use_graph else 1
+            n = min(self._lanes, len(starts)) if (not self.use_graph and self._lanes != "auto") else 1
             if n > 1:
                 # clip lanes (Engine.lanes): chunk k through plan k % n on stream k % n -- the chunks are
                 # independent chains of launches and the generator mixes HBM-bound and matrix-bound kernels
@@ -2174,8 +2236,23 @@ class Engine:
             self._validate(model, x, model.arch.dims)
             with torch.cuda.device(x.device):
                 plan = self.plan_for(model, _dense16(x))
+        own_plan = plan is not None
         with torch.cuda.device(x.device), plan.exclusive():
-            return self._autotune(model, x, iters, verbose, persist, only_untuned, plan)
+            plan = self._autotune(model, x, iters, verbose, persist, only_untuned, plan)
+        # the clip-lanes verdict of this (architecture, shape), measured on the tuned tiles of both launch shapes -- only for
+        # the engine's own full-batch plan and only when the knob is on "auto"
+        if (self._lanes == "auto" and not own_plan and not self.use_graph and x.shape[0] >= 2 and x.shape[0] % 2 == 0
+                and os.environ.get("PTX_TUNE_LANES", "1") != "0"
+                and not (only_untuned and lanes_lookup(lanes_key(model, _dense16(x).shape, self._precision)) is not None)):
+            with torch.cuda.device(x.device):
+                half = _dense16(_dense16(x)[:x.shape[0] // 2])
+                hp = self.plan_for(model, half)
+                with hp.exclusive():
+                    self._autotune(model, half, iters, verbose, False, only_untuned, hp)
+                self.tune_lanes(model, x, verbose=verbose)
+            if persist:
+                save_tuned_table()
+        return plan
 
     def _autotune(self, model, x, iters=3, verbose=False, persist=False, only_untuned=False, plan=None):
         lib = _lib.lib()
@@ -2428,17 +2505,27 @@ class Engine:
         """HIP-event time of EVERY launch of a compiled (and run) plan on the current stream, convs and HBM-bound
         passes alike: rows of (label, kind, algorithmic bytes, MACs, ms, tile / kernel name).  kind is "conv" for the
         implicit-GEMM launches, "stem" for the direct stem kernels, "mem" for tagged HBM passes, "mfma" for the fused attention, "other" for the rest.
-        Each launch is bracketed by its own event pair INSIDE `iters` ordinary passes over the plan (round 5), so it is timed in
-        the company it keeps in a forward -- the same caches, the same clock / power state.  `isolated=True` (or
-        PTX_PROFILE_ISOLATED=1) is the older method, every launch repeated `iters` times back to back on its own: on the round-5
-        boxes that over-states the MFMA-bound launches by 5-19 % (the stem 1.76 ms against 1.50-1.62 ms in a forward; the
-        rows then SUM to more than the step they are part of), because five identical matrix-bound launches in a row pull the
-        clock down."""
+
+        Method (round 6).  The launches are timed INSIDE ordinary passes over the plan -- the caches and the clock / power
+        state of a forward -- by a CHAIN of events, one after every launch: interval i = event i -> event i + 1, so the
+        intervals of a pass sum to that pass by construction.  An event between two launches costs the stream a marker
+        packet, so an instrumented pass is longer than a plain one; the same call therefore also times `iters` PLAIN passes
+        (two events around all of them) and removes the difference as a constant per launch:
+            overhead = (instrumented pass - plain pass) / launches,   ms_i = interval_i - overhead
+        so that sum(ms_i) == the plain pass (rows are rescaled by a common factor if a clamp at 25 % of the raw interval
+        was hit).  `self.last_profile` keeps the calibration: {"plain_pass_ms", "instrumented_pass_ms", "launches",
+        "overhead_us_per_launch", "raw_sum_ms", "clamped"}.  Round 5 bracketed each launch with its OWN pair of events and
+        reported the raw brackets: they summed to 5.76 ms in a 5.39 ms step.
+
+        `isolated=True` (or PTX_PROFILE_ISOLATED=1) is the round-1..4 method, every launch repeated `iters` times back to back
+        on its own: it over-states the MFMA-bound launches by 5-19 % (five identical matrix-bound launches in a row pull
+        the clock down)."""
         if isolated is None:
             isolated = os.environ.get("PTX_PROFILE_ISOLATED", "0") == "1"
         st = _stream()
         flat = [t for s in plan.steps for t in (s.active() if isinstance(s, (AltStep, ProgramStep)) else [s])]
         ms_of = []
+        self.last_profile = None
         if isolated:
             for stp in flat:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -2450,16 +2537,41 @@ class Engine:
                 e1.synchronize()
                 ms_of.append(e0.elapsed_time(e1) / iters)
         else:
-            for stp in flat:                    # one untimed pass: every launch has run once in this order
-                stp(st)
-            ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in flat] for _ in range(iters)]
-            for it in range(iters):
-                for i, stp in enumerate(flat):
-                    ev[it][i][0].record()
+            n = len(flat)
+            for _ in range(2):                  # untimed passes: every launch has run in this order, clocks are up
+                for stp in flat:
                     stp(st)
-                    ev[it][i][1].record()
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
+            pa, pb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pc, pd = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def plain(e0, e1, k):
+                e0.record()
+                for _ in range(k):
+                    for stp in flat:
+                        stp(st)
+                e1.record()
+            half = max(1, iters // 2)
+            plain(pa, pb, half)                 # plain passes on BOTH sides of the instrumented ones (clock drift)
+            for it in range(iters):
+                ev[it][0].record()
+                for i, stp in enumerate(flat):
+                    stp(st)
+                    ev[it][i + 1].record()
+            plain(pc, pd, half)
             torch.cuda.synchronize()
-            ms_of = [sum(ev[it][i][0].elapsed_time(ev[it][i][1]) for it in range(iters)) / iters for i in range(len(flat))]
+            plain_ms = (pa.elapsed_time(pb) + pc.elapsed_time(pd)) / (2 * half)
+            raw = [sum(ev[it][i].elapsed_time(ev[it][i + 1]) for it in range(iters)) / iters for i in range(n)]
+            inst_ms = sum(ev[it][0].elapsed_time(ev[it][n]) for it in range(iters)) / iters
+            over = max(0.0, (inst_ms - plain_ms) / max(n, 1))
+            ms_of = [max(r - over, 0.25 * r) for r in raw]
+            clamped = sum(1 for r in raw if r - over < 0.25 * r)
+            tot = sum(ms_of)
+            if tot > 0 and (clamped or inst_ms < plain_ms):
+                ms_of = [m * plain_ms / tot for m in ms_of]
+            self.last_profile = {"method": "event chain inside ordinary passes, constant per-launch marker overhead removed",
+                                 "iters": iters, "launches": n, "plain_pass_ms": plain_ms, "instrumented_pass_ms": inst_ms,
+                                 "raw_sum_ms": sum(raw), "overhead_us_per_launch": 1e3 * over, "clamped": clamped}
         rows = []
         for stp, ms in zip(flat, ms_of):
             if isinstance(stp, ConvStep):

@@ -279,19 +279,42 @@ def test_stream_k_attention_workspace_rule_is_per_sample(ptx, monkeypatch):
 
 
 def test_clip_lanes_knob(ptx, monkeypatch):
-    """Engine.lanes: opt-in, validated, read from PTX_LANES at construction; lanes_for() never errors -- a batch the lane
-    count does not divide (or the hipGraph mode) keeps the single-plan path."""
+    """Engine.lanes: "auto" by default (round 6: the tuned table's measured verdict per architecture and input shape, 1
+    without one), validated, read from PTX_LANES at construction; lanes_for() never errors -- a batch the lane count does
+    not divide (or the hipGraph mode) keeps the single-plan path."""
+    from pretorched_x_amd import engine as E
+    monkeypatch.delenv("PTX_LANES", raising=False)
     m = ptx.resnet3d10(num_classes=3)
     e = m.engine()
-    assert e.lanes == 1 and e.lanes_for(8) == 1
+    assert e.lanes == "auto" and e.lanes_for(8) == 1
+    shape = (8, 3, 4, 32, 32)
+    assert e.lanes_for(8, m, shape) == 1                    # never measured: one plan
+    key = E.lanes_key(m, shape, "fp32")
+    assert key.startswith("lanes:") and "resnet3d10" in key
+    try:
+        E.lanes_store(key, 2)                               # what Engine.tune_lanes records when two lanes win by 1.5 %
+        assert E.lanes_lookup(key) == 2 and e.lanes_for(8, m, shape) == 2
+        assert e.lanes_for(8, m, (8, 3, 4, 32, 48)) == 1    # another shape is another decision
+        assert e.lanes_for(7, m, (7,) + shape[1:]) == 1
+        e.use_graph = True
+        assert e.lanes_for(8, m, shape) == 1
+        e.use_graph = False
+        E.lanes_store(key, 1)
+        assert e.lanes_for(8, m, shape) == 1
+        # the entry travels with the tuned table (rank 0 tunes, every rank adopts: parallel.broadcast_tuned_table)
+        assert E.tuned_snapshot()[key] == ("lanes", 1)
+    finally:
+        E._tuned_table().pop(key, None)
     e.lanes = 2
     assert [e.lanes_for(b) for b in (1, 2, 3, 8)] == [1, 2, 1, 2]
     e.use_graph = True
     assert e.lanes_for(8) == 1
     e.use_graph = False
-    for bad in (0, 9, -1, 2.0, "2", True):
+    for bad in (0, 9, -1, 2.0, "2", True, "Auto"):
         with pytest.raises(ptx.PtxError):
             e.lanes = bad
+    e.lanes = "auto"
+    assert e.lanes == "auto"
     monkeypatch.setenv("PTX_LANES", "2")
     assert ptx.resnet3d10(num_classes=3).engine().lanes == 2
     import copy

@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the clip-parallel path (runs on CPU): sharding + the single
-all-gather must reproduce the rank-order == clip-order of the whole batch, for equal and ragged
-shards.  The forward itself is a stand-in (the HIP engine needs a GPU); the collective logic
-is what is under test."""
+"""gloo tests of the clip-parallel path (run on CPU): sharding + the single all-gather must reproduce the
+rank-order == clip-order of the whole batch, for equal and ragged shards -- at world size 2 and, since round 6, at world
+size 8 in the regimes the metric names (8 clips per rank; config 4's 16 clips over 8 ranks; strong scaling at 1 clip per
+rank; a ragged 12-over-8 in which two ranks hold nothing).  The forward itself is a stand-in (the HIP engine needs a
+GPU); the collective logic, bench.py's timed region and its launcher are what is under test."""
 import os
 import socket
 import sys
@@ -23,7 +24,9 @@ def _free_port():
 
 def _fake_forward(clips):
     # deterministic per-clip "logits": depends only on the clip's content
-    flat = clips.reshape(clips.shape[0], -1)
+    flat = clips.flatten(1)                   # (an empty shard -- 12 clips over 8 ranks -- gives [0, 4] logits)
+    if flat.shape[0] == 0:
+        return flat.new_zeros((0, 4))
     return torch.stack([flat.mean(1), flat.abs().max(1).values, flat[:, 0], flat.sum(1)], 1)
 
 
@@ -101,6 +104,30 @@ def _strong_worker(rank, world, port, total, q, workload):
     dist.destroy_process_group()
 
 
+def _collect(procs, q, world, limit=240.0):
+    """One result per rank -- or a failure as soon as a rank dies / the deadline passes: never a parent blocked forever on
+    a queue nobody will write to (the other ranks of a dead one sit in a collective until gloo times out)."""
+    import time
+    res, deadline = [], time.time() + limit
+    try:
+        while len(res) < world:
+            if not q.empty():
+                res.append(q.get())
+                continue
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "a rank exited with %s" % dead
+            assert time.time() < deadline, "ranks did not report within %.0f s (%d of %d did)" % (limit, len(res), world)
+            time.sleep(0.05)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return res
+
+
 def _run(total, world=2, target=None, extra=()):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -109,18 +136,11 @@ def _run(total, world=2, target=None, extra=()):
         procs = [ctx.Process(target=target, args=(r, world, port, total, q) + tuple(extra)) for r in range(world)]
         for p in procs:
             p.start()
-        res = [q.get() for _ in range(world)]
-        for p in procs:
-            p.join(60)
-            assert p.exitcode == 0
-        return res
+        return _collect(procs, q, world)
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get() for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = _collect(procs, q, world)
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (total, 4) for _, _, shape in res), res
 
@@ -202,3 +222,78 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env_nccl, capture_output=True, text=True, timeout=300)
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "visible GPU" in r.stderr, r.stderr[-500:]
+
+
+# ---- world size 8: the regimes the metric names -------------------------------------------------------------
+
+def test_world8_gather_equal_and_ragged():
+    """8 ranks: 64 clips (8 per rank, the weak-scaling shape), 16 (config 4: 2 per rank), 8 (strong: 1 per rank) and 12
+    (torch.chunk semantics, as DataParallel's scatter: six ranks hold 2 clips, ranks 6 and 7 hold none)."""
+    for total in (64, 16, 8, 12):
+        _run(total=total, world=8)
+
+
+def test_world8_bench_weak_regime_is_self_verifying():
+    """bench.timed_steps at 8 ranks x 8 clips + verify_gather + the rank-0 tuned-table broadcast."""
+    res = _run(total=64, world=8, target=_bench_worker, extra=(False,))
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, verify, ok_out, calls, timed, has, n in res:
+        assert verify == {"gather_order_ok": True, "replicas_identical": True, "ranks": 8, "rows": 64,
+                          "deterministic": True}, (rank, verify)
+        assert ok_out and timed and calls == 5
+        assert has == ("64x64x16/2x2/m32/dma", 2) and n
+    res = _run(total=64, world=8, target=_bench_worker, extra=(True,))
+    assert all(v["gather_order_ok"] and v["replicas_identical"] and v["deterministic"] is False for _, v, *_ in res)
+
+
+def test_world8_bench_strong_regimes():
+    """--scaling strong at 8 ranks: config 4 (16 clips, 2 per rank), the headline batch (8 clips, ONE per rank) and a ragged
+    12-clip batch (2,2,2,2,2,2,0,0): every rank ends with the whole batch's logits in clip order."""
+    from pretorched_x_amd.parallel import shard_bounds
+    for total, workload in ((16, "cfg4"), (8, "cfg2"), (12, "cfg3")):
+        res = _run(total=total, world=8, target=_strong_worker, extra=(workload,))
+        per = {rank: n for rank, _, _, n, _ in res}
+        assert [per[r] for r in range(8)] == [shard_bounds(total, 8, r)[1] - shard_bounds(total, 8, r)[0] for r in range(8)]
+        assert sum(per.values()) == total
+        for rank, verify, ok, n, tot in res:
+            assert tot == total and ok, (rank, n)
+            assert verify["gather_order_ok"] and verify["replicas_identical"] and verify["deterministic"] and verify["rows"] == total
+            assert verify["ranks"] == 8
+
+
+def test_bench_gpus_8_self_launch_standin_lines():
+    """`python bench.py --gpus 8 --scaling both` WITHOUT a launcher and without GPUs: PTX_BENCH_STANDIN=1 + PTX_BENCH_BACKEND=gloo
+    runs the real N-rank code path of bench.py (self-launch under torch.distributed.run, local_batch, timed_steps, the
+    gather, the per-rank bookkeeping) with a CPU stand-in forward.  One JSON line per scaling mode, 8 entries in
+    rank_ms_per_step and ranks_seen; config 4's 16 clips leave 2 per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, PTX_BENCH_STANDIN="1", PTX_BENCH_BACKEND="gloo", PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PTX_BENCH_LAUNCH_CHECK"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--scaling", "both", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and [ln["scaling"] for ln in lines] == ["weak", "strong"], (r.stderr[-1500:], lines)
+    weak, strong = lines
+    for ln in lines:
+        assert ln["standin"] is True and ln["n_gpus"] == 8 and ln["roofline"] is None
+        assert "FUNCTIONAL CHECK" in ln["config"]["parallelism"]
+        assert len(ln["rank_ms_per_step"]["ms_per_step"]) == 8 and ln["rank_ms_per_step"]["max"] >= ln["rank_ms_per_step"]["min"] > 0
+        seen = ln["ranks_seen"]
+        assert seen["world_size"] == 8 and sorted(r_["rank"] for r_ in seen["ranks"]) == list(range(8))
+        assert len({r_["pid"] for r_ in seen["ranks"]}) == 8
+        assert ln["distributed_check"] == {"gather_order_ok": True, "replicas_identical": True, "ranks": 8,
+                                           "rows": ln["config"]["global_batch"], "deterministic": True}
+    assert weak["config"]["global_batch"] == 64 and [r_["units"] for r_ in weak["ranks_seen"]["ranks"]] == [8] * 8
+    assert strong["config"]["global_batch"] == 8 and [r_["units"] for r_ in strong["ranks_seen"]["ranks"]] == [1] * 8
+    # config 4: 16 clips over 8 ranks, strong by construction
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--workload", "cfg4", "--scaling", "strong", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-1500:]
+    assert lines[0]["config"]["global_batch"] == 16 and [r_["units"] for r_ in lines[0]["ranks_seen"]["ranks"]] == [2] * 8
+    # the stand-in refuses to pose as an RCCL run
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(env, PTX_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "PTX_BENCH_STANDIN" in r.stderr
