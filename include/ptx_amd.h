@@ -185,65 +185,6 @@ int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tai
                          const float* bias, const float* w2_packed, const float* bias2, const float* res, float* y,
                          int config, ptx_stream_t stream);
 
-/* --------------------------------------------------------------------------------------------
- * Conv PROGRAM: an ordered list of fp32 convolutions (bias / ReLU / same-shape residual epilogues, optional second source)
- * executed by ONE persistent launch -- the small-M tail of a video ResNet, where a launch per conv is bound by tile
- * quantisation on 256 CUs and per-launch ramps rather than by the matrix cores.  Replaces the op sequence of whole
- * bottlenecks:  conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu, block after block
- * (resnet3D.py:125-143 with shortcut B :175-185; the six factored GEMMs of a (2+1)D bottleneck, r2plus1d.py:68-88).
- * The tiles of all stages sit on one queue -- in wavefront order over (stage, clip group), so tiles of several stages are
- * runnable at any time -- persistent workgroups take them in order and a tile waits only for the ROW TILES of the producing
- * stages it reads (per-row-tile completion counters); no grid barrier exists, the launch completes for any grid size
- * (csrc/conv_program.hip).  Arithmetic and k-order are those of
- * ptx_conv3d_fwd on the same tile and split: results are bit-identical to the stage-by-stage launches.
- *   stage.tile     index into ptx_conv_program_tile_name (the tile shapes compiled into the program kernel), < 0: library's pick
- *   stage.split_k  <= 0: library's pick.  Split-K stages reduce in-launch (last arriver, split order).
- * Rules: every stage writes its own buffer (no reuse inside a program); a stage that reads an earlier stage's output reads
- * it with the producer's row stride; flags other than PTX_EPI_RELU | PTX_EPI_RES_ADD, grouped and fp16 / split-operand convs
- * are refused (PTX_ERR_UNSUPPORTED: keep those as their own launches).
- * Use: ptx_conv_program_plan (sizes) -> allocate `workspace_bytes` of device workspace (256-byte aligned) and `image_bytes`
- * of host + device memory -> ptx_conv_program_build fills the HOST image (it embeds the stage pointers and workspace
- * addresses) -> copy it to the device once -> ptx_conv_program_fwd per forward (asynchronous; one memset node + one kernel).
- * ptx_conv_program_error synchronises the stream and reads the program's error word (a dependency wait that ran out of
- * polls -- a bug or a wedged device, never a data-dependent condition): code4 = {code, waiting stage, queue index, producer}.
- * ------------------------------------------------------------------------------------------ */
-typedef struct ptx_conv_stage {
-    ptx_conv3d_desc desc;
-    const float* x;          /* input  (may be an earlier stage's y)                         */
-    const float* x2;         /* second source (ptx_conv3d_dual_fwd semantics) or NULL        */
-    const float* w_packed;
-    const float* bias;       /* or NULL                                                      */
-    const float* res;        /* PTX_EPI_RES_ADD operand (may be an earlier stage's y) or NULL */
-    float* y;
-    int32_t tile;
-    int32_t split_k;
-} ptx_conv_stage;
-
-typedef struct ptx_conv_program_info {
-    int32_t n_stages, total_items;   /* queue length = sum over stages of tiles x splits              */
-    int32_t ctrl_words;              /* 32-bit words at the head of the workspace zeroed per launch   */
-    int32_t lds_bytes;               /* dynamic LDS of the program kernel                             */
-    int32_t launches_replaced;       /* conv + split-K reduce launches the program stands for         */
-    int32_t n_chunks;                /* (stage, clip group) runs of the queue                         */
-    uint64_t image_bytes, workspace_bytes;
-} ptx_conv_program_info;
-
-int ptx_conv_program_num_tiles(void);
-const char* ptx_conv_program_tile_name(int tile);
-int ptx_conv_program_plan(const ptx_conv_stage* stages, int32_t n, ptx_conv_program_info* info);
-/* the plan as text, one line per stage: tile, split, tiles, halo rows, producers ("<stage>:x|res|x2") -- host only */
-int ptx_conv_program_describe(const ptx_conv_stage* stages, int32_t n, char* text, size_t text_bytes);
-int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, void* workspace, size_t workspace_bytes,
-                           void* image_host, size_t image_bytes, ptx_conv_program_info* info);
-int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
-                         ptx_stream_t stream);
-int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream);
-/* diagnostic: the same launch with a phase clock -- 8 x uint64 per queue item written by the workgroup that ran it: the
- * 100 MHz wall clock at [0] item taken, [1] dependencies complete, [2] tile computed and drained, [3] published;
- * [4] CU id | workgroup << 32; [5] stage | tile << 32; [6] 1 + split slice | last-arriver << 32 (scripts/gpu_prog_probe.py) */
-int ptx_conv_program_trace_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
-                               void* trace, size_t trace_bytes, ptx_stream_t stream);
-
 /* Small-Cin STEM convolution with split operands (PTX_F16X3_OPERANDS), read straight from a channels-last input whose
  * positions are 16 bytes (Ci <= 4, ldx == 4) -- `conv1` of the ResNet3D family (resnet3D.py:153), the 2-D ResNet / I3D
  * stems, the (1,7,7) spatial stem of R2Plus1D (r2plus1d.py:73-88).  A workgroup stages the input patch of one temporal
@@ -526,16 +467,6 @@ typedef struct ptx_nonlocal_desc {
 int ptx_nonlocal_supported(const ptx_nonlocal_desc* desc);
 int ptx_nonlocal_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
                      ptx_stream_t stream);
-/* The same operator over a caller-provided scratch buffer, which unlocks the STREAM-K form for long sequences whose
- * 64-query tiles do not fill the chip evenly (nonlocalnet.py:143-166 at N = 1568: 25 tiles x 8 clips = 200 workgroups on 256
- * CUs): the (query tile, key tile) units of one clip are cut into 32 (<= 32 query tiles) or 64 equal chunks, one workgroup
- * each; partial (O, max, sum) blocks meet in the workspace and a second launch folds them in chunk order.  The split is a
- * function of the per-sample extents only -- a clip's bits do not depend on the batch it arrives in.
- * ptx_nonlocal_workspace_bytes: bytes this descriptor's stream-K form needs (0: the plain kernels cover it).  With
- * workspace == NULL, too small or not 16-byte aligned, ptx_nonlocal_ws_fwd runs exactly what ptx_nonlocal_fwd runs. */
-size_t ptx_nonlocal_workspace_bytes(const ptx_nonlocal_desc* desc);
-int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
-                        void* workspace, size_t workspace_bytes, ptx_stream_t stream);
 /* Batched C[b] = op(A[b] x B[b]^T): A [batch][M][lda] (row-major, K contiguous),
  * B [batch][Nn][ldb] (row-major, K contiguous), C [batch][M][ldc]; fp32 MFMA.
  * Used for f = theta^T phi  (nonlocalnet.py:156) and y = softmax(f) g  (:160). */
@@ -608,6 +539,89 @@ int ptx_conv1x1_pro_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const pt
 int ptx_conv3x3_f16_supported(const ptx_conv3d_desc* desc);
 int ptx_conv3x3_f16_fwd(const ptx_conv3d_desc* desc, const void* x, const void* w_packed, const float* bias, void* y,
                         const ptx_conv_fused_ext* ext, ptx_stream_t stream);
+
+/* ============================================================================================
+ * EXPERIMENTAL entry points (PTX_EXPERIMENTAL_API).  Built, tested and exported, but NOT on the default path: each was
+ * measured SLOWER than what the engine runs by default on MI355X and is reachable only through an opt-in environment
+ * switch.  Kept as reproducible negative results (numbers and A/B logs under profiles/); their signatures may change or
+ * disappear without a version bump, and no reference-side binding should be written against them.
+ *   ptx_conv_program_*            conv programs (PTX_PROGRAM=1|auto): config 2 -3.7 %, config 3 -13 % vs the launches
+ *                                 (profiles/r05_program_probe.txt, r05_program_engine_ab.txt)
+ *   ptx_nonlocal_workspace_bytes,
+ *   ptx_nonlocal_ws_fwd           stream-K attention (PTX_NL_STREAMK=1): 246 vs 233 us at 8 clips x N = 1568
+ *                                 (profiles/r05_attention_streamk.txt)
+ * ============================================================================================ */
+#define PTX_EXPERIMENTAL_API /* marks the declarations below; expands to nothing */
+
+/* --------------------------------------------------------------------------------------------
+ * Conv PROGRAM: an ordered list of fp32 convolutions (bias / ReLU / same-shape residual epilogues, optional second source)
+ * executed by ONE persistent launch -- the small-M tail of a video ResNet, where a launch per conv is bound by tile
+ * quantisation on 256 CUs and per-launch ramps rather than by the matrix cores.  Replaces the op sequence of whole
+ * bottlenecks:  conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += residual -> relu, block after block
+ * (resnet3D.py:125-143 with shortcut B :175-185; the six factored GEMMs of a (2+1)D bottleneck, r2plus1d.py:68-88).
+ * The tiles of all stages sit on one queue -- in wavefront order over (stage, clip group), so tiles of several stages are
+ * runnable at any time -- persistent workgroups take them in order and a tile waits only for the ROW TILES of the producing
+ * stages it reads (per-row-tile completion counters); no grid barrier exists, the launch completes for any grid size
+ * (csrc/conv_program.hip).  Arithmetic and k-order are those of
+ * ptx_conv3d_fwd on the same tile and split: results are bit-identical to the stage-by-stage launches.
+ *   stage.tile     index into ptx_conv_program_tile_name (the tile shapes compiled into the program kernel), < 0: library's pick
+ *   stage.split_k  <= 0: library's pick.  Split-K stages reduce in-launch (last arriver, split order).
+ * Rules: every stage writes its own buffer (no reuse inside a program); a stage that reads an earlier stage's output reads
+ * it with the producer's row stride; flags other than PTX_EPI_RELU | PTX_EPI_RES_ADD, grouped and fp16 / split-operand convs
+ * are refused (PTX_ERR_UNSUPPORTED: keep those as their own launches).
+ * Use: ptx_conv_program_plan (sizes) -> allocate `workspace_bytes` of device workspace (256-byte aligned) and `image_bytes`
+ * of host + device memory -> ptx_conv_program_build fills the HOST image (it embeds the stage pointers and workspace
+ * addresses) -> copy it to the device once -> ptx_conv_program_fwd per forward (asynchronous; one memset node + one kernel).
+ * ptx_conv_program_error synchronises the stream and reads the program's error word (a dependency wait that ran out of
+ * polls -- a bug or a wedged device, never a data-dependent condition): code4 = {code, waiting stage, queue index, producer}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ptx_conv_stage {
+    ptx_conv3d_desc desc;
+    const float* x;          /* input  (may be an earlier stage's y)                         */
+    const float* x2;         /* second source (ptx_conv3d_dual_fwd semantics) or NULL        */
+    const float* w_packed;
+    const float* bias;       /* or NULL                                                      */
+    const float* res;        /* PTX_EPI_RES_ADD operand (may be an earlier stage's y) or NULL */
+    float* y;
+    int32_t tile;
+    int32_t split_k;
+} ptx_conv_stage;
+
+typedef struct ptx_conv_program_info {
+    int32_t n_stages, total_items;   /* queue length = sum over stages of tiles x splits              */
+    int32_t ctrl_words;              /* 32-bit words at the head of the workspace zeroed per launch   */
+    int32_t lds_bytes;               /* dynamic LDS of the program kernel                             */
+    int32_t launches_replaced;       /* conv + split-K reduce launches the program stands for         */
+    int32_t n_chunks;                /* (stage, clip group) runs of the queue                         */
+    uint64_t image_bytes, workspace_bytes;
+} ptx_conv_program_info;
+
+PTX_EXPERIMENTAL_API int ptx_conv_program_num_tiles(void);
+PTX_EXPERIMENTAL_API const char* ptx_conv_program_tile_name(int tile);
+PTX_EXPERIMENTAL_API int ptx_conv_program_plan(const ptx_conv_stage* stages, int32_t n, ptx_conv_program_info* info);
+/* the plan as text, one line per stage: tile, split, tiles, halo rows, producers ("<stage>:x|res|x2") -- host only */
+PTX_EXPERIMENTAL_API int ptx_conv_program_describe(const ptx_conv_stage* stages, int32_t n, char* text, size_t text_bytes);
+PTX_EXPERIMENTAL_API int ptx_conv_program_build(const ptx_conv_stage* stages, int32_t n, void* workspace, size_t workspace_bytes,
+                           void* image_host, size_t image_bytes, ptx_conv_program_info* info);
+PTX_EXPERIMENTAL_API int ptx_conv_program_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
+                         ptx_stream_t stream);
+PTX_EXPERIMENTAL_API int ptx_conv_program_error(const void* workspace, int32_t* code4, ptx_stream_t stream);
+/* diagnostic: the same launch with a phase clock -- 8 x uint64 per queue item written by the workgroup that ran it: the
+ * 100 MHz wall clock at [0] item taken, [1] dependencies complete, [2] tile computed and drained, [3] published;
+ * [4] CU id | workgroup << 32; [5] stage | tile << 32; [6] 1 + split slice | last-arriver << 32 (scripts/gpu_prog_probe.py) */
+PTX_EXPERIMENTAL_API int ptx_conv_program_trace_fwd(const ptx_conv_program_info* info, const void* image_dev, void* workspace, int32_t wgs_per_cu,
+                               void* trace, size_t trace_bytes, ptx_stream_t stream);
+
+/* The same operator over a caller-provided scratch buffer, which unlocks the STREAM-K form for long sequences whose
+ * 64-query tiles do not fill the chip evenly (nonlocalnet.py:143-166 at N = 1568: 25 tiles x 8 clips = 200 workgroups on 256
+ * CUs): the (query tile, key tile) units of one clip are cut into 32 (<= 32 query tiles) or 64 equal chunks, one workgroup
+ * each; partial (O, max, sum) blocks meet in the workspace and a second launch folds them in chunk order.  The split is a
+ * function of the per-sample extents only -- a clip's bits do not depend on the batch it arrives in.
+ * ptx_nonlocal_workspace_bytes: bytes this descriptor's stream-K form needs (0: the plain kernels cover it).  With
+ * workspace == NULL, too small or not 16-byte aligned, ptx_nonlocal_ws_fwd runs exactly what ptx_nonlocal_fwd runs. */
+PTX_EXPERIMENTAL_API size_t ptx_nonlocal_workspace_bytes(const ptx_nonlocal_desc* desc);
+PTX_EXPERIMENTAL_API int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* desc, const float* theta, const float* phi, const float* g, float* y,
+                        void* workspace, size_t workspace_bytes, ptx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -206,6 +206,19 @@ def header_symbols(path=HEADER_PATH):
     return sorted(set(re.findall(r"\b(ptx_[a-z0-9_]+)\s*\(", text)))
 
 
+def experimental_symbols(path=HEADER_PATH):
+    """Function names declared with PTX_EXPERIMENTAL_API in include/ptx_amd.h: built, tested and exported, but off the
+    default path (each measured slower than what the engine runs) -- their ABI is not part of the drop-in contract."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"PTX_EXPERIMENTAL_API\s+[a-z_ \*]+?\b(ptx_[a-z0-9_]+)\s*\(", text)))
+
+
+# the experimental part of SIGNATURES (kept in step with the header by tests/test_abi_and_host.py)
+EXPERIMENTAL = ("ptx_conv_program_num_tiles", "ptx_conv_program_tile_name", "ptx_conv_program_plan", "ptx_conv_program_describe",
+                "ptx_conv_program_build", "ptx_conv_program_fwd", "ptx_conv_program_trace_fwd", "ptx_conv_program_error",
+                "ptx_nonlocal_workspace_bytes", "ptx_nonlocal_ws_fwd")
+
 _lib = None
 
 

@@ -10,8 +10,6 @@ tree itself, builds a plan-owning twin whose children ARE the instance's submodu
 `features / logits / forward` on the INSTANCE (never on the class: other instances of the reference class are untouched).
 Calls outside the engine's contract (train() mode, autograd, CPU tensors) run the reference's own methods, unchanged.
 """
-import functools
-
 import torch
 import torch.nn as nn
 
@@ -82,7 +80,7 @@ def _nl_view(nl):
 class AdoptedResNet(VideoResNet):
     """VideoResNet over ANOTHER model's modules (see accelerate).  Never constructed from an Arch name."""
 
-    def __init__(self, source, arch):
+    def __init__(self, source, arch, engine=None):
         nn.Module.__init__(self)
         object.__setattr__(self, "_source", source)           # not a child: the source owns this twin, not vice versa
         self.arch_name = "adopted:%s" % type(source).__name__
@@ -109,7 +107,10 @@ class AdoptedResNet(VideoResNet):
         del cin
         self.fc = None
         self.train(False)
-        self._init_engine()
+        if engine is None:
+            self._init_engine()
+        else:
+            self._engine = engine             # a DataParallel replica's twin shares the original's Engine
 
     # the classifier is read from the SOURCE at call time: users replace `last_linear` on the instance they hold
     @property
@@ -122,35 +123,84 @@ class AdoptedResNet(VideoResNet):
         return self
 
 
+_METHODS = ("features", "logits", "forward")
+
+
+def _twin_of(model):
+    """The engine-owning twin OF THIS INSTANCE.  A copy of an accelerated model (copy.deepcopy, an unpickled torch.save,
+    a DataParallel replica) carries a copy of the original's __dict__ -- its twin must be one over ITS OWN modules, never
+    the original's (silent wrong-model / cross-device execution), so it is rebuilt on first use."""
+    twin = model.__dict__.get("_ptx_twin")
+    if twin is None or twin.__dict__.get("_source") is not model:
+        twin = AdoptedResNet(model, _arch_of(model))
+        object.__setattr__(model, "_ptx_twin", twin)
+        object.__setattr__(model, "_engine", twin._engine)
+    return twin
+
+
+class _Bound:
+    """`model.<name>` of an accelerated instance: a picklable, deep-copyable callable stored in the instance __dict__ that
+    resolves the twin from the instance it is bound to AT CALL TIME (a closure over the original model and twin, as in
+    round 5, kept serving the original after a copy)."""
+    __slots__ = ("model", "name")
+
+    def __init__(self, model, name):
+        self.model, self.name = model, name
+
+    def __deepcopy__(self, memo):
+        import copy
+        return _Bound(copy.deepcopy(self.model, memo), self.name)       # memo holds the copy under construction
+
+    def __reduce__(self):
+        return (_Bound, (self.model, self.name))
+
+    @property
+    def __wrapped__(self):
+        return getattr(type(self.model), self.name)
+
+    def __call__(self, *a, **k):
+        model, name = self.model, self.name
+        if name == "engine":
+            return _twin_of(model)._engine
+        if name == "_replicate_for_data_parallel":
+            # nn.DataParallel (examples/imagenet_eval.py:136) copies __dict__ into every replica: re-bind the replica's
+            # methods to the replica, and give it a twin over ITS modules (the per-device broadcast copies) that shares the
+            # original's Engine -- plans are keyed by (shape, device), weight identity stays the original's (Engine.owner)
+            rep = type(model)._replicate_for_data_parallel(model)
+            twin = AdoptedResNet(rep, _twin_of(model).arch, engine=_twin_of(model)._engine)
+            object.__setattr__(twin, "_is_replica", True)
+            object.__setattr__(rep, "_ptx_twin", twin)
+            _bind(rep)
+            return rep
+        ref_fn = getattr(type(model), name)
+        x = a[0] if a else None
+        if len(a) != 1 or k or eager.wanted(model, x):
+            return ref_fn(model, *a, **k)                    # the reference's own code: train() / autograd / CPU
+        twin = _twin_of(model)
+        return getattr(twin._engine, name)(twin, x)
+
+
+def _bind(model):
+    cls = type(model)
+    for name in _METHODS:
+        if callable(getattr(cls, name, None)):
+            object.__setattr__(model, name, _Bound(model, name))
+    object.__setattr__(model, "engine", _Bound(model, "engine"))
+    object.__setattr__(model, "_replicate_for_data_parallel", _Bound(model, "_replicate_for_data_parallel"))
+
+
 def accelerate(model):
     """Bind the MI355X engine to `model`, an instance of the reference's ResNet3D / R2Plus1D / NonLocalResNet3D
     (/root/reference/pretorched/models/resnet3D.py:146, r2plus1d.py:99, nonlocalnet.py:423).  Returns `model`, with
-    `features`, `logits` (when its class has them) and `forward` bound on the instance; `model.engine()` is the Engine."""
+    `features`, `logits` (when its class has them) and `forward` bound on the instance; `model.engine()` is the Engine.
+    Copies stay correct: copy.deepcopy / torch.save + torch.load give an instance with its own twin and engine (built on
+    first use), nn.DataParallel replicas run their own device's weights through the original's Engine."""
     if isinstance(model, VideoResNet):
         return model                                           # already engine-backed
     if not isinstance(model, nn.Module):
         raise PtxError("accelerate expects an nn.Module")
-    arch = _arch_of(model)
-    cls = type(model)
-    orig = {n: getattr(cls, n) for n in ("features", "logits", "forward") if callable(getattr(cls, n, None))}
-    twin = AdoptedResNet(model, arch)
+    twin = AdoptedResNet(model, _arch_of(model))
     object.__setattr__(model, "_ptx_twin", twin)
     object.__setattr__(model, "_engine", twin._engine)         # eager.wanted(model, x) reads the autograd opt-in here
-    model.engine = lambda: twin._engine
-
-    def bind(name, hip):
-        ref_fn = orig[name]
-
-        @functools.wraps(ref_fn)
-        def method(x, *a, **k):
-            if a or k or eager.wanted(model, x):
-                return ref_fn(model, x, *a, **k)               # the reference's own code: train() / autograd / CPU
-            return hip(twin, x)
-        object.__setattr__(model, name, method)
-
-    if "features" in orig:
-        bind("features", twin._engine.features)
-    if "logits" in orig:
-        bind("logits", twin._engine.logits)
-    bind("forward", twin._engine.forward)
+    _bind(model)
     return model

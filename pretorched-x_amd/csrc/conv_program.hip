@@ -331,6 +331,14 @@ static int prog_prepare(const ptx_conv_stage* st, int n, ProgPlan& pl, ptx_conv_
         if (d->flags & ~allowed)
             return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d: only fp32 convs with bias / ReLU / same-shape residual (flags 0x%x)", i, d->flags);
         if (d->groups > 1) return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d: grouped convs keep their own launch", i);
+        // the row-tile dependency range [in_row(m0) - halo_lo, in_row(m1) + halo_hi] (prog_tile_deps / dep_tiles) takes the
+        // first and last output row of a tile as the extremes of what it reads: true when the input row of an output is
+        // monotone in the output's raster index, i.e. the padding stays inside the filter's half width and a step of one
+        // output row / frame never moves BACKWARDS in the input raster.  Anything else keeps its own launch.
+        if (d->pT < 0 || d->pH < 0 || d->pW < 0 || d->pT > (d->kT - 1 + 1) / 2 || d->pH > (d->kH - 1 + 1) / 2 || d->pW > (d->kW - 1 + 1) / 2 ||
+            (int64_t)(d->Wo - 1) * d->sW > (int64_t)d->sH * d->Wi || (int64_t)(d->Ho - 1) * d->sH * d->Wi > (int64_t)d->sT * d->Hi * d->Wi)
+            return fail(PTX_ERR_UNSUPPORTED, "conv_program: stage %d: geometry outside the monotone row order the tile dependencies assume "
+                        "(padding beyond the filter half width, or an output row / frame step that moves backwards in the input)", i);
         ptx_conv3d_desc dd = *d;
         dd.flags &= ~PTX_SPLITK_FUSED;
         HostStage& h = hs[(size_t)i];

@@ -437,6 +437,10 @@ __global__ void __launch_bounds__(256 * KS) nl_attention_kernel(const NlArgs p) 
     } while (SK && u < u_end);
 }
 
+// most pieces one query tile can be cut into by the stream-K split: the combine kernel keeps that many partials in registers,
+// and the host refuses (falls back to the plain kernel) any (chunks, query tiles) pair that could exceed it
+constexpr int kNlSkMaxPieces = 6;
+
 // Stream-K combine: query tile (b, qt) <- its pieces, in chunk order.  Piece k holds unnormalised rows O_k, running maxima m_k
 // and running sums l_k of its key range:  M = max_k m_k,  y = (sum_k O_k e^(m_k - M)) / (sum_k l_k e^(m_k - M)) * scale
 // (scale = 2^-12 under split operands: the factor their softmax weights carry).  One workgroup per query tile, 16-byte items.
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(256) nl_sk_combine_kernel(const NlArgs p, cons
     // a workgroup = 256 / (DV / 4) query rows of one tile, one 16-byte item per thread: every load of a thread is independent
     // of the others (one memory round trip), and a clip's 25 tiles x 16 row groups fill the chip
     constexpr int F4 = DV / 4, ROWS = 256 / F4, PARTS = 64 / ROWS;
-    constexpr int kMaxPieces = 6;            // <= sk_chunks / q_tiles + 2 with q_tiles >= 8 (nl_sk_chunks)
+    constexpr int kMaxPieces = kNlSkMaxPieces;       // nl_sk_chunks refuses any split with more pieces per query tile
     const int tile = xcd_remap(blockIdx.x / PARTS, p.q_tiles * p.batch), part = blockIdx.x % PARTS;
     const int b = tile / p.q_tiles, qt = tile - b * p.q_tiles;
     const long long U = (long long)p.q_tiles * n_tiles;
@@ -749,17 +753,23 @@ static int launch_nl_sk(const NlArgs& a, hipStream_t st) {
 // start at 32 different key offsets, the clip's whole 3.2 MB of keys / values is live at once and a step's LDS-DMA no longer
 // returns within one tile of prefetch: 4.7 -> 5.7 us per 32-key step, more than the 22 % of steps the chunks save.
 static int nl_sk_chunks(const ptx_nonlocal_desc* d) {
+    // the three knobs are read at EVERY call (tests and tuning sessions flip them inside one process)
     const char* e = getenv("PTX_NL_STREAMK");
+    const char* ek = getenv("PTX_NL_KSPLIT");
+    const char* ed = getenv("PTX_NL_DS");
     const int env = e ? atoi(e) : 0;
-    static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
-    static const int ds_env = getenv("PTX_NL_DS") ? atoi(getenv("PTX_NL_DS")) : 1;
+    const int ks_env = ek ? atoi(ek) : -1;
+    const int ds_env = ed ? atoi(ed) : 1;
     if (!env || ks_env == 0) return 0;
     if (d->mode & (PTX_NL_SCALE | PTX_NL_F16 | PTX_NL_OUT_F16 | PTX_NL_RELU)) return 0;
     if (!(d->d > 64 && d->d <= 256 && d->dv <= 256) || d->Nk < 512) return 0;
     if (d->Nq <= 512 && ds_env) return 0;
     const int q_tiles = cdiv(d->Nq, 64);
     if (q_tiles < 8 || q_tiles > 64) return 0;
-    return q_tiles <= 32 ? 32 : 64;
+    const int chunks = q_tiles <= 32 ? 32 : 64;
+    // a query tile's units span at most chunks / q_tiles whole chunks plus one partial chunk at either end
+    if (chunks / q_tiles + 2 > kNlSkMaxPieces) return 0;
+    return chunks;
 }
 static size_t nl_sk_slot_floats(const ptx_nonlocal_desc* d) { return (size_t)64 * (d->dv <= 128 ? 128 : 256) + 128; }
 
@@ -823,7 +833,7 @@ extern "C" int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* d, const float* thet
     // short sequences: the d-split kernel (one 16-query group per workgroup, the channel axes spread over its waves).  Chosen
     // from PER-SAMPLE extents only, like everything below: a clip's bits must not depend on the batch it arrives in.
     // Exact fp32 MFMAs also under a split-operand plan (fp32-accurate by contract, as for d > 512).  PTX_NL_DS=0: off (A/B).
-    static const int ds_env = getenv("PTX_NL_DS") ? atoi(getenv("PTX_NL_DS")) : 1;
+    const int ds_env = getenv("PTX_NL_DS") ? atoi(getenv("PTX_NL_DS")) : 1;          // read per call, like nl_sk_chunks
     if (ds_env && d->Nq <= 512 && d->d > 64 && d->d <= 512 && d->dv <= 512) {
         if (d->d <= 256 && d->dv <= 256) return launch_nl_ds<256, 256, 4>(a, st);
         return launch_nl_ds<512, 512, 8>(a, st);
@@ -835,7 +845,7 @@ extern "C" int ptx_nonlocal_ws_fwd(const ptx_nonlocal_desc* d, const float* thet
     // batch size or a rank's shard size (the reference is batch-independent, nonlocalnet.py:143-166).  At large
     // grids the two variants measure the same (8 waves per CU either way), so the key split is simply the kernel for
     // 64 < d <= 256 and Nk >= 128.
-    static const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
+    const int ks_env = getenv("PTX_NL_KSPLIT") ? atoi(getenv("PTX_NL_KSPLIT")) : -1;
     const bool ksplit = ks_env != 0 && a.Nk >= 128;
     // stream-K over a caller-provided workspace (ptx_nonlocal_workspace_bytes): long sequences whose query tiles do not fill
     // the chip evenly.  Without a (large enough, 16-byte aligned) workspace the plain key-split kernel below runs.

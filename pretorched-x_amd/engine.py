@@ -562,7 +562,12 @@ class ProgramStep:
     """A run of consecutive small-M ConvSteps as ONE persistent launch (ptx_conv_program_fwd, csrc/conv_program.hip): the
     tiles of all its convs on one queue, per-row-tile dependencies instead of kernel boundaries.  `convs` are the launches it
     stands for -- still complete ConvSteps, run instead when `use_program` is off (PTX_PROGRAM=0, or the tuner measured the
-    launches faster)."""
+    launches faster).
+    Numerical caveat: "bit-identical to the launches" holds for the SAME tile and split.  Under PTX_PROGRAM=auto
+    the program runs the library's own tile / split picks while the fallback ConvSteps run the tuned table's, so which bits
+    a forward produces depends on which side the tuner's 3 % timing rule picked on that machine (same 1e-5 class either
+    way); and Engine._autotune retunes the member ConvSteps AFTER the image was built, so with PTX_PROGRAM_TILES=tuned the
+    image keeps the pre-tune tiles until the plan is recompiled.  Experimental, off by default."""
     __slots__ = ("convs", "use_program", "label", "macs", "hbm_bytes", "info", "image", "ws", "wgs", "plan", "stages", "kernel", "key")
 
     def __call__(self, st):
@@ -2055,7 +2060,18 @@ class Engine:
         with plan.exclusive():
             plan.bind(model)
             plan.run_features(x)
-            return plan.run_head(self, model)
+            out = plan.run_head(self, model)
+            # conv programs (experimental, PTX_PROGRAM=1 / force / auto): a dependency wait that ran out of polls leaves its
+            # stages partially written and only sets the program's error word -- read it before the logits are handed out
+            # (one stream synchronisation per forward, paid by the opt-in mode only; PTX_PROGRAM_CHECK=0 skips it)
+            if getattr(plan, "program_steps", None) and os.environ.get("PTX_PROGRAM_CHECK", "1") != "0":
+                for ps in plan.program_steps:
+                    if ps.use_program:
+                        err = ps.error()
+                        if err is not None:
+                            raise PtxError("%s: the conv program stopped with error %s (code, waiting stage, queue index, "
+                                           "producer stage): its outputs are incomplete" % (ps.label, err))
+            return out
 
     def forward(self, model, x):
         """features -> logits without leaving channels-last."""

@@ -315,6 +315,41 @@ def build_biggan(self, model):
     self.pooled = None
 
 
+# ---- guard of the packed-fp16 affine -------------------------------------------------------------
+# Two consumer kernels of the fp16 generator plan apply a BatchNorm's folded scale / shift to their INPUT fragments as packed
+# fp16 FMAs (ptx_conv1x1_pro_f16_fwd: a GBlock's cBN1 + ReLU; ptx_rgb_conv3x3_f16_fwd: the output layer's BN + ReLU), with the
+# tables rounded to halfs.  That is only as good as the tables' range and conditioning:
+#   * a table entry above the half range (65504) becomes inf;
+#   * v = x * scale + shift with shift = bias - mean * scale cancels when |mean| >> sigma: the fp16 FMA's rounding error is
+#     2^-11 |scale * mean| against a signal of |scale| * sigma, i.e. 2^-11 |mean| / sigma of a standard deviation.
+# The producer stores a RAW-only map when its consumer takes this path, so the decision is made where the plan is compiled,
+# from the model's own parameters: worst-case table magnitudes below HALF_TABLE_MAX for any conditioning vector with
+# |cond| <= cond_max, and |mean| / sigma <= HALF_CANCEL_MAX (error <= 0.8 % of a standard deviation per normalisation).
+# Otherwise the block keeps the two-output flow, whose affine runs in fp32 in the PRODUCER's epilogue.
+HALF_TABLE_MAX = 6.0e4
+HALF_CANCEL_MAX = 16.0
+COND_ABS_MAX = 6.0           # |z| of a (truncated) normal sample; the class embedding's own maximum is added by the caller
+
+
+def half_affine_ok(bn, eps, cond_max=COND_ABS_MAX):
+    """(ok, (max |scale| bound, max |shift| bound, max |mean| / sigma)) for a (conditional) BatchNorm whose folded tables a
+    consumer kernel would apply as packed fp16 FMAs.  Conditional (`gain` / `bias` are bias-free Linears of the conditioning
+    vector, gain = 1 + W_g cond): bounds over every |cond|_inf <= cond_max; plain (`gain` / `bias` parameters): exact."""
+    with torch.no_grad():
+        mean, var = bn.stored_mean.detach().float(), bn.stored_var.detach().float()
+        sigma = (var + eps).sqrt()
+        if isinstance(bn.gain, torch.nn.Linear):
+            g = 1.0 + bn.gain.weight.detach().float().abs().sum(1) * cond_max
+            b = bn.bias.weight.detach().float().abs().sum(1) * cond_max
+        else:
+            g, b = bn.gain.detach().float().abs(), bn.bias.detach().float().abs()
+        scale = g / sigma
+        shift = b + mean.abs() * scale
+        vals = [float(v) for v in torch.stack([scale.max(), shift.max(), (mean.abs() / sigma).max()]).tolist()]
+    ok = vals[0] < HALF_TABLE_MAX and vals[1] < HALF_TABLE_MAX and vals[2] <= HALF_CANCEL_MAX
+    return bool(ok), tuple(vals)
+
+
 def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all, tot, oscale, oshift):
     """precision='fp16' (BASELINE.json config 5 "fp16 MFMA"): the fused cBN + upsample + conv generator stage.
 
@@ -336,10 +371,32 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         o = offs[id(bn)]
         return (_ptr(scale_all, o), _ptr(shift_all, o), tot)
 
+    import os
+    eps = float(model.bn_eps)
+    with torch.no_grad():
+        cond_max = max(COND_ABS_MAX, float(model.shared.weight.detach().abs().max()))
+    guard_on = os.environ.get("PTX_HALF_AFFINE_GUARD", "1") != "0"       # 0: A/B runs and the test that shows the failure
+    guarded = []                      # (module ref, verdict the plan was compiled with): re-checked when the weights change
+
+    def half_ok(bn):
+        ok, _ = half_affine_ok(bn, eps, cond_max)
+        guarded.append((self.ref(bn), ok))
+        return ok or not guard_on
+
+    def recheck():
+        for r, was in guarded:
+            ok, vals = half_affine_ok(self.get(r), eps, cond_max)
+            if ok != was and guard_on:
+                from .engine import PtxError
+                raise PtxError("BigGAN fp16 plan: a BatchNorm's folded tables %s the range the packed-fp16 affine is safe in "
+                               "(max |scale| %.3g, max |shift| %.3g, max |mean| / sigma %.3g) since this plan was compiled: call "
+                               "model.refresh() to recompile it" % ("left" if was else "entered", vals[0], vals[1], vals[2]))
+    if torch.device(self.dev).type != "meta":
+        self.refreshers.append(recheck)
+
     def pro_ok(nb, H, W):
         """The NEXT block's conv1 can apply its own cBN1 + ReLU to its input fragments (ptx_conv1x1_pro_f16_fwd), so the conv
         that produces its input stores the raw sum only.  PTX_CONV1_PRO=0: the two-output flow (A/B runs)."""
-        import os
         if nb is None or nb.kind != "gblock" or os.environ.get("PTX_CONV1_PRO", "1") == "0":
             return False
         K, Co = nb.conv1.in_channels, nb.conv1.out_channels
@@ -357,7 +414,10 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         d.kT = d.kH = d.kW = d.sT = d.sH = d.sW = 1
         d.Kc, d.Co_pad, d.groups = pk_.Kc // 2, pk_.Co_pad, 1
         d.flags = PTX_F16_OPERANDS | PTX_EPI_OUT_F16 | PTX_EPI_AFFINE | PTX_EPI_RELU
-        return bool(self.lib.ptx_conv1x1_pro_f16_supported(C.byref(d)))
+        if not self.lib.ptx_conv1x1_pro_f16_supported(C.byref(d)):
+            return False
+        # ... and the tables that kernel would apply as packed fp16 FMAs must be in range and well conditioned
+        return half_ok(nb.bn1)
 
     xa, xr = cbn(h, flat[0][2].bn1), h          # activated input of the first block (halfs), its skip operand (fp32)
     for k, (si, bi, blk) in enumerate(flat):
@@ -385,7 +445,7 @@ def _biggan_fp16_stages(self, model, h, cbn, affine, offs, scale_all, shift_all,
         t = self.conv(t, pk(blk.conv3), one, (0, 1, 1), relu=True, affine=tab(blk.bn4), out_f16=True, label=name + ".conv3")
         skip = dict(res=xr) if (not up and blk.in_channels == blk.out_channels) else \
             dict(res=xr, res_kind="up", res_stride=(0, int(up), int(up)))
-        if nxt is None and _rgb_conv_ok(self, blk.conv4.out_channels, t, model.output_layer[2], obn.channels):
+        if nxt is None and _rgb_conv_ok(self, blk.conv4.out_channels, t, model.output_layer[2], obn.channels) and half_ok(obn):
             # last block, image conv on its own kernel (round 4): the output layer's BN + ReLU runs on that kernel's A
             # fragments, so this conv stores the RAW sum only -- no activated copy of the last feature map exists
             xr = self.conv(t, pk(blk.conv4), one, zero, out_f16=True, label=name + ".conv4", **skip)

@@ -20,6 +20,12 @@ def test_header_and_bindings_agree(ptx):
     for name in declared:
         assert hasattr(lib, name)
     assert b"gfx950" in lib.ptx_version()
+    # the experimental section of the header (entry points off the default path: conv programs, stream-K attention) is
+    # exactly the set the binding calls experimental; everything else is the drop-in contract INTEGRATION.md documents
+    assert L.experimental_symbols() == sorted(L.EXPERIMENTAL) and set(L.EXPERIMENTAL) <= declared
+    integ = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "INTEGRATION.md")).read()
+    stable = declared - set(L.EXPERIMENTAL)
+    assert "%d stable" % len(stable) in integ and "%d experimental" % len(L.EXPERIMENTAL) in integ, (len(stable), len(L.EXPERIMENTAL))
     # the binary names the sources it was compiled from (sha256 over csrc/*.hip, csrc/*.h, include/ptx_amd.h, computed by
     # build.py): what a test run loads is what this tree's source compiles to
     from pretorched_x_amd import _lib as L
@@ -931,3 +937,43 @@ def test_generator_fp16_plan_wiring_without_gpu(ptx, monkeypatch):
     k, _ = kinds(PTX_CONV3X3_F16="0", PTX_CONV1X1_F16="0", PTX_CONV1_PRO="0", PTX_RGB_CONV="0", PTX_ATTN_F16="0")
     assert not any(v != ["ConvStep"] and v != ["pass"] and v != ["pass", "pass"] for v in k.values()), k
     assert "output_layer.2" in k and len(k["affine_act_upsample"]) == 2
+
+
+def test_half_affine_guard_decides_the_fp16_generator_flow(ptx, monkeypatch):
+    """VERDICT r5 #6 / ADVICE r4 #1: a consumer kernel that applies BatchNorm tables as packed fp16 FMAs is only chosen when the
+    tables are inside the half range and well conditioned -- decided on the host from the model's parameters
+    (plans.half_affine_ok), per plan; otherwise the producer keeps the fp32 affine in its epilogue (two-output flow)."""
+    from pretorched_x_amd import plans as P
+    from pretorched_x_amd.engine import Plan
+    G = ptx.biggan_deep(128, ch=32, precision="fp16")
+    eps = float(G.bn_eps)
+    obn = G.output_layer[0]
+    bn1 = G.blocks[-1][0].bn1
+    ok, (smax, hmax, ratio) = P.half_affine_ok(obn, eps)
+    assert ok and abs(smax - 1.0 / (1.0 + eps) ** 0.5) < 1e-5 and hmax == 0.0 and ratio == 0.0       # default init: gain 1, var 1
+    assert P.half_affine_ok(bn1, eps)[0]
+
+    def n_steps(label):
+        plan = Plan(G.engine(), G, (2, G.dim_z), torch.device("meta"))
+        return sum(1 for s in plan.steps if getattr(s, "label", "") == label)
+    assert n_steps("rgb_conv3x3") == 1
+    with torch.no_grad():
+        # (a) cancellation: |mean| = 1e3 sigma on one channel
+        obn.stored_mean[3] = 1e3 * float((obn.stored_var[3] + eps).sqrt())
+        ok, vals = P.half_affine_ok(obn, eps)
+        assert not ok and vals[2] > 900 and n_steps("rgb_conv3x3") == 0
+        monkeypatch.setenv("PTX_HALF_AFFINE_GUARD", "0")
+        assert n_steps("rgb_conv3x3") == 1                     # the switch the GPU test uses to show the failure
+        monkeypatch.delenv("PTX_HALF_AFFINE_GUARD")
+        obn.stored_mean[3] = 0.0
+        assert P.half_affine_ok(obn, eps)[0]
+        # (b) range: one scale at 7e4
+        obn.gain[0] = 7e4 * float((obn.stored_var[0] + eps).sqrt())
+        ok, vals = P.half_affine_ok(obn, eps)
+        assert not ok and vals[0] >= 6.9e4 and n_steps("rgb_conv3x3") == 0
+        obn.gain[0] = 1.0
+        # a conditional BN: the bound covers every conditioning vector with |cond| <= cond_max
+        assert P.half_affine_ok(bn1, eps, cond_max=6.0)[0]
+        bn1.gain.weight[5].fill_(1e3)                          # |gain| can reach 1 + 256 * 1e3 * 6 = 1.5e6
+        ok, vals = P.half_affine_ok(bn1, eps, cond_max=6.0)
+        assert not ok and vals[0] > 1e6

@@ -211,3 +211,33 @@ def test_accelerate_golden_weights_through_a_foreign_instance(ptx):
         pooled = m(x)
     assert pooled.shape == (x.shape[0], 2048)
     assert np.isfinite(pooled.cpu().numpy()).all()
+
+
+@needs_ref
+def test_accelerated_instances_survive_copies(ptx):
+    """the bound methods of an accelerated instance resolve their twin from the instance they are called on --
+    copy.deepcopy, pickle (torch.save(model)) and nn.DataParallel replicas must never run the ORIGINAL model's twin."""
+    import copy
+    import pickle
+    ref = ref_shim.import_reference()
+    m = ref.resnet3d18(num_classes=5, pretrained=None).eval()
+    ptx.accelerate(m)
+    x = torch.randn(1, 3, 4, 32, 32, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = m(x).clone()                                    # CPU tensor: the reference path answers
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone is not m and clone.forward.model is clone and clone.engine.model is clone
+        eng = clone.engine()                                   # first use: a twin over the CLONE's modules, its own Engine
+        assert clone._ptx_twin._source is clone and eng is clone._ptx_twin._engine and eng is not m.engine()
+        assert clone._ptx_twin.conv1 is clone.conv1 and clone._ptx_twin.conv1 is not m.conv1
+        with torch.no_grad():
+            assert torch.equal(clone(x), want)
+        clone.conv1.weight.data.zero_()                        # the copies share nothing with the original
+        with torch.no_grad():
+            assert torch.equal(m(x), want)
+    # DataParallel's replicate: __dict__ is copied, then the replica's methods are re-bound to the replica and its twin
+    # shares the original's Engine (plans are per device; weight identity is the original's)
+    rep = m._replicate_for_data_parallel()
+    assert rep is not m and rep.forward.model is rep and rep.features.model is rep
+    assert rep._ptx_twin._source is rep and rep._ptx_twin._engine is m.engine() and rep._ptx_twin._is_replica
+    assert m.forward.model is m and m._ptx_twin._source is m

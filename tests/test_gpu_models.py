@@ -112,6 +112,31 @@ def test_config3_full_size_parity(ptx, case):
     print("%s max|dlogits| = %.3e (max|logit| %.2f)" % (case, err, ref.abs().max().item()))
 
 
+@pytest.mark.parametrize("case", ["resnet3d50_cfg2", "nonlocal_r2plus1d50_cfg3"])
+def test_strong_scaling_shard_shapes_against_the_goldens(ptx, case):
+    """at 8 GPUs the metric's 8-clip batch leaves ONE clip per rank (config 4: two) -- plans of batch 1 and
+    batch 2 pick other tiles / split-K factors than the 8-clip plan and had no parity test.  Clips are independent
+    (eval-mode BN, per-sample attention), so the first rows of the full-size goldens are the expected logits of the shards
+    rank 0 would run: clip 0 alone, clips 0-1, and -- the shard of the LAST rank -- clip 7 alone."""
+    blob = load_golden(case)
+    ref = torch.from_numpy(blob["logits"])
+    if case == "resnet3d50_cfg2":
+        model, _ = _build(ptx, "resnet3d50", dict(num_classes=339, pretrained=None), int(blob["w_seed"]))
+        x = synth_clips(8, 16, 224, int(blob["x_seed"]))
+    else:
+        arch, kw = GOLDEN_CASES[case]
+        model, _ = _build(ptx, arch, kw, **golden_recipe(blob))
+        x = golden_input(blob)
+    assert x.shape[0] == 8 and ref.shape[0] == 8
+    for lo, hi in ((0, 1), (0, 2), (7, 8)):
+        out = model(x[lo:hi].contiguous().to(DEV))
+        torch.cuda.synchronize()
+        err = _check(out, ref[lo:hi], "%s clips [%d, %d) vs golden rows" % (case, lo, hi))
+        assert torch.equal(out.cpu().argmax(1), ref[lo:hi].argmax(1))
+        print("%s shard [%d, %d): max|dlogits| = %.3e" % (case, lo, hi, err))
+    assert len(model.engine()._plans) == 2          # one plan per shard SHAPE (batch 1, batch 2)
+
+
 def test_stream_k_attention_in_a_plan(ptx, monkeypatch):
     """PTX_NL_STREAMK=1 (off by default: measured slower): the N = 1568 attention launches of config 3's
     full-strength NL composite run the stream-K form over the plan's scratch buffer -- same golden logits at the 1e-3 bar,
@@ -741,6 +766,52 @@ def test_biggan_generator_fp16(ptx):
     print("biggan-deep-256 fp16: max|d image| = %.3e, mean %.3e" % (err.max().item(), err.mean().item()))
     assert err.max().item() <= 5e-2 and err.mean().item() <= 3e-3
     assert torch.equal(img, G(z.to(DEV), G.shared(lab.to(DEV))))
+
+
+def test_biggan_fp16_adversarial_bn_tables_take_the_fp32_affine(ptx, monkeypatch):
+    """the output layer's BatchNorm with an adversarial table -- channel 0 at scale 7e4 (above the half range),
+    every other channel at |mean| = 1e3 sigma (its fp16 FMA cancels: 2^-11 * 1e3 = half a standard deviation of error) --
+    must come out at the plan's usual 5e-2 bound, because the host guard (plans.half_affine_ok) sends such a table through
+    the producer's fp32 affine instead of the consumer's packed-fp16 FMAs; with the guard switched off the same weights FAIL
+    (that is the point of the guard).  Weights are arranged so the exact answer stays O(1): channel 0 of the residual
+    stream is identically zero (its scale multiplies 0), the other channels' mean is the last conv4's bias."""
+    from oracle import biggan_standin as BG
+    from pretorched_x_amd.testing import BIGGAN_RECIPE
+    outs = {}
+    for guard in ("1", "0"):
+        monkeypatch.setenv("PTX_HALF_AFFINE_GUARD", guard)
+        G = ptx.biggan_deep(128, ch=32, precision="fp16")
+        sd = synth_state_dict(G.state_dict(), 1234, **BIGGAN_RECIPE)
+        eps = float(G.bn_eps)
+        bw2 = G.bottom_width ** 2
+        for k in list(sd):
+            if k.endswith((".conv4.weight", ".conv4.bias", ".o.weight", ".o.bias")):
+                sd[k][0] = 0.0                                   # nothing ever writes channel 0 of the residual stream
+        sd["linear.weight"][:bw2] = 0.0                          # (the first linear's rows are (c, h, w)-ordered)
+        sd["linear.bias"][:bw2] = 0.0
+        last = max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        sigma = (sd["output_layer.0.stored_var"] + eps).sqrt()
+        sd["output_layer.0.stored_mean"] = 1e3 * sigma
+        sd["blocks.%d.1.conv4.bias" % last] = sd["blocks.%d.1.conv4.bias" % last] + sd["output_layer.0.stored_mean"]
+        sd["blocks.%d.1.conv4.bias" % last][0] = 0.0
+        sd["output_layer.0.stored_mean"][0] = 0.0
+        sd["output_layer.0.stored_var"][0] = 0.0                 # sigma_0 = sqrt(eps)
+        sd["output_layer.0.gain"][0] = 7e4 * eps ** 0.5          # scale_0 = 7e4, times (x_0 - mean_0) = 0
+        G.load_state_dict(sd)
+        G = G.to(DEV).eval()
+        g = torch.Generator().manual_seed(5)
+        z, lab = torch.randn(2, 128, generator=g), torch.randint(0, 1000, (2,), generator=g)
+        img = G(z.to(DEV), G.shared(lab.to(DEV)))
+        torch.cuda.synchronize()
+        want = BG.forward(sd, z, sd["shared.weight"][lab])
+        assert torch.isfinite(want).all() and want.abs().max().item() < 1.0 and want.std().item() > 1e-2      # a real image, not saturated
+        err = (img.cpu() - want).abs()
+        outs[guard] = float("inf") if not torch.isfinite(err).all() else err.max().item()
+        plan = list(G.engine()._plans.values())[-1]
+        assert sum(1 for s_ in plan.steps if getattr(s_, "label", "") == "rgb_conv3x3") == (0 if guard == "1" else 1)
+    print("biggan fp16, adversarial output-BN tables: max|d image| guarded %.3e, unguarded %.3e" % (outs["1"], outs["0"]))
+    assert outs["1"] <= 5e-2, outs
+    assert not outs["0"] <= 5e-2, outs
 
 
 @pytest.mark.parametrize("arch,kw,shape", [("resnet3d50", dict(num_classes=17, pretrained=None), (3, 3, 8, 112, 112)),
