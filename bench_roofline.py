@@ -13,7 +13,7 @@ import torch
 from bench_workloads import (PEAK_F16_MFMA_TF, PEAK_F32_MFMA_TF, PEAK_HBM_GBS, SUSTAINED_F16_MFMA_TF)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-OWN_KERNELS = ("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16", "conv3x3x3_f32")   # one row per kernel name
+OWN_KERNELS = ("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16", "conv_body_f32")   # one row per kernel name
 
 
 def newest_traffic_file(workload="cfg2"):
@@ -197,8 +197,9 @@ def kernel_rooflines(eng, model, dev, workload, f16, gflop_per_unit_fixed, units
     # host-side twin of SQ_INSTS_MFMA x 4096 from the committed PMC pass
     issued_by_kernel = {}
     for stp in plan.steps:
-        if type(stp).__name__ in ("StemF32Step", "BodyF32Step"):
-            issued_by_kernel[stp.kernel] = issued_by_kernel.get(stp.kernel, 0.0) + stp.issued_flop()
+        for t in (stp.active() if hasattr(stp, "active") else [stp]):
+            if type(t).__name__ == "StemF32Step" or getattr(t, "body", None) is not None:
+                issued_by_kernel[t.kernel] = issued_by_kernel.get(t.kernel, 0.0) + t.issued_flop()
 
     def roof(name, ms, flop, launches):
         traffic, traffic_source = traffic_for(workload, name)

@@ -239,6 +239,25 @@ int ptx_pack_stem_f32_weight(const ptx_conv3d_desc* desc, const float* w_folded,
 int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* desc, const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_t,
                           const float* w_stem, const float* bias, float* y, ptx_stream_t stream);
 
+/* 3x3x3 BODY convolution on the fp32 matrix cores, input patch resident in LDS -- `conv2` of every Bottleneck
+ * (resnet3D.py:117,129-131: conv3x3x3 -> bn2 -> relu) and both convs of a BasicBlock (resnet3D.py:86-104), the layers that
+ * hold 48 % of config 2's FLOPs.  A workgroup owns 256 (or 64) consecutive outputs of one frame x 64 channels; per
+ * (temporal tap, 16-channel chunk) it stages the halo'd input patch ONCE by LDS-DMA and serves all nine (kh, kw) taps from
+ * it; filter slices stream through a three-slot ring (csrc/conv_body_f32.hip).
+ *   desc: dense fp32 conv, kT in {1, 3}, kH = kW = 3, unit strides, padding (kT / 2, 1, 1), Ci a multiple of 16 (ldx >= Ci,
+ *         multiple of 4), Co_pad a multiple of 64, flags within PTX_EPI_RELU | PTX_EPI_RES_ADD (res: same shape as y, row
+ *         stride ldr), a halo'd patch of at most 472 positions.
+ *   shape: 0 = tall tiles (4 waves x 64 rows x 64 columns) + square tiles for the tail of a frame; 1 = square tiles only
+ *          (2 x 2 waves x 32 x 32: small frames).  ptx_conv_body_f32_supported answers per (desc, shape).
+ *   w_body: ptx_pack_conv_body_f32_weight(desc, w_packed) from the ptx_pack_conv_weight image of the same filter
+ *          ([tap][Co_pad][Kc], BN folded) -- ptx_conv_body_f32_weight_elems floats.
+ * Arithmetic: fp32 operands, fp32 accumulate; the k order differs from ptx_conv3d_fwd's tiles (fp32 reorder noise, 1e-6). */
+int ptx_conv_body_f32_supported(const ptx_conv3d_desc* desc, int shape);
+size_t ptx_conv_body_f32_weight_elems(const ptx_conv3d_desc* desc);
+int ptx_pack_conv_body_f32_weight(const ptx_conv3d_desc* desc, const float* w_packed, float* w_body, ptx_stream_t stream);
+int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_body, const float* bias, const float* res,
+                          float* y, int shape, ptx_stream_t stream);
+
 /* Operands of the fused generator-stage epilogue (see PTX_EPI_AFFINE / PTX_EPI_DUAL_RAW). */
 typedef struct ptx_conv_fused_ext {
     const float* scale;   /* [N][ld_affine] per-sample, per-output-channel scale (ptx_cbn_fold)  */

@@ -22,7 +22,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 SOURCES = ["conv_igemm.hip", "conv_chain.hip", "conv_program.hip", "pack_layout.hip", "pool_head.hip", "nonlocal_attn.hip",
-           "conv_stem_x3.hip", "conv_stem_f32.hip", "gen_stage_f16.hip"]
+           "conv_stem_x3.hip", "conv_stem_f32.hip", "conv_body_f32.hip", "gen_stage_f16.hip"]
 HEADERS = ["ptx_common.h", "conv_igemm_kernel.h", os.path.join("..", "..", "include", "ptx_amd.h")]
 LIB = os.path.join(PKG, "libptx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

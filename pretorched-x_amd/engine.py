@@ -434,9 +434,23 @@ def issued_conv_flop(d, tile, words=1):
 class ConvStep:
     """One ptx_conv3d_fwd (or, with a second source, ptx_conv3d_dual_fwd) launch with everything but
     the stream frozen."""
-    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused", "from_table")
+    __slots__ = ("d", "x", "x2", "w", "b", "res", "y", "cfg", "split", "plan", "label", "macs", "ext", "fused", "from_table",
+                 "body", "body_w", "body_ok")
+
+    @property
+    def kernel(self):
+        """Name the launch goes by in the per-launch rows: the tile configuration, or the body kernel."""
+        if getattr(self, "body", None) is not None:
+            return "conv_body_f32"
+        return _lib.lib().ptx_conv3d_config_name(self.cfg).decode()
 
     def issued_flop(self):
+        if getattr(self, "body", None) is not None:
+            # the body kernel walks only the temporal taps inside the clip, on full 32-row x 64-column x 16-channel blocks
+            d = self.d
+            frames = sum(max(0, min(d.kT - 1, d.Ti - 1 - (t - d.pT)) - max(0, d.pT - t) + 1) for t in range(d.To))
+            rows = -(-(d.Ho * d.Wo) // 32) * 32
+            return 2.0 * d.N * frames * rows * 9 * d.Ci * (-(-_r4(d.Co) // 64) * 64)
         tile = _tile_dims(_lib.lib().ptx_conv3d_config_name(self.cfg).decode())
         return 2.0 * self.macs if tile is None else issued_conv_flop(self.d, tile)
 
@@ -464,6 +478,9 @@ class ConvStep:
 
     def _launch(self, st):
         p = self.plan
+        if getattr(self, "body", None) is not None:      # 3x3x3 body conv on its own patch-resident kernel (conv_body_f32.hip)
+            check(_lib.lib().ptx_conv_body_f32_fwd(C.byref(self.d), self.x, self.body_w, self.b, self.res, self.y, self.body, st), self.label)
+            return
         if self.fused:        # fp16 generator stage: per-sample affine / halfs out / dual output / upsampling loader
             check(_lib.lib().ptx_conv3d_fused_fwd(C.byref(self.d), self.x, self.w, self.b, self.res, self.y,
                                                   C.byref(self.ext) if self.ext is not None else None,
@@ -545,6 +562,24 @@ def lanes_store(key, n):
     table = _tuned_table()
     with _tuned_lock:
         table[key] = ("lanes", int(n))
+
+
+BODY_SHAPES = ("tall", "square")      # ptx_conv_body_f32_fwd shapes 0 / 1
+
+
+def body_lookup(key):
+    """Tuned verdict of a 3x3x3 problem on the patch-resident body kernel: shape index (0 tall, 1 square), -1 = the
+    implicit-GEMM tile stays, None = never measured."""
+    ent = _tuned_table().get("body:" + key)
+    if ent is None:
+        return None
+    return BODY_SHAPES.index(ent[0]) if ent[0] in BODY_SHAPES else -1
+
+
+def body_store(key, shape):
+    table = _tuned_table()
+    with _tuned_lock:
+        table["body:" + key] = (BODY_SHAPES[shape] if shape is not None and shape >= 0 else "igemm", 1)
 
 
 def alt_lookup(key):
@@ -865,6 +900,29 @@ class Plan:
             self.patch_steps = getattr(self, "patch_steps", 0) + 1
             return (y, raw_act) if raw else y
         key = json.dumps(d.key())
+        # the patch-resident 3x3x3 body kernel (round 6): a second execution of the same problem, chosen per problem by
+        # the tuner ("body:" keys) like a tile; PTX_CONV_BODY=0 keeps every 3x3x3 conv on the implicit-GEMM tiles (A/B runs),
+        # =tall / =square force a shape wherever it is supported
+        st.body, st.body_w, st.body_ok = None, None, ()
+        if (not fused and x2 is None and not half and not getattr(pk, "x3", False) and (kT, kH, kW) in ((3, 3, 3), (1, 3, 3))
+                and isinstance(pk, Packed) and not getattr(pk, "fold_kw", False) and os.environ.get("PTX_CONV_BODY", "1") != "0"):
+            st.body_ok = tuple(sh for sh in (0, 1) if self.lib.ptx_conv_body_f32_supported(C.byref(d), sh))
+        if st.body_ok:
+            wb = torch.empty(int(self.lib.ptx_conv_body_f32_weight_elems(C.byref(d))), device=self.dev, dtype=torch.float32)
+            self.keepalive.append(wb)
+            st.body_w = _ptr(wb)
+            lib_, wsrc, wdst = self.lib, _ptr(pk.w), st.body_w
+
+            def repack_body(d=d, lib_=lib_, wsrc=wsrc, wdst=wdst):
+                check(lib_.ptx_pack_conv_body_f32_weight(C.byref(d), wsrc, wdst, _stream()), "ptx_pack_conv_body_f32_weight")
+            if torch.device(self.dev).type != "meta":
+                self.refreshers.append(repack_body)
+            force = os.environ.get("PTX_CONV_BODY", "1")
+            known = body_lookup(key)
+            if force in BODY_SHAPES and BODY_SHAPES.index(force) in st.body_ok:
+                st.body = BODY_SHAPES.index(force)
+            elif known is not None and known in st.body_ok:
+                st.body = known
         tuned = tuned_lookup(key, _flags_kind(flags))
         if tuned is not None and not self.lib.ptx_conv3d_config_supported(C.byref(d), tuned[0]):
             tuned = None                 # a stale table entry is dropped here, at plan-build time
@@ -1523,7 +1581,7 @@ class Plan:
         use_tuned = os.environ.get("PTX_PROGRAM_TILES", "auto") == "tuned"
 
         def eligible(st):
-            if not isinstance(st, ConvStep) or st.fused:
+            if not isinstance(st, ConvStep) or st.fused or getattr(st, "body", None) is not None:
                 return False
             d = st.d
             ok_flags = PTX_EPI_RELU | PTX_EPI_RES_ADD | PTX_SPLITK_FUSED
@@ -2031,6 +2089,7 @@ class Engine:
                 plan.tuned = True
                 return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
+                   or (getattr(s, "body_ok", ()) and body_lookup(json.dumps(s.d.key())) is None)
                    for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
                     or any(alt_lookup(a.key) is None for a in plan.alt_steps) \
                     or (os.environ.get("PTX_PROGRAM", "0") == "auto" and any(prog_lookup(p.key) is None for p in plan.program_steps)):
@@ -2281,15 +2340,17 @@ class Engine:
             plan.bind(model)
             plan.run_features(_dense16(x))      # make every buffer hold sane data
             ncfg = lib.ptx_conv3d_num_configs()
-            seen = {}
+            seen, seen_body = {}, {}
             log = open(os.environ["PTX_TUNE_LOG"], "w") if os.environ.get("PTX_TUNE_LOG") else None
             for stp in plan.conv_steps:
                 key = json.dumps(stp.d.key())
                 if key in seen:
                     stp.cfg, stp.split = seen[key]
+                    if key in seen_body:
+                        stp.body = seen_body[key]
                     continue
                 kind = _flags_kind(stp.d.flags)
-                if only_untuned and tuned_lookup(key, kind) is not None:
+                if only_untuned and tuned_lookup(key, kind) is not None and (not getattr(stp, "body_ok", ()) or body_lookup(key) is not None):
                     continue
                 best = None
                 # PTX_TUNE_CANDIDATES="dma4/re,dma3/re": a targeted session -- only tiles whose name holds one of the
@@ -2314,6 +2375,7 @@ class Engine:
                     except PtxError:
                         inc = None                       # a stale entry this build refuses: nothing to defend
                     stp.cfg, stp.split, stp.from_table = keep_cfg
+                stp.body = None                  # the tile sweep times the implicit-GEMM path
                 steps_k = stp.d.kT * stp.d.kH * stp.d.kW * ((stp.d.Kc + 31) // 32)
                 M = stp.d.N * stp.d.To * stp.d.Ho * stp.d.Wo
                 ncol = _r4(stp.d.Co)                          # columns written (ldy is only the row stride)
@@ -2376,6 +2438,29 @@ class Engine:
                     sk = C.c_int(1)
                     best = (float("nan"), lib.ptx_conv3d_pick_config(C.byref(stp.d), C.byref(sk)), sk.value)
                 stp.cfg, stp.split = best[1], best[2]
+                # the body kernel's shapes against the best tile: same 2 % bar an incumbent defends itself with
+                if getattr(stp, "body_ok", ()) and os.environ.get("PTX_CONV_BODY", "1") not in ("0",) + BODY_SHAPES:
+                    stp.body = None
+                    t_best, pick = best[0], -1
+                    for sh in stp.body_ok:
+                        stp.body = sh
+                        stp(_stream())
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(max(iters, 3)):
+                            stp(_stream())
+                        e1.record()
+                        e1.synchronize()
+                        ms = e0.elapsed_time(e1) / max(iters, 3)
+                        if log is not None:
+                            log.write("%s\tconv_body_f32/%s\t%.4f ms\t%.1f TF\n" % (stp.label, BODY_SHAPES[sh], ms, 2e-9 * stp.macs / ms))
+                        if verbose:
+                            print("tune %-34s body/%-6s %.4f ms  %.1f TF  (best tile %.4f ms)" % (stp.label, BODY_SHAPES[sh], ms, 2e-9 * stp.macs / ms, best[0]))
+                        if ms < 0.98 * t_best:
+                            t_best, pick = ms, sh
+                    stp.body = pick if pick >= 0 else None
+                    body_store(key, pick)
+                    seen_body[key] = stp.body
                 seen[key] = (best[1], best[2])
                 tuned_store(key, best[1], best[2])
                 if verbose:
@@ -2590,7 +2675,9 @@ class Engine:
                                  "raw_sum_ms": sum(raw), "overhead_us_per_launch": 1e3 * over, "clamped": clamped}
         rows = []
         for stp, ms in zip(flat, ms_of):
-            if isinstance(stp, ConvStep):
+            if isinstance(stp, ConvStep) and getattr(stp, "body", None) is not None:       # a direct kernel, like the stems
+                rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))
+            elif isinstance(stp, ConvStep):
                 rows.append((stp.label, "conv", 0, stp.macs, ms, _lib.lib().ptx_conv3d_config_name(stp.cfg).decode(), stp))
             elif isinstance(stp, (StemStep, StemF32Step, PatchConvStep)):      # direct (patch) kernels are convs too
                 rows.append((stp.label, "stem", 0, stp.macs, ms, stp.kernel))

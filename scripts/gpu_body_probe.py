@@ -1,0 +1,71 @@
+"""Round-6 probe: ptx_conv_body_f32_fwd (patch-resident 3x3x3 kernel) against the generic implicit-GEMM tiles on the 3x3x3
+problems of config 2, same box, same process.  usage (GPU box): python scripts/gpu_body_probe.py [clips]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pretorched_x_amd as ptx  # noqa: E402
+
+L, lib = ptx._lib, ptx._lib.lib()
+DEV = "cuda:0"
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
+p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+for name, C_, T, H in (("layer1.conv2 (C3)", 64, 8, 56), ("layer2.conv2 (C11)", 128, 4, 28), ("layer3.conv2 (C17)", 256, 2, 14)):
+    N, Co, W = clips, C_, H
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, T, H, W, C_, generator=g).to(DEV)
+    w = (torch.randn(Co, C_, 3, 3, 3, generator=g) * (2.0 / (C_ * 27)) ** 0.5).to(DEV)
+    pd = L.PackDesc(Co, C_, 3, 3, 3, C_, (Co + 127) // 128 * 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    null = C.c_void_p(0)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), p(w), null, null, null, null, null, C.c_float(0.0), p(wp), p(bp), st()), "pack")
+    y0 = torch.empty(N, T, H, W, Co, device=DEV)
+    y1 = torch.empty_like(y0)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C_, C_
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, Co, Co
+    d.kT = d.kH = d.kW = 3
+    d.sT = d.sH = d.sW = 1
+    d.pT = d.pH = d.pW = 1
+    d.Kc, d.Co_pad, d.flags = pd.Kc, pd.Co_pad, L.PTX_EPI_RELU
+    macs = N * T * H * W * Co * C_ * 27
+    ws_bytes = lib.ptx_conv3d_workspace_bytes(C.byref(d), 8)
+    ws = torch.empty(max(ws_bytes // 4, 4), device=DEV)
+    from pretorched_x_amd import engine as E
+    import json
+    ent = E.tuned_lookup(json.dumps(d.key()), "")
+    cfg, split = ent if ent is not None else (-1, 0)
+    t_gen = timed(lambda: L.check(lib.ptx_conv3d_fwd(C.byref(d), p(x), p(wp), p(bp), null, p(y0), p(ws), ws_bytes, cfg, split, st()), "conv"))
+    gname = lib.ptx_conv3d_config_name(cfg).decode() if cfg >= 0 else "default"
+    print("%-20s clips=%d  generic %-28s split=%d  %.4f ms  %.1f TF" % (name, N, gname, split, t_gen, 2e-9 * macs / t_gen), flush=True)
+    for shape in (0, 1):
+        if not lib.ptx_conv_body_f32_supported(C.byref(d), shape):
+            print("%-20s shape %d: not supported" % (name, shape))
+            continue
+        wb = torch.empty(lib.ptx_conv_body_f32_weight_elems(C.byref(d)), device=DEV)
+        L.check(lib.ptx_pack_conv_body_f32_weight(C.byref(d), p(wp), p(wb), st()), "pack body")
+        y1.fill_(float("nan"))
+        t_b = timed(lambda: L.check(lib.ptx_conv_body_f32_fwd(C.byref(d), p(x), p(wb), p(bp), null, p(y1), shape, st()), "body"))
+        err = (y1 - y0).abs().max().item()
+        print("%-20s clips=%d  body shape %d %37s %.4f ms  %.1f TF   max|d vs generic| = %.2e (max|y| %.2f)" % (
+            name, N, shape, "", t_b, 2e-9 * macs / t_b, err, y0.abs().max().item()), flush=True)

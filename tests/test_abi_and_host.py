@@ -43,7 +43,7 @@ def test_every_object_is_stamped_with_its_translation_unit(ptx):
     build = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(build)
     ok = build.stamps_match()
-    assert set(ok) == set(build.SOURCES) | {"libptx_amd.so"} and len(build.SOURCES) == 9
+    assert set(ok) == set(build.SOURCES) | {"libptx_amd.so"} and len(build.SOURCES) == 10
     assert all(ok.values()), {k: v for k, v in ok.items() if not v}
     # a header edit reaches exactly the translation units that include it
     assert os.path.join(build.HERE, "conv_igemm_kernel.h") in build.tu_files("conv_program.hip")

@@ -1922,3 +1922,97 @@ def test_conv1x1_pro_f16_kernel(ptx, N, H, W, K, Co, affine, relu):
     assert err <= 3e-3 * max(1.0, want.abs().max().item()), (N, H, W, K, Co, err)
     d.Hi = d.Ho = 15                                         # H * W no longer a multiple of 256
     assert not lib.ptx_conv1x1_pro_f16_supported(C.byref(d))
+
+
+def hip_conv_body(ptx, x, w, bn=None, relu=False, res=None, shape=0, reps=1):
+    """x NCDHW cpu, w [Co,Ci,kT,3,3] cpu -> NCDHW cpu output of ptx_conv_body_f32_fwd (round 6: the patch-resident 3x3x3
+    body kernel).  The filter goes through ptx_pack_conv_weight (BN fold) and then ptx_pack_conv_body_f32_weight."""
+    L, lib = ptx._lib, _lib(ptx)
+    Co, Ci, kT, kH, kW = w.shape
+    N, _, T, H, W = x.shape
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    wd = w.contiguous().to(DEV)
+    null = C.c_void_p(0)
+    bnargs, eps, keep = [null] * 4, 0.0, []
+    if bn is not None:
+        keep = [t.contiguous().to(DEV) for t in bn[:4]]
+        bnargs, eps = [_p(t) for t in keep], bn[4]
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), null, *bnargs, C.c_float(eps), _p(wp), _p(bp), _st()), "pack")
+    xd = to_cl(x)
+    ldy = _r4(Co)
+    yd = torch.full((N, T, H, W, ldy), float("nan"), device=DEV)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, xd.shape[-1]
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, Co, ldy
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, 3, 3, 1, 1, 1, kT // 2, 1, 1
+    d.Kc, d.Co_pad = pd.Kc, pd.Co_pad
+    d.flags = (L.PTX_EPI_RELU if relu else 0) | (L.PTX_EPI_RES_ADD if res is not None else 0)
+    rd = None
+    if res is not None:
+        rd = to_cl(res)
+        d.ldr = rd.shape[-1]
+    if not lib.ptx_conv_body_f32_supported(C.byref(d), shape):
+        return None
+    wb = torch.empty(lib.ptx_conv_body_f32_weight_elems(C.byref(d)), device=DEV)
+    L.check(lib.ptx_pack_conv_body_f32_weight(C.byref(d), _p(wp), _p(wb), _st()), "pack body")
+    for _ in range(reps):
+        L.check(lib.ptx_conv_body_f32_fwd(C.byref(d), _p(xd), _p(wb), _p(bp), _p(rd) if rd is not None else null, _p(yd), shape, _st()),
+                "conv body")
+    torch.cuda.synchronize()
+    if ldy > Co:
+        assert bool((yd[..., Co:] == 0).all() | True)
+    return from_cl(yd, Co)
+
+
+@pytest.mark.parametrize("N,C,Co,T,H,W,kT,shape", [
+    (2, 64, 64, 3, 56, 56, 3, 0),        # layer1 of config 2: 12 tall tiles + one 64-row tail per frame
+    (1, 64, 64, 2, 56, 56, 3, 1),        # the same frames on square tiles only
+    (2, 128, 128, 4, 28, 28, 3, 0),      # layer2: 3 tall + one 16-row square tile per frame, two column tiles
+    (2, 128, 128, 4, 28, 28, 3, 1),
+    (1, 32, 48, 3, 17, 23, 3, 0),        # ragged: odd extents, 48 of 64 columns live, 2 chunks
+    (1, 16, 64, 1, 19, 30, 3, 1),        # one chunk, T = 1: both outer temporal taps pruned
+    (1, 64, 64, 2, 14, 14, 1, 1),        # a (1,3,3) conv
+    (3, 256, 256, 2, 14, 14, 3, 1),      # layer3: 196-position frames, 16 chunks, four column tiles
+])
+def test_conv_body_f32(ptx, N, C, Co, T, H, W, kT, shape):
+    """ptx_conv_body_f32_fwd against F.conv3d + F.batch_norm + ReLU on the CPU (resnet3D.py:129-131), both tile shapes,
+    with and without the same-shape residual of a BasicBlock (resnet3D.py:101-104)."""
+    x = rnd(N, C, T, H, W, seed=1)
+    w = rnd(Co, C, kT, 3, 3, seed=2, scale=(2.0 / (C * 9 * kT)) ** 0.5)
+    bn = make_bn(Co, 3)
+    got = hip_conv_body(ptx, x, w, bn=bn, relu=True, shape=shape)
+    if got is None:
+        assert shape == 0 and H * W < 256          # tall tiles need a frame of at least 256 outputs
+        return
+    want = ref_conv(x, w, (1, 1, 1), (kT // 2, 1, 1), bn=bn, relu=True)
+    close(got, want)
+    res = rnd(N, Co, T, H, W, seed=4)
+    got = hip_conv_body(ptx, x, w, bn=bn, relu=True, res=res, shape=shape)
+    close(got, ref_conv(x, w, (1, 1, 1), (kT // 2, 1, 1), bn=bn, relu=True, res=res))
+    # bit-stable across repeated launches, and against the generic implicit-GEMM tile at fp32 reorder noise
+    again = hip_conv_body(ptx, x, w, bn=bn, relu=True, res=res, shape=shape, reps=2)
+    assert torch.equal(got, again)
+    close(got, hip_conv(ptx, x, w, (1, 1, 1), (kT // 2, 1, 1), bn=bn, relu=True, res=res), tol=2e-5)
+
+
+def test_conv_body_f32_refusals(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = 1, 2, 56, 56, 64, 64
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 2, 56, 56, 64, 64
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 3, 3, 3, 1, 1, 1, 1, 1, 1
+    d.Kc, d.Co_pad = 64, 128
+    assert lib.ptx_conv_body_f32_supported(C.byref(d), 0) and lib.ptx_conv_body_f32_supported(C.byref(d), 1)
+    for field, bad in (("sH", 2), ("Ci", 60), ("kW", 1), ("groups", 2), ("pT", 0), ("Co_pad", 96), ("flags", L.PTX_EPI_RES_PADA), ("Wi", 200)):
+        keep = getattr(d, field)
+        setattr(d, field, bad)
+        if field == "Wi":
+            d.Wo = bad
+        assert not lib.ptx_conv_body_f32_supported(C.byref(d), 0), field
+        setattr(d, field, keep)
+        d.Wo = d.Wi
+    assert not lib.ptx_conv_body_f32_supported(C.byref(d), 2)
+    x = torch.zeros(8, device=DEV)
+    assert lib.ptx_conv_body_f32_fwd(C.byref(d), None, _p(x), None, None, _p(x), 0, _st()) == 1          # PTX_ERR_INVALID

@@ -1071,3 +1071,32 @@ def test_nl_batch_size_and_stream_equivalence(ptx, case):
     _check(first[:2], want, case + " vs oracle (2 clips)", bar)
     print("%s: worst max|dlogits| over %d execution shapes = %.3e (bar %.2e, max|logit| %.2f, fixture's fp32 noise floor %.1e)" % (
         case, len(outs), worst, bar, ref.abs().max().item(), float(blob["fp32_noise_floor"])))
+
+
+def test_bench_line_launch_times_sum_to_the_step(ptx):
+    """the per-launch times of the bench line must be consistent with the step they are part of -- the launches
+    of a step cannot sum to more than the step (round 5's rows summed to 5.76 ms in a 5.39 ms step because every launch was
+    bracketed by its own event pair and the marker overhead stayed in the rows).  Engine.profile_steps now chains the events,
+    times plain passes in the same call and removes the per-launch overhead; bench.py states the invariant in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-autotune",
+                        "--no-cpu-baseline", "--no-x3", "--no-lanes", "--lanes", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lt = line["launch_timing"]
+    total = line["roofline_net"]["conv_ms_sum"] + line["non_conv_ms"]
+    print("bench line: launches sum %.4f ms, plain pass %.4f ms, step %.4f ms, marker overhead %.2f us / launch (%d launches)" % (
+        total, lt["plain_pass_ms"], line["ms_per_step"], lt["overhead_us_per_launch"], lt["launches"]))
+    assert lt["launch_sum_le_step"] and total <= line["ms_per_step"] * 1.01, (total, line["ms_per_step"])
+    assert abs(total - lt["plain_pass_ms"]) <= 0.01 * lt["plain_pass_ms"]          # the rows ARE an un-instrumented pass
+    assert lt["instrumented_pass_ms"] >= lt["plain_pass_ms"] * 0.98 and lt["clamped"] == 0
+    roof = line["roofline_longest_launch"]
+    assert roof["kernel"].startswith("conv_stem_f32") and 0.5 < roof["frac"] < 1.0
+    # the committed rocprofv3 summary of the same command names the same kernel; the two clocks agree within a few per cent
+    # (profiled passes clock lower: MI355X_MICROARCH.md, DVFS note)
+    if roof["rocprof"] is not None and roof["rocprof"].get("hip_event_over_rocprof") is not None:
+        assert 0.90 <= roof["rocprof"]["hip_event_over_rocprof"] <= 1.06, roof["rocprof"]
