@@ -279,8 +279,9 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
     plan = None
     if lanes_used > 1:
         single_ms = lanes_leg["ms_per_step"] if lanes_leg and lanes_leg["lanes"] == 1 else None
+    if lanes_leg is not None:
         with torch.cuda.device(dev):
-            plan = eng.plan_for(model, x)
+            plan = eng.plan_for(model, x)          # the full-batch plan (the lanes leg left half-batch plans behind it)
     fields, gflop_per_unit = R.kernel_rooflines(eng, model, dev, args.workload, f16, GFLOP_PER_CLIP if headline else None,
                                                 clips_per_s / world, ms_per_step, plan=plan, single_plan_ms=single_ms)
     if lanes_used > 1:

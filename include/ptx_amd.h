@@ -257,6 +257,20 @@ size_t ptx_conv_body_f32_weight_elems(const ptx_conv3d_desc* desc);
 int ptx_pack_conv_body_f32_weight(const ptx_conv3d_desc* desc, const float* w_packed, float* w_body, ptx_stream_t stream);
 int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* desc, const float* x, const float* w_body, const float* bias, const float* res,
                           float* y, int shape, ptx_stream_t stream);
+/* The body kernel with a CHAINED 1x1x1 tail -- a Bottleneck's `conv2 -> bn2 -> relu -> conv3 -> bn3 -> out += residual -> relu`
+ * (resnet3D.py:129-142) in ONE launch, as ptx_conv3d_chain_fwd does on the implicit-GEMM tiles: the [rows][<= 64] result of the
+ * 3x3x3 conv is parked in LDS 32 rows at a time and fed to the tail as its A operand; the tail's filter fragments come from
+ * global memory (L2-resident).
+ *   conv: as ptx_conv_body_f32_fwd, Co <= 64, flags within PTX_EPI_RELU (the ReLU BETWEEN the convs), ldy ignored.
+ *   tail: 1x1x1 / unit stride over conv's output positions, Ci = conv->Co, Co_pad a multiple of 64, flags within
+ *         PTX_EPI_RELU | PTX_EPI_RES_ADD (res: same shape as y, row stride ldr), ldy = row stride of y.
+ *   w_tail: ptx_pack_conv_body_tail_f32_weight(tail, w2_packed) from the ptx_pack_conv_weight image of the tail's filter. */
+int ptx_conv_body_chain_f32_supported(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail, int shape);
+size_t ptx_conv_body_tail_f32_weight_elems(const ptx_conv3d_desc* tail);
+int ptx_pack_conv_body_tail_f32_weight(const ptx_conv3d_desc* tail, const float* w2_packed, float* w_tail, ptx_stream_t stream);
+int ptx_conv_body_chain_f32_fwd(const ptx_conv3d_desc* conv, const ptx_conv3d_desc* tail, const float* x, const float* w_body,
+                                const float* bias, const float* w_tail, const float* bias2, const float* res, float* y, int shape,
+                                ptx_stream_t stream);
 
 /* Operands of the fused generator-stage epilogue (see PTX_EPI_AFFINE / PTX_EPI_DUAL_RAW). */
 typedef struct ptx_conv_fused_ext {

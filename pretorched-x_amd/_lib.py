@@ -143,6 +143,10 @@ SIGNATURES = {
     "ptx_conv_body_f32_weight_elems": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ptx_pack_conv_body_f32_weight": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
     "ptx_conv_body_f32_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
+    "ptx_conv_body_chain_f32_supported": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int]),
+    "ptx_conv_body_tail_f32_weight_elems": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ptx_pack_conv_body_tail_f32_weight": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
+    "ptx_conv_body_chain_f32_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "ptx_conv_program_num_tiles": (C.c_int, []),
     "ptx_conv_program_tile_name": (C.c_char_p, [C.c_int]),
     "ptx_conv_program_plan": (C.c_int, [C.POINTER(ConvStage), _I, C.POINTER(ConvProgramInfo)]),

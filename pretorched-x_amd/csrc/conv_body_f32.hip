@@ -53,7 +53,17 @@ struct BodyF32Args {
     unsigned flags;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;
     unsigned dv_w[2], dv_pc[2], dv_npos_tall[2], dv_npos_sq[2];
+    // chained 1x1x1 tail (ptx_conv_body_chain_f32_fwd): y = epi2(relu?(conv(x) + bias) . w2 + bias2 (+ res)); then `y`, `ldy`,
+    // `ncol`, `res`, `ldr`, `y_bytes`, `r_bytes` above describe the TAIL's output and `flags` its epilogue
+    const float* w2;       // [N2 / 64][8 octets][2][64][4]
+    const float* bias2;
+    int ncol1;             // columns of the first conv (<= 64)
+    unsigned flags1;       // PTX_EPI_RELU between the two convs
+    unsigned w2_bytes;
 };
+
+constexpr int kB3ParkStride = 32 * 4 + 4;            // floats between the 4-channel groups of a parked 32-row tile (+4: bank spread)
+constexpr int kB3Park = 16 * kB3ParkStride;          // floats of one parked [32 rows][64 channels] tile: 8.25 KiB
 
 __device__ __forceinline__ unsigned b3_fdiv(unsigned n, const unsigned (&dv)[2]) {
     return dv[0] ? (__umulhi(n, dv[0]) >> dv[1]) : n;
@@ -67,7 +77,7 @@ static inline void b3_fdiv_make(unsigned d, unsigned (&out)[2]) {
 }
 
 // One tile.  WM x WN waves, each RT x CT MFMA tiles of 32 x 32; NP = 16-byte patch pieces per thread.
-template <int WM, int WN, int RT, int CT, int NP>
+template <int WM, int WN, int RT, int CT, int NP, bool CHAIN>
 __device__ __forceinline__ void conv_body_tile(const BodyF32Args& p, float* smem, const int n, const int to, const int m0, const int nt,
                                                const int PR, const unsigned (&dv_npos)[2]) {
     static_assert(WM * WN == 4, "four waves");
@@ -227,6 +237,99 @@ __device__ __forceinline__ void conv_body_tile(const BodyF32Args& p, float* smem
         }
     }
 
+    if (CHAIN) {
+        // ---- chained tail: the [rows][64] result of this conv (bias + ReLU applied) is PARKED in LDS 32 rows at a time and fed
+        // to the 1x1x1 tail as its A operand; the tail's filter fragments come straight from global memory (64 KiB, L2-resident,
+        // the same for every workgroup); one 64-column chunk of the tail's output at a time: bias2 (+ residual) + ReLU, stored.
+        const bool relu1 = (p.flags1 & PTX_EPI_RELU) != 0;
+        const bool relu2 = (p.flags & PTX_EPI_RELU) != 0;
+        const bool has_res = (p.flags & PTX_EPI_RES_ADD) != 0;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.r_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, p.w2_bytes, 0x00020000);
+        const int m_frame = (n * p.T + to) * frame;
+        const int n_chunks2 = (p.ncol + 63) >> 6;
+        float* Pk = smem + wm * kB3Park;               // the parked tile of this wave ROW (shared by its WN waves)
+        __syncthreads();                                // every wave is done with the patch and the ring: the region is free
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (i > 0) {
+                if (WN > 1) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int c = (wn * CT + j) * 32 + l32;
+                const float bv = (p.bias && c < p.ncol1) ? p.bias[c] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    v = relu1 ? fmaxf(v, 0.f) : v;
+                    Pk[(c >> 2) * kB3ParkStride + ((r & 3) + 8 * (r >> 2) + 4 * g) * 4 + (c & 3)] = v;
+                }
+            }
+            if (WN > 1) __syncthreads();
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool tile_ok = (m0 + (wm * RT + i) * 32) < frame;
+            if (tile_ok) {
+                for (int nc = wn; nc < n_chunks2; nc += WN) {
+                    f32x16 acc2[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+                    const unsigned wbase = (unsigned)(((nc * 8 * 2 + g) * 64 + l32) * 16);
+                    f32x4 fb2[2], fbn[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        fb2[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + j * 512, 0, 0));
+#pragma unroll 1
+                    for (int q = 0; q < 8; ++q) {           // (rolled: unrolled, hipcc hoists all sixteen filter loads -- 64 registers)
+                        const f32x4 fa2 = *reinterpret_cast<const f32x4*>(Pk + (2 * q + g) * kB3ParkStride + l32 * 4);
+                        if (q < 7) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                fbn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + (q + 1) * 2048 + j * 512, 0, 0));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[k], fb2[j][k], acc2[j], 0, 0, 0);
+                        if (q < 7) {
+                            fb2[0] = fbn[0];
+                            fb2[1] = fbn[1];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = nc * 64 + j * 32 + l32;
+                        const bool co_ok = co < p.ncol;
+                        const float bv = (p.bias2 && co_ok) ? p.bias2[co] : 0.f;
+                        float rv[16];
+                        if (has_res) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ml = m0 + (wm * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                                const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldr + (unsigned)co) * 4u;
+                                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (co_ok && ml < frame) ? off : kOOB, 0, 0));
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = m0 + (wm * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                            float v = acc2[j][r] + bv;
+                            if (has_res) v += rv[r];
+                            v = relu2 ? fmaxf(v, 0.f) : v;
+                            const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldy + (unsigned)co) * 4u;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ml < frame) ? off : kOOB, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias (+ folded BN) (+ residual) + ReLU; lane = output channel, 16 rows per accumulator tile ----
     if (!active) return;
     const bool relu = (p.flags & PTX_EPI_RELU) != 0;
@@ -268,34 +371,52 @@ __device__ __forceinline__ void conv_body_tile(const BodyF32Args& p, float* smem
 // Tile list of a launch: blockIdx.x < n_tall -> tall tiles (frames in XCD-contiguous chunks), then the square tiles.
 // blockIdx.y = 64-channel column tile.  (Two plain kernels rather than one template: hipcc's host pass dropped the stub of
 // the second instantiation.)
+template <bool CHAIN>
 __device__ __forceinline__ void conv_body_square(const BodyF32Args& p, float* smem, int b, int nt) {
     const int tile = xcd_remap(b, p.n_sq);
     const int f = tile / p.sq_per_frame, k = tile - f * p.sq_per_frame;
     const int n = f / p.T, to = f - n * p.T;
-    conv_body_tile<2, 2, 1, 1, 8>(p, smem, n, to, p.tall_per_frame * 256 + k * 64, nt, p.PR_sq, p.dv_npos_sq);
+    conv_body_tile<2, 2, 1, 1, 8, CHAIN>(p, smem, n, to, p.tall_per_frame * 256 + k * 64, nt, p.PR_sq, p.dv_npos_sq);
 }
 
-__global__ void __launch_bounds__(kB3NT, 2) conv_body_f32_kernel(const BodyF32Args p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <bool CHAIN>
+__device__ __forceinline__ void conv_body_mixed(const BodyF32Args& p, float* smem) {
     const int b = blockIdx.x;
     if (b < p.n_tall) {
         const int tile = xcd_remap(b, p.n_tall);
         const int f = tile / p.tall_per_frame, k = tile - f * p.tall_per_frame;        // frame (n, to), tile inside it
         const int n = f / p.T, to = f - n * p.T;
-        conv_body_tile<4, 1, 2, 2, 8>(p, smem, n, to, k * 256, blockIdx.y, p.PR_tall, p.dv_npos_tall);
+        conv_body_tile<4, 1, 2, 2, 8, CHAIN>(p, smem, n, to, k * 256, blockIdx.y, p.PR_tall, p.dv_npos_tall);
     } else {
-        conv_body_square(p, smem, b - p.n_tall, blockIdx.y);
+        conv_body_square<CHAIN>(p, smem, b - p.n_tall, blockIdx.y);
     }
+}
+
+__global__ void __launch_bounds__(kB3NT, 2) conv_body_f32_kernel(const BodyF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_body_mixed<false>(p, smem);
 }
 
 __global__ void __launch_bounds__(kB3NT, 2) conv_body_f32_sq_kernel(const BodyF32Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv_body_square(p, smem, blockIdx.x, blockIdx.y);
+    conv_body_square<false>(p, smem, blockIdx.x, blockIdx.y);
+}
+
+// the same two launches with the chained 1x1x1 tail (one column tile: the tail needs the whole intermediate row)
+__global__ void __launch_bounds__(kB3NT, 3) conv_body_chain_f32_kernel(const BodyF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_body_mixed<true>(p, smem);
+}
+
+__global__ void __launch_bounds__(kB3NT, 3) conv_body_chain_f32_sq_kernel(const BodyF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_body_square<true>(p, smem, blockIdx.x, 0);
 }
 
 // generic packed filter [tap][Co_pad][Kc] (ptx_pack_conv_weight: BN scale folded in) -> [nt][kt][chunk][kh * 3 + kw][q][g][64][4]
+// (taps = 9; taps = 1 / kT = 1 / chunks = 4 packs a pointwise filter as the chained tail's [N2 / 64][8 octets][2][64][4] image)
 __global__ void __launch_bounds__(256) pack_body_f32_kernel(const float* __restrict__ wp, float* __restrict__ out, int kT, int Co_pad,
-                                                            int Kc, int chunks, int total) {
+                                                            int Kc, int chunks, int taps, int total) {
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int i = idx & 3;
         int r = idx >> 2;
@@ -305,15 +426,15 @@ __global__ void __launch_bounds__(256) pack_body_f32_kernel(const float* __restr
         r >>= 1;
         const int q = r & 1;
         r >>= 1;
-        const int tap = r % 9;
-        r /= 9;
+        const int tap = r % taps;
+        r /= taps;
         const int ch = r % chunks;
         r /= chunks;
         const int kt = r % kT;
         const int nt = r / kT;
         const int c = ch * kB3CK + 8 * q + 4 * g + i;
         const int co = nt * kB3BN + col;
-        out[idx] = (co < Co_pad && c < Kc) ? wp[((size_t)(kt * 9 + tap) * Co_pad + co) * Kc + c] : 0.f;
+        out[idx] = (co < Co_pad && c < Kc) ? wp[((size_t)(kt * taps + tap) * Co_pad + co) * Kc + c] : 0.f;
     }
 }
 
@@ -370,11 +491,11 @@ extern "C" int ptx_pack_conv_body_f32_weight(const ptx_conv3d_desc* d, const flo
         return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: a (1|3)x3x3 filter, Ci a multiple of 16, Co_pad a multiple of 64");
     if (total >= (1ull << 31)) return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: filter too large");
     hipLaunchKernelGGL(pack_body_f32_kernel, dim3((unsigned)std::min<size_t>(cdiv64((int64_t)total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       w_packed, w_body, d->kT, d->Co_pad, d->Kc, d->Ci / kB3CK, (int)total);
+                       w_packed, w_body, d->kT, d->Co_pad, d->Kc, d->Ci / kB3CK, 9, (int)total);
     return hip_check(hipGetLastError(), "pack_conv_body_f32 launch");
 }
 
-static int launch_body(bool tall, const BodyF32Args& a, dim3 grid, size_t lds, ptx_stream_t stream) {
+static int launch_body(bool tall, bool chain, const BodyF32Args& a, dim3 grid, size_t lds, ptx_stream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
@@ -382,11 +503,38 @@ static int launch_body(bool tall, const BodyF32Args& a, dim3 grid, size_t lds, p
         const int max_lds = (int)((16 * kB3PosMax + 3 * kB3Slot) * sizeof(float));
         PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_body_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_body_f32_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_body_chain_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_body_chain_f32_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    if (tall) hipLaunchKernelGGL(conv_body_f32_kernel, grid, dim3(kB3NT), lds, (hipStream_t)stream, a);
+    if (tall && chain) hipLaunchKernelGGL(conv_body_chain_f32_kernel, grid, dim3(kB3NT), lds, (hipStream_t)stream, a);
+    else if (tall) hipLaunchKernelGGL(conv_body_f32_kernel, grid, dim3(kB3NT), lds, (hipStream_t)stream, a);
+    else if (chain) hipLaunchKernelGGL(conv_body_chain_f32_sq_kernel, grid, dim3(kB3NT), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_body_f32_sq_kernel, grid, dim3(kB3NT), lds, (hipStream_t)stream, a);
     return PTX_OK;
+}
+
+// geometry / pointer-independent part of the launch arguments of `d` on `shape`; returns the dynamic LDS bytes
+static size_t body_make_args(const ptx_conv3d_desc* d, int shape, BodyF32Args& a, BodyGeom& g) {
+    body_geom(d, shape, &g);
+    a.N = d->N; a.T = d->Ti; a.H = d->Hi; a.W = d->Wi; a.C = d->Ci; a.ldx = d->ldx;
+    a.kT = d->kT; a.pT = d->pT;
+    a.chunks = d->Ci / kB3CK;
+    a.PC = d->Wi + 2;
+    a.tall_per_frame = g.tall_per_frame; a.sq_per_frame = g.sq_per_frame;
+    a.PR_tall = g.PR_tall; a.PR_sq = g.PR_sq;
+    const int frames = d->N * d->Ti;
+    a.n_tall = frames * g.tall_per_frame;
+    a.n_sq = frames * g.sq_per_frame;
+    const uint64_t M = (uint64_t)d->N * d->Ti * d->Hi * d->Wi;
+    a.x_bytes = (unsigned)(M * d->ldx * 4ull);
+    a.w_bytes = (unsigned)(ptx_conv_body_f32_weight_elems(d) * 4ull);
+    b3_fdiv_make((unsigned)d->Wi, a.dv_w);
+    b3_fdiv_make((unsigned)a.PC, a.dv_pc);
+    b3_fdiv_make((unsigned)(a.PR_tall * a.PC), a.dv_npos_tall);
+    b3_fdiv_make((unsigned)(a.PR_sq * a.PC), a.dv_npos_sq);
+    const int npos = std::max(g.tall_per_frame ? a.PR_tall * a.PC : 0, a.PR_sq * a.PC);
+    return (size_t)(16 * npos + 3 * kB3Slot) * sizeof(float);
 }
 
 extern "C" int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* d, const float* x, const float* w_body, const float* bias, const float* res,
@@ -398,33 +546,83 @@ extern "C" int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* d, const float* x, c
                     "multiple of 64, bias / ReLU / same-shape residual epilogue, and an input patch of at most %d positions (shape %d)", kB3PosMax, shape);
     if ((d->flags & PTX_EPI_RES_ADD) && !res) return fail(PTX_ERR_INVALID, "conv_body_f32: PTX_EPI_RES_ADD without a residual");
     BodyGeom g;
-    body_geom(d, shape, &g);
     BodyF32Args a{};
+    const size_t lds = body_make_args(d, shape, a, g);
     a.x = x; a.w = w_body; a.bias = bias; a.res = (d->flags & PTX_EPI_RES_ADD) ? res : nullptr; a.y = y;
-    a.N = d->N; a.T = d->Ti; a.H = d->Hi; a.W = d->Wi; a.C = d->Ci; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr > 0 ? d->ldr : d->ldy;
+    a.ldy = d->ldy; a.ldr = d->ldr > 0 ? d->ldr : d->ldy;
     a.ncol = (d->Co + 3) / 4 * 4;
-    a.kT = d->kT; a.pT = d->pT;
-    a.chunks = d->Ci / kB3CK;
-    a.PC = d->Wi + 2;
-    a.tall_per_frame = g.tall_per_frame; a.sq_per_frame = g.sq_per_frame;
-    a.PR_tall = g.PR_tall; a.PR_sq = g.PR_sq;
-    const int frames = d->N * d->Ti;
-    a.n_tall = frames * g.tall_per_frame;
-    a.n_sq = frames * g.sq_per_frame;
     a.flags = d->flags;
     const uint64_t M = (uint64_t)d->N * d->Ti * d->Hi * d->Wi;
-    a.x_bytes = (unsigned)(M * d->ldx * 4ull);
-    a.w_bytes = (unsigned)(ptx_conv_body_f32_weight_elems(d) * 4ull);
     a.y_bytes = (unsigned)(M * d->ldy * 4ull);
     a.r_bytes = (unsigned)(M * a.ldr * 4ull);
-    b3_fdiv_make((unsigned)d->Wi, a.dv_w);
-    b3_fdiv_make((unsigned)a.PC, a.dv_pc);
-    b3_fdiv_make((unsigned)(a.PR_tall * a.PC), a.dv_npos_tall);
-    b3_fdiv_make((unsigned)(a.PR_sq * a.PC), a.dv_npos_sq);
-    const int npos = std::max(g.tall_per_frame ? a.PR_tall * a.PC : 0, a.PR_sq * a.PC);
-    const size_t lds = (size_t)(16 * npos + 3 * kB3Slot) * sizeof(float);
     const dim3 grid((unsigned)(a.n_tall + a.n_sq), (unsigned)cdiv(a.ncol, kB3BN));
-    int rc = launch_body(g.tall_per_frame > 0, a, grid, lds, stream);
+    int rc = launch_body(g.tall_per_frame > 0, false, a, grid, lds, stream);
     if (rc != PTX_OK) return rc;
     return hip_check(hipGetLastError(), "conv_body_f32 launch");
+}
+
+// ---- chained: conv (body kernel) -> bias -> ReLU -> 1x1x1 tail -> bias2 (-> + residual) -> ReLU in ONE launch ----
+extern "C" int ptx_conv_body_chain_f32_supported(const ptx_conv3d_desc* d, const ptx_conv3d_desc* t, int shape) {
+    if (!d || !t) return 0;
+    if ((d->flags & ~PTX_EPI_RELU) || (t->flags & ~(PTX_EPI_RELU | PTX_EPI_RES_ADD))) return 0;
+    ptx_conv3d_desc dd = *d;
+    dd.ldy = (d->Co + 3) / 4 * 4;                       // the first conv's output never reaches memory
+    if (!ptx_conv_body_f32_supported(&dd, shape)) return 0;
+    if (d->Co > kB3BN) return 0;                        // the tail needs the whole intermediate row in one workgroup
+    if (t->kT != 1 || t->kH != 1 || t->kW != 1 || t->sT != 1 || t->sH != 1 || t->sW != 1 || t->pT || t->pH || t->pW || t->groups > 1) return 0;
+    if (t->N != d->N || t->Ti != d->To || t->Hi != d->Ho || t->Wi != d->Wo || t->To != d->To || t->Ho != d->Ho || t->Wo != d->Wo) return 0;
+    if (t->Ci != d->Co || t->Kc < t->Ci || t->Co < 1 || t->Co_pad % kB3BN || t->Co_pad < t->Co) return 0;
+    if (t->ldy < (t->Co + 3) / 4 * 4 || t->ldy % 4) return 0;
+    if ((t->flags & PTX_EPI_RES_ADD) && (t->ldr < t->Co || t->ldr % 4)) return 0;
+    const int64_t M = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    if (M * t->ldy * 4 >= 0x80000000LL || M * std::max(t->ldr, 1) * 4 >= 0x80000000LL) return 0;
+    return 1;
+}
+
+extern "C" size_t ptx_conv_body_tail_f32_weight_elems(const ptx_conv3d_desc* t) {
+    if (!t || t->Co_pad <= 0 || t->Co_pad % kB3BN) return 0;
+    return (size_t)(t->Co_pad / kB3BN) * 8 * 2 * 64 * 4;
+}
+
+extern "C" int ptx_pack_conv_body_tail_f32_weight(const ptx_conv3d_desc* t, const float* w_packed, float* w_tail, ptx_stream_t stream) {
+    if (!t || !w_packed || !w_tail) return fail(PTX_ERR_INVALID, "pack_conv_body_tail_f32: null pointer");
+    const size_t total = ptx_conv_body_tail_f32_weight_elems(t);
+    if (!total || t->kT != 1 || t->kH != 1 || t->kW != 1 || t->Ci > 64 || t->Kc < t->Ci)
+        return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_tail_f32: a 1x1x1 filter over <= 64 channels, Co_pad a multiple of 64");
+    hipLaunchKernelGGL(pack_body_f32_kernel, dim3((unsigned)std::min<size_t>(cdiv64((int64_t)total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w_packed, w_tail, 1, t->Co_pad, t->Kc, 4, 1, (int)total);
+    return hip_check(hipGetLastError(), "pack_conv_body_tail_f32 launch");
+}
+
+extern "C" int ptx_conv_body_chain_f32_fwd(const ptx_conv3d_desc* d, const ptx_conv3d_desc* t, const float* x, const float* w_body,
+                                           const float* bias, const float* w_tail, const float* bias2, const float* res, float* y, int shape,
+                                           ptx_stream_t stream) {
+    if (!d || !t || !x || !w_body || !w_tail || !y) return fail(PTX_ERR_INVALID, "conv_body_chain_f32: null pointer");
+    if (((uintptr_t)x | (uintptr_t)w_body | (uintptr_t)w_tail | (uintptr_t)y | (uintptr_t)res) & 15)
+        return fail(PTX_ERR_INVALID, "conv_body_chain_f32: pointers must be 16-byte aligned");
+    if (!ptx_conv_body_chain_f32_supported(d, t, shape))
+        return fail(PTX_ERR_UNSUPPORTED, "conv_body_chain_f32: a body conv (ptx_conv_body_f32_supported) of at most 64 output channels with a ReLU-only "
+                    "epilogue, followed by a dense 1x1x1 / unit-stride conv over its output positions (bias / ReLU / same-shape residual)");
+    if ((t->flags & PTX_EPI_RES_ADD) && !res) return fail(PTX_ERR_INVALID, "conv_body_chain_f32: PTX_EPI_RES_ADD without a residual");
+    ptx_conv3d_desc dd = *d;
+    dd.ldy = (d->Co + 3) / 4 * 4;
+    BodyGeom g;
+    BodyF32Args a{};
+    size_t lds = body_make_args(&dd, shape, a, g);
+    lds = std::max(lds, (size_t)4 * kB3Park * sizeof(float));          // four parked tiles (tall) / two (square)
+    a.x = x; a.w = w_body; a.bias = bias; a.res = (t->flags & PTX_EPI_RES_ADD) ? res : nullptr; a.y = y;
+    a.w2 = w_tail; a.bias2 = bias2;
+    a.ncol1 = (d->Co + 3) / 4 * 4;
+    a.flags1 = d->flags;
+    a.flags = t->flags;
+    a.ldy = t->ldy; a.ldr = t->ldr > 0 ? t->ldr : t->ldy;
+    a.ncol = (t->Co + 3) / 4 * 4;
+    const uint64_t M = (uint64_t)d->N * d->Ti * d->Hi * d->Wi;
+    a.y_bytes = (unsigned)(M * t->ldy * 4ull);
+    a.r_bytes = (unsigned)(M * a.ldr * 4ull);
+    a.w2_bytes = (unsigned)(ptx_conv_body_tail_f32_weight_elems(t) * 4ull);
+    const dim3 grid((unsigned)(a.n_tall + a.n_sq), 1u);
+    int rc = launch_body(g.tall_per_frame > 0, true, a, grid, lds, stream);
+    if (rc != PTX_OK) return rc;
+    return hip_check(hipGetLastError(), "conv_body_chain_f32 launch");
 }

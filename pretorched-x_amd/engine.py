@@ -496,13 +496,21 @@ class ConvStep:
 class ChainStep:
     """One ptx_conv3d_chain_fwd launch: conv -> BN -> ReLU -> 1x1x1 conv -> BN (-> + residual) -> ReLU, the intermediate
     tile kept in LDS (conv_chain.hip)."""
-    __slots__ = ("d", "d2", "x", "w", "b", "w2", "b2", "res", "y", "cfg", "plan", "label", "macs", "hbm_bytes", "key")
+    __slots__ = ("d", "d2", "x", "w", "b", "w2", "b2", "res", "y", "cfg", "plan", "label", "macs", "hbm_bytes", "key",
+                 "body", "body_ok", "body_w", "body_w2")
 
     @property
     def kernel(self):
+        if getattr(self, "body", None) is not None:
+            return "conv_body_chain_f32"
         return _lib.lib().ptx_conv3d_chain_config_name(self.cfg).decode()
 
     def issued_flop(self):
+        if getattr(self, "body", None) is not None:
+            d = self.d
+            frames = sum(max(0, min(d.kT - 1, d.Ti - 1 - (t - d.pT)) - max(0, d.pT - t) + 1) for t in range(d.To))
+            rows = -(-(d.Ho * d.Wo) // 32) * 32
+            return 2.0 * d.N * rows * 64.0 * (frames * 9 * d.Ci + d.To * (-(-_r4(self.d2.Co) // 64) * 64))
         tile = _tile_dims(self.kernel)
         if tile is None:
             return 2.0 * self.macs
@@ -512,6 +520,10 @@ class ChainStep:
         return issued_conv_flop(self.d, tile) + tail
 
     def __call__(self, st):
+        if getattr(self, "body", None) is not None:       # the patch-resident body kernel with its chained tail
+            check(_lib.lib().ptx_conv_body_chain_f32_fwd(C.byref(self.d), C.byref(self.d2), self.x, self.body_w, self.b, self.body_w2,
+                                                         self.b2, self.res, self.y, self.body, st), self.label)
+            return
         check(_lib.lib().ptx_conv3d_chain_fwd(C.byref(self.d), C.byref(self.d2), self.x, self.w, self.b, self.w2, self.b2,
                                               self.res, self.y, self.cfg, st), self.label)
 
@@ -1003,6 +1015,29 @@ class Plan:
         st.res = _ptr(res.t) if res is not None else C.c_void_p(0)
         st.macs = M * (pk.Co * getattr(pk, "real_ci", pk.Ci) * kT * kH * kW + pk2.Co * pk.Co)
         st.hbm_bytes = 0
+        # the same pair on the patch-resident body kernel with its chained tail (round 6): a second execution of the chained
+        # launch, chosen per pair by the tuner ("body:chain:" keys); PTX_CONV_BODY=0 / tall / square as for the plain convs
+        st.body, st.body_ok, st.body_w, st.body_w2 = None, (), None, None
+        if not x3 and (kT, kH, kW) in ((3, 3, 3), (1, 3, 3)) and os.environ.get("PTX_CONV_BODY", "1") != "0":
+            st.body_ok = tuple(sh for sh in (0, 1) if self.lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(d2), sh))
+        if st.body_ok:
+            wb = torch.empty(int(self.lib.ptx_conv_body_f32_weight_elems(C.byref(d))), device=self.dev, dtype=torch.float32)
+            wt = torch.empty(int(self.lib.ptx_conv_body_tail_f32_weight_elems(C.byref(d2))), device=self.dev, dtype=torch.float32)
+            self.keepalive += [wb, wt]
+            st.body_w, st.body_w2 = _ptr(wb), _ptr(wt)
+            lib_, w1s, w2s = self.lib, _ptr(pk.w), _ptr(pk2.w)
+
+            def repack_body_chain(d=d, d2=d2, lib_=lib_, w1s=w1s, w2s=w2s, w1d=st.body_w, w2d=st.body_w2):
+                check(lib_.ptx_pack_conv_body_f32_weight(C.byref(d), w1s, w1d, _stream()), "ptx_pack_conv_body_f32_weight")
+                check(lib_.ptx_pack_conv_body_tail_f32_weight(C.byref(d2), w2s, w2d, _stream()), "ptx_pack_conv_body_tail_f32_weight")
+            if torch.device(self.dev).type != "meta":
+                self.refreshers.append(repack_body_chain)
+            force = os.environ.get("PTX_CONV_BODY", "1")
+            known = body_lookup(key)
+            if force in BODY_SHAPES and BODY_SHAPES.index(force) in st.body_ok:
+                st.body = BODY_SHAPES.index(force)
+            elif known is not None and known in st.body_ok:
+                st.body = known
         self.chain_steps.append(st)
         return y, st
 
@@ -2090,7 +2125,8 @@ class Engine:
                 return
             if any(tuned_lookup(json.dumps(s.d.key()), _flags_kind(s.d.flags)) is None
                    or (getattr(s, "body_ok", ()) and body_lookup(json.dumps(s.d.key())) is None)
-                   for s in plan.conv_steps) or any(chain_lookup(s.key) is None for s in plan.chain_steps) \
+                   for s in plan.conv_steps) or any(chain_lookup(s.key) is None or (getattr(s, "body_ok", ()) and body_lookup(s.key) is None)
+                                                    for s in plan.chain_steps) \
                     or any(alt_lookup(a.key) is None for a in plan.alt_steps) \
                     or (os.environ.get("PTX_PROGRAM", "0") == "auto" and any(prog_lookup(p.key) is None for p in plan.program_steps)):
                 self._autotune(model, x, iters=2, only_untuned=True, plan=plan)
@@ -2307,11 +2343,11 @@ class Engine:
         """Time every compiled tile configuration (x a few split-K factors) for each distinct conv
         problem of the plan with HIP events and keep the fastest.  Holds the plan's exclusive lock: the
         tuner relaunches convs into the plan's buffers."""
+        own_plan = plan is not None
         if plan is None:
             self._validate(model, x, model.arch.dims)
             with torch.cuda.device(x.device):
                 plan = self.plan_for(model, _dense16(x))
-        own_plan = plan is not None
         with torch.cuda.device(x.device), plan.exclusive():
             plan = self._autotune(model, x, iters, verbose, persist, only_untuned, plan)
         # the clip-lanes verdict of this (architecture, shape), measured on the tuned tiles of both launch shapes -- only for
@@ -2469,14 +2505,17 @@ class Engine:
                         lib.ptx_conv3d_config_name(best[1]).decode(), best[2], best[0],
                         2e-9 * stp.macs / best[0]))
             # chained launches: time every chained tile that holds the intermediate row
-            seen_c = {}
+            seen_c, seen_cb = {}, {}
             for stp in plan.chain_steps:
                 if stp.key in seen_c:
                     stp.cfg = seen_c[stp.key]
+                    if stp.key in seen_cb:
+                        stp.body = seen_cb[stp.key]
                     continue
-                if only_untuned and chain_lookup(stp.key) is not None:
+                if only_untuned and chain_lookup(stp.key) is not None and (not getattr(stp, "body_ok", ()) or body_lookup(stp.key) is not None):
                     continue
                 best = None
+                stp.body = None                  # the chained-tile sweep times the implicit-GEMM chain
                 for cfg in range(lib.ptx_conv3d_chain_num_configs()):
                     if not lib.ptx_conv3d_chain_supported(C.byref(stp.d), C.byref(stp.d2), cfg):
                         continue
@@ -2501,6 +2540,29 @@ class Engine:
                     stp.cfg = keep
                 if best is not None:
                     stp.cfg = best[1]
+                    # ... and the body kernel's chained form against the best chained tile (2 % bar)
+                    if getattr(stp, "body_ok", ()) and os.environ.get("PTX_CONV_BODY", "1") not in ("0",) + BODY_SHAPES:
+                        t_best, pick = best[0], -1
+                        for sh in stp.body_ok:
+                            stp.body = sh
+                            stp(_stream())
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(max(iters, 3)):
+                                stp(_stream())
+                            e1.record()
+                            e1.synchronize()
+                            ms = e0.elapsed_time(e1) / max(iters, 3)
+                            if log is not None:
+                                log.write("%s\tconv_body_chain_f32/%s\t%.4f ms\t%.1f TF\n" % (stp.label, BODY_SHAPES[sh], ms, 2e-9 * stp.macs / ms))
+                            if verbose:
+                                print("tune %-34s body-chain/%-6s %.4f ms  %.1f TF  (best chained tile %.4f ms)" % (
+                                    stp.label, BODY_SHAPES[sh], ms, 2e-9 * stp.macs / ms, best[0]))
+                            if ms < 0.98 * t_best:
+                                t_best, pick = ms, sh
+                        stp.body = pick if pick >= 0 else None
+                        body_store(stp.key, pick)
+                        seen_cb[stp.key] = stp.body
                     seen_c[stp.key] = best[1]
                     chain_store(stp.key, best[1])
                     if verbose:

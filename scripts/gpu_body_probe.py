@@ -69,3 +69,61 @@ for name, C_, T, H in (("layer1.conv2 (C3)", 64, 8, 56), ("layer2.conv2 (C11)", 
         err = (y1 - y0).abs().max().item()
         print("%-20s clips=%d  body shape %d %37s %.4f ms  %.1f TF   max|d vs generic| = %.2e (max|y| %.2f)" % (
             name, N, shape, "", t_b, 2e-9 * macs / t_b, err, y0.abs().max().item()), flush=True)
+
+
+# ---- the chained tail: layer1.{1,2}.conv2 + conv3 (+ residual + ReLU) of config 2, body kernel vs ptx_conv3d_chain_fwd ----
+N, C_, N1, N2, T, H, W = clips, 64, 64, 256, 8, 56, 56
+g = torch.Generator().manual_seed(2)
+x = torch.randn(N, T, H, W, C_, generator=g).to(DEV)
+res = torch.randn(N, T, H, W, N2, generator=g).to(DEV)
+w1 = (torch.randn(N1, C_, 3, 3, 3, generator=g) * (2.0 / (C_ * 27)) ** 0.5).to(DEV)
+w2 = (torch.randn(N2, N1, 1, 1, 1, generator=g) * (2.0 / N1) ** 0.5).to(DEV)
+null = C.c_void_p(0)
+
+
+def pack(w):
+    Co, Ci, kT, kH, kW = w.shape
+    pd = L.PackDesc(Co, Ci, kT, kH, kW, Ci, (Co + 127) // 128 * 128, 0)
+    wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+    bp = torch.empty(pd.Co_pad, device=DEV)
+    L.check(lib.ptx_pack_conv_weight(C.byref(pd), p(w), null, null, null, null, null, C.c_float(0.0), p(wp), p(bp), st()), "pack")
+    return pd, wp, bp
+
+
+pd1, wp1, bp1 = pack(w1)
+pd2, wp2, bp2 = pack(w2)
+d = L.ConvDesc()
+d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C_, C_
+d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, N1, N1
+d.kT = d.kH = d.kW = 3
+d.sT = d.sH = d.sW = 1
+d.pT = d.pH = d.pW = 1
+d.Kc, d.Co_pad, d.flags, d.groups = pd1.Kc, pd1.Co_pad, L.PTX_EPI_RELU, 1
+t = L.ConvDesc()
+t.N, t.Ti, t.Hi, t.Wi, t.Ci, t.ldx = N, T, H, W, N1, N1
+t.To, t.Ho, t.Wo, t.Co, t.ldy = T, H, W, N2, N2
+t.kT = t.kH = t.kW = t.sT = t.sH = t.sW = 1
+t.Kc, t.Co_pad, t.flags, t.ldr, t.groups = pd2.Kc, pd2.Co_pad, L.PTX_EPI_RELU | L.PTX_EPI_RES_ADD, N2, 1
+y0 = torch.empty(N, T, H, W, N2, device=DEV)
+y1 = torch.empty_like(y0)
+macs = N * T * H * W * (N1 * C_ * 27 + N2 * N1)
+best = None
+for cfg in range(lib.ptx_conv3d_chain_num_configs()):
+    if not lib.ptx_conv3d_chain_supported(C.byref(d), C.byref(t), cfg):
+        continue
+    ms = timed(lambda: L.check(lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(t), p(x), p(wp1), p(bp1), p(wp2), p(bp2), p(res), p(y0), cfg, st()), "chain"), 10)
+    if best is None or ms < best[0]:
+        best = (ms, cfg)
+L.check(lib.ptx_conv3d_chain_fwd(C.byref(d), C.byref(t), p(x), p(wp1), p(bp1), p(wp2), p(bp2), p(res), p(y0), best[1], st()), "chain")
+print("layer1 conv2+conv3     clips=%d  chained tile %-34s %.4f ms  %.1f TF" % (N, lib.ptx_conv3d_chain_config_name(best[1]).decode(), best[0], 2e-9 * macs / best[0]), flush=True)
+wb = torch.empty(lib.ptx_conv_body_f32_weight_elems(C.byref(d)), device=DEV)
+wt = torch.empty(lib.ptx_conv_body_tail_f32_weight_elems(C.byref(t)), device=DEV)
+L.check(lib.ptx_pack_conv_body_f32_weight(C.byref(d), p(wp1), p(wb), st()), "pack body")
+L.check(lib.ptx_pack_conv_body_tail_f32_weight(C.byref(t), p(wp2), p(wt), st()), "pack tail")
+for shape in (0, 1):
+    if not lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(t), shape):
+        continue
+    y1.fill_(float("nan"))
+    ms = timed(lambda: L.check(lib.ptx_conv_body_chain_f32_fwd(C.byref(d), C.byref(t), p(x), p(wb), p(bp1), p(wt), p(bp2), p(res), p(y1), shape, st()), "body chain"))
+    print("layer1 conv2+conv3     clips=%d  body chain shape %d %28s %.4f ms  %.1f TF   max|d vs chained tile| = %.2e (max|y| %.2f)" % (
+        N, shape, "", ms, 2e-9 * macs / ms, (y1 - y0).abs().max().item(), y0.abs().max().item()), flush=True)

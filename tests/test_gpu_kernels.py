@@ -2016,3 +2016,72 @@ def test_conv_body_f32_refusals(ptx):
     assert not lib.ptx_conv_body_f32_supported(C.byref(d), 2)
     x = torch.zeros(8, device=DEV)
     assert lib.ptx_conv_body_f32_fwd(C.byref(d), None, _p(x), None, None, _p(x), 0, _st()) == 1          # PTX_ERR_INVALID
+
+
+@pytest.mark.parametrize("N,C,N1,N2,T,H,W,shape,with_res", [
+    (2, 64, 64, 256, 3, 56, 56, 0, True),       # layer1.{1,2} of config 2: conv2 + conv3 + residual + ReLU
+    (1, 64, 64, 256, 2, 56, 56, 1, True),
+    (1, 32, 48, 100, 2, 17, 23, 0, False),      # ragged: 48 intermediate channels, 100 output columns, no residual
+    (2, 64, 64, 128, 2, 14, 14, 1, True),
+])
+def test_conv_body_chain_f32(ptx, N, C, N1, N2, T, H, W, shape, with_res):
+    """ptx_conv_body_chain_f32_fwd: conv3x3x3 -> bn -> relu -> conv1x1x1 -> bn (-> += residual) -> relu in one launch
+    (resnet3D.py:129-142) against the same ops on the CPU, and against ptx_conv3d_chain_fwd's arithmetic class (fp32)."""
+    L, lib = ptx._lib, _lib(ptx)
+    x = rnd(N, C, T, H, W, seed=11)
+    w1 = rnd(N1, C, 3, 3, 3, seed=12, scale=(2.0 / (C * 27)) ** 0.5)
+    w2 = rnd(N2, N1, 1, 1, 1, seed=13, scale=(2.0 / N1) ** 0.5)
+    bn1, bn2 = make_bn(N1, 14), make_bn(N2, 15)
+    res = rnd(N, N2, T, H, W, seed=16) if with_res else None
+    null = C.c_void_p(0)
+
+    def pack(w, bn):
+        Co, Ci, kT, kH, kW = w.shape
+        pd = L.PackDesc(Co, Ci, kT, kH, kW, _r4(Ci), (Co + 127) // 128 * 128, 0)
+        wp = torch.empty(lib.ptx_packed_weight_elems(C.byref(pd)), device=DEV)
+        bp = torch.empty(pd.Co_pad, device=DEV)
+        ts = [t.contiguous().to(DEV) for t in bn[:4]]
+        wd = w.contiguous().to(DEV)
+        L.check(lib.ptx_pack_conv_weight(C.byref(pd), _p(wd), null, *[_p(t) for t in ts], C.c_float(bn[4]), _p(wp), _p(bp), _st()), "pack")
+        torch.cuda.synchronize()
+        return pd, wp, bp
+    pd1, wp1, bp1 = pack(w1, bn1)
+    pd2, wp2, bp2 = pack(w2, bn2)
+    xd = to_cl(x)
+    yd = torch.full((N, T, H, W, _r4(N2)), float("nan"), device=DEV)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C, xd.shape[-1]
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, N1, _r4(N1)
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 3, 3, 3, 1, 1, 1, 1, 1, 1
+    d.Kc, d.Co_pad, d.flags = pd1.Kc, pd1.Co_pad, L.PTX_EPI_RELU
+    t = L.ConvDesc()
+    t.N, t.Ti, t.Hi, t.Wi, t.Ci, t.ldx = N, T, H, W, N1, _r4(N1)
+    t.To, t.Ho, t.Wo, t.Co, t.ldy = T, H, W, N2, _r4(N2)
+    t.kT = t.kH = t.kW = t.sT = t.sH = t.sW = 1
+    t.Kc, t.Co_pad = pd2.Kc, pd2.Co_pad
+    t.flags = L.PTX_EPI_RELU | (L.PTX_EPI_RES_ADD if with_res else 0)
+    rd = to_cl(res) if with_res else None
+    t.ldr = rd.shape[-1] if with_res else 0
+    if not lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(t), shape):
+        assert shape == 0 and H * W < 256
+        return
+    wb = torch.empty(lib.ptx_conv_body_f32_weight_elems(C.byref(d)), device=DEV)
+    wt = torch.empty(lib.ptx_conv_body_tail_f32_weight_elems(C.byref(t)), device=DEV)
+    L.check(lib.ptx_pack_conv_body_f32_weight(C.byref(d), _p(wp1), _p(wb), _st()), "pack body")
+    L.check(lib.ptx_pack_conv_body_tail_f32_weight(C.byref(t), _p(wp2), _p(wt), _st()), "pack tail")
+    outs = []
+    for _ in range(2):
+        yd.fill_(float("nan"))
+        L.check(lib.ptx_conv_body_chain_f32_fwd(C.byref(d), C.byref(t), _p(xd), _p(wb), _p(bp1), _p(wt), _p(bp2),
+                                                _p(rd) if with_res else null, _p(yd), shape, _st()), "body chain")
+        torch.cuda.synchronize()
+        outs.append(from_cl(yd, N2))
+    mid = ref_conv(x, w1, (1, 1, 1), (1, 1, 1), bn=bn1, relu=True)
+    want = ref_conv(mid, w2, (1, 1, 1), (0, 0, 0), bn=bn2, relu=True, res=res)
+    close(outs[0], want)
+    assert torch.equal(outs[0], outs[1])
+    # an over-wide first conv or a strided tail is refused
+    d.Co = 128
+    assert not lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(t), shape)
+    d.Co, t.sH = N1, 2
+    assert not lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(t), shape)
