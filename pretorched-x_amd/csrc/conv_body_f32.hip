@@ -273,32 +273,49 @@ __device__ __forceinline__ void conv_body_tile(const BodyF32Args& p, float* smem
             const bool tile_ok = (m0 + (wm * RT + i) * 32) < frame;
             if (tile_ok) {
                 for (int nc = wn; nc < n_chunks2; nc += WN) {
+                    // the residual rows of this chunk first: their latency hides behind the 64 MFMAs below
+                    float rv[2][16];
+                    if (has_res) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int co = nc * 64 + j * 32 + l32;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ml = m0 + (wm * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                                const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldr + (unsigned)co) * 4u;
+                                rv[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (co < p.ncol && ml < frame) ? off : kOOB, 0, 0));
+                            }
+                        }
+                    }
                     f32x16 acc2[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
                     const unsigned wbase = (unsigned)(((nc * 8 * 2 + g) * 64 + l32) * 16);
-                    f32x4 fb2[2], fbn[2];
+                    // filter fragments two octets ahead of the MFMAs that use them (L2 latency ~ one octet's 512 MFMA cycles)
+                    f32x4 fb0[2], fb1[2], fb2_[2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        fb2[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + j * 512, 0, 0));
+                    for (int j = 0; j < 2; ++j) {
+                        fb0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + j * 512, 0, 0));
+                        fb1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + 2048 + j * 512, 0, 0));
+                    }
 #pragma unroll 1
                     for (int q = 0; q < 8; ++q) {           // (rolled: unrolled, hipcc hoists all sixteen filter loads -- 64 registers)
                         const f32x4 fa2 = *reinterpret_cast<const f32x4*>(Pk + (2 * q + g) * kB3ParkStride + l32 * 4);
-                        if (q < 7) {
+                        const unsigned nxt = q + 2 < 8 ? wbase + (q + 2) * 2048 : kOOB;
 #pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                fbn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, wbase + (q + 1) * 2048 + j * 512, 0, 0));
-                        }
+                        for (int j = 0; j < 2; ++j)
+                            fb2_[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, nxt == kOOB ? kOOB : nxt + j * 512, 0, 0));
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
-                                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[k], fb2[j][k], acc2[j], 0, 0, 0);
-                        if (q < 7) {
-                            fb2[0] = fbn[0];
-                            fb2[1] = fbn[1];
+                                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[k], fb0[j][k], acc2[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            fb0[j] = fb1[j];
+                            fb1[j] = fb2_[j];
                         }
                     }
 #pragma unroll
@@ -306,20 +323,11 @@ __device__ __forceinline__ void conv_body_tile(const BodyF32Args& p, float* smem
                         const int co = nc * 64 + j * 32 + l32;
                         const bool co_ok = co < p.ncol;
                         const float bv = (p.bias2 && co_ok) ? p.bias2[co] : 0.f;
-                        float rv[16];
-                        if (has_res) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ml = m0 + (wm * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                                const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldr + (unsigned)co) * 4u;
-                                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (co_ok && ml < frame) ? off : kOOB, 0, 0));
-                            }
-                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ml = m0 + (wm * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                             float v = acc2[j][r] + bv;
-                            if (has_res) v += rv[r];
+                            if (has_res) v += rv[j][r];
                             v = relu2 ? fmaxf(v, 0.f) : v;
                             const unsigned off = ((unsigned)(m_frame + ml) * (unsigned)p.ldy + (unsigned)co) * 4u;
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && ml < frame) ? off : kOOB, 0, 0);

@@ -1890,20 +1890,25 @@ class Engine:
         if self.use_graph or x.shape[0] < 2 or x.shape[0] % 2:
             return 1
         keep = self._lanes
-        ms = {}
+        ms = {1: [], 2: []}
         try:
-            for n in (1, 2):
+            for n in (1, 2):                     # plans compiled, tiles tuned, clocks up
                 self._lanes = n
-                for _ in range(2):
+                for _ in range(3):
                     self.forward(model, x)
-                torch.cuda.synchronize(x.device)
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    self.forward(model, x)
-                torch.cuda.synchronize(x.device)
-                ms[n] = 1e3 * (time.perf_counter() - t0) / iters
+            # interleaved rounds (1, 2, 1, 2, ...): clock / thermal drift hits both arms alike; the verdict is the MEDIAN round
+            for _ in range(5):
+                for n in (1, 2):
+                    self._lanes = n
+                    torch.cuda.synchronize(x.device)
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        self.forward(model, x)
+                    torch.cuda.synchronize(x.device)
+                    ms[n].append(1e3 * (time.perf_counter() - t0) / iters)
         finally:
             self._lanes = keep
+        ms = {n: sorted(v)[len(v) // 2] for n, v in ms.items()}
         best = 2 if ms[2] < 0.985 * ms[1] else 1
         lanes_store(key, best)
         if verbose:
@@ -2701,9 +2706,17 @@ class Engine:
                 ms_of.append(e0.elapsed_time(e1) / iters)
         else:
             n = len(flat)
-            for _ in range(2):                  # untimed passes: every launch has run in this order, clocks are up
+            # untimed passes first: every launch has run in this order and the clocks are back up -- the caller may have left
+            # the GPU idle for seconds (bench.py's CPU leg), and the first tens of milliseconds after an idle period run at a
+            # lower clock (measured: a pass 1.9 % slower than the timed steps of the same plan when only two passes preceded it)
+            t_warm = time.perf_counter()
+            for k in range(64):
                 for stp in flat:
                     stp(st)
+                if k >= 3 and (k & 3) == 3:
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - t_warm > 0.25:
+                        break
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
             pa, pb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             pc, pd = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -2018,18 +2018,18 @@ def test_conv_body_f32_refusals(ptx):
     assert lib.ptx_conv_body_f32_fwd(C.byref(d), None, _p(x), None, None, _p(x), 0, _st()) == 1          # PTX_ERR_INVALID
 
 
-@pytest.mark.parametrize("N,C,N1,N2,T,H,W,shape,with_res", [
+@pytest.mark.parametrize("N,Cin,N1,N2,T,H,W,shape,with_res", [
     (2, 64, 64, 256, 3, 56, 56, 0, True),       # layer1.{1,2} of config 2: conv2 + conv3 + residual + ReLU
     (1, 64, 64, 256, 2, 56, 56, 1, True),
     (1, 32, 48, 100, 2, 17, 23, 0, False),      # ragged: 48 intermediate channels, 100 output columns, no residual
     (2, 64, 64, 128, 2, 14, 14, 1, True),
 ])
-def test_conv_body_chain_f32(ptx, N, C, N1, N2, T, H, W, shape, with_res):
+def test_conv_body_chain_f32(ptx, N, Cin, N1, N2, T, H, W, shape, with_res):
     """ptx_conv_body_chain_f32_fwd: conv3x3x3 -> bn -> relu -> conv1x1x1 -> bn (-> += residual) -> relu in one launch
     (resnet3D.py:129-142) against the same ops on the CPU, and against ptx_conv3d_chain_fwd's arithmetic class (fp32)."""
     L, lib = ptx._lib, _lib(ptx)
-    x = rnd(N, C, T, H, W, seed=11)
-    w1 = rnd(N1, C, 3, 3, 3, seed=12, scale=(2.0 / (C * 27)) ** 0.5)
+    x = rnd(N, Cin, T, H, W, seed=11)
+    w1 = rnd(N1, Cin, 3, 3, 3, seed=12, scale=(2.0 / (Cin * 27)) ** 0.5)
     w2 = rnd(N2, N1, 1, 1, 1, seed=13, scale=(2.0 / N1) ** 0.5)
     bn1, bn2 = make_bn(N1, 14), make_bn(N2, 15)
     res = rnd(N, N2, T, H, W, seed=16) if with_res else None
@@ -2050,7 +2050,7 @@ def test_conv_body_chain_f32(ptx, N, C, N1, N2, T, H, W, shape, with_res):
     xd = to_cl(x)
     yd = torch.full((N, T, H, W, _r4(N2)), float("nan"), device=DEV)
     d = L.ConvDesc()
-    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, C, xd.shape[-1]
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Cin, xd.shape[-1]
     d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, N1, _r4(N1)
     d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 3, 3, 3, 1, 1, 1, 1, 1, 1
     d.Kc, d.Co_pad, d.flags = pd1.Kc, pd1.Co_pad, L.PTX_EPI_RELU
