@@ -13,7 +13,7 @@ import torch
 from bench_workloads import (PEAK_F16_MFMA_TF, PEAK_F32_MFMA_TF, PEAK_HBM_GBS, SUSTAINED_F16_MFMA_TF)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-OWN_KERNELS = ("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16", "conv_body_f32")   # one row per kernel name
+OWN_KERNELS = ("conv_stem", "conv3x3_f16", "conv1x1_skip_f16", "conv1x1_pro_f16", "conv_body_f32", "conv_tstack_f32")   # one row per kernel name
 
 
 def newest_traffic_file(workload="cfg2"):

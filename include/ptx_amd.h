@@ -251,6 +251,10 @@ int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* desc, const float* x, int64_t s
  *          (2 x 2 waves x 32 x 32: small frames).  ptx_conv_body_f32_supported answers per (desc, shape).
  *   w_body: ptx_pack_conv_body_f32_weight(desc, w_packed) from the ptx_pack_conv_weight image of the same filter
  *          ([tap][Co_pad][Kc], BN folded) -- ptx_conv_body_f32_weight_elems floats.
+ * The same entry points also take the TEMPORAL half of a SpatioTemporalConv (r2plus1d.py:84-88) on a T-STACKED tile (shape 0
+ * only): kT in {3, 5, 7}, kH = kW = 1, unit strides, padding (kT / 2, 0, 0); a workgroup owns the same 32 positions of 8
+ * consecutive output frames and stages the 8 + kT - 1 input frames they touch once per 16-channel chunk.  Channels are walked
+ * in 16-wide chunks: ceil(Ci / 16) * 16 <= min(Kc, ldx), the columns [Ci, that) of x finite (their filter rows are zero).
  * Arithmetic: fp32 operands, fp32 accumulate; the k order differs from ptx_conv3d_fwd's tiles (fp32 reorder noise, 1e-6). */
 int ptx_conv_body_f32_supported(const ptx_conv3d_desc* desc, int shape);
 size_t ptx_conv_body_f32_weight_elems(const ptx_conv3d_desc* desc);

@@ -60,6 +60,8 @@ struct BodyF32Args {
     int ncol1;             // columns of the first conv (<= 64)
     unsigned flags1;       // PTX_EPI_RELU between the two convs
     unsigned w2_bytes;
+    // T-stacked tile of a (kT,1,1) temporal conv (conv_tstack_f32_kernel): tiles of 8 frames x 32 positions
+    int HW, t_tiles, s_tiles;
 };
 
 constexpr int kB3ParkStride = 32 * 4 + 4;            // floats between the 4-channel groups of a parked 32-row tile (+4: bank spread)
@@ -421,6 +423,204 @@ __global__ void __launch_bounds__(kB3NT, 3) conv_body_chain_f32_sq_kernel(const 
     conv_body_square<true>(p, smem, blockIdx.x, 0);
 }
 
+// ---- (kT,1,1) temporal convolutions on the same skeleton: the T-STACKED tile (VERDICT r5 #2b) ----
+// Conv3d(C, Co, (kT,1,1), stride 1, pad (kT/2,0,0)) + BN (+ residual) + ReLU: the temporal half of a SpatioTemporalConv
+// (r2plus1d.py:84-88) -- config 3's (7,1,1) stem conv (110 -> 64 channels over 8 x 32 x 56 x 56 positions, 20 % of the net's
+// FLOPs) and the (3,1,1) halves of its stride-1 body convs.  On the generic tiles the 128 rows of a workgroup lie in ONE frame,
+// so each of the kT taps stages a different input frame and the tensor goes through L2 kT times (FETCH + WRITE = 1.43x the
+// algorithmic bytes, profiles/r05_pmc_traffic_cfg3.json).  Here a workgroup owns the SAME 32 positions of 8 CONSECUTIVE output
+// frames (256 rows x 64 output channels); the patch of a phase (16 channels) holds those positions of the 8 + kT - 1 input
+// frames the tile touches and serves all kT taps: tap kt reads the patch kt frames (= 32 positions) further down.  LDS fill
+// per MFMA drops to (8 + kT - 1) / (8 kT) of the generic tile's, tiles adjacent in T follow each other in an XCD's chunk (their
+// 6-frame overlap hits L2).  Wave w owns output frames 2w and 2w + 1 (one 32-row MFMA tile each): a (frame, tap) whose input
+// frame lies outside the clip is SKIPPED per row tile (wave-uniform), so the zero padding costs no MFMAs.
+// Measured (profiles/r06_tstack_ab.txt): 116 TF on config 3's stem conv against 124.6 TF for the best generic tile -- the conv
+// is MFMA-bound, not fill-bound, and 256-row x 49-step workgroups quantise worse (12.25 tiles per CU).  The tuner keeps the
+// generic tiles there; the kernel stays as an execution it may pick per problem ("body:" keys).
+// Filter slices: [n tile][chunk][kt][2][2][64][4] (the body pack with taps = kT); K order as in the body kernel.
+constexpr int kTsF = 8;                    // output frames per tile
+constexpr int kTsS = 32;                   // positions per frame slab
+
+template <int NP>
+__device__ __forceinline__ void conv_tstack_tile(const BodyF32Args& p, float* smem, const int n, const int t0, const int s0, const int nt) {
+    constexpr unsigned kOOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    constexpr int RT = 2, CT = 2;
+    const int NPOS = (kTsF + p.kT - 1) * kTsS;          // positions of the patch
+    float* As = smem;                                   // [4][NPOS][4]
+    float* Bs = smem + 16 * NPOS;                       // [3][kB3Slot]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l32 = lane & 31;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-thread sources of the patch pieces (phase independent): piece q = tid + 256 i = group * NPOS + frame * 32 + position
+    unsigned a_src[NP];
+    const int n_pieces = 4 * NPOS;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int q = tid + kB3NT * i;
+        const int grp = (int)b3_fdiv((unsigned)q, p.dv_npos_tall);
+        const int pos = q - grp * NPOS;
+        const int t = t0 - p.pT + (pos >> 5), s = s0 + (pos & 31);
+        const bool ok = grp < 4 && (unsigned)t < (unsigned)p.T && s < p.HW;
+        a_src[i] = ok ? (unsigned)((((n * p.T + t) * p.HW + s) * p.ldx + grp * 4) * 4) : kOOB;
+    }
+    const unsigned b_src = (unsigned)(tid * 16);
+    const int n_steps = p.chunks * p.kT;
+
+    auto dma_patch = [&](int ph) {
+        const unsigned cbase = (unsigned)(ph * kB3CK * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + kB3NT * i < n_pieces)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(As + (wave * 64 + kB3NT * i) * 4), 16,
+                                                         a_src[i] == kOOB ? kOOB : a_src[i] + cbase, 0, 0, 0);
+    };
+    // filter slice of step s = chunk * kT + kt: [nt][chunk][kt] blocks of kB3Slot floats
+    auto dma_b = [&](int slot, int s) {
+        const unsigned tbase = (unsigned)((nt * n_steps + s) * (kB3Slot * 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + slot * kB3Slot + wave * 256), 16, b_src + tbase, 0, 0, 0);
+    };
+
+    // ---- this wave's rows: row tile i = output frame t0 + 2 wave + i, positions s0 + l32; its valid taps [lo, hi] ----
+    int a_row[RT], kt_lo[RT], kt_hi[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int f = wave * RT + i, t = t0 + f;
+        a_row[i] = (g * NPOS + f * kTsS + l32) * 4;
+        kt_lo[i] = t < p.T ? max(0, p.pT - t) : 1;
+        kt_hi[i] = t < p.T ? min(p.kT - 1, p.T - 1 - t + p.pT) : 0;
+    }
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 fa[2][RT], fb[2][CT];
+    const int b_lane = (g * 64 + l32) * 4;              // + q * 512 + j * 128 floats
+    auto load_group = [&](int q, const float* Ab, const float* Bb) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) fa[q][i] = *reinterpret_cast<const f32x4*>(Ab + a_row[i] + q * 8 * NPOS);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) fb[q][j] = *reinterpret_cast<const f32x4*>(Bb + b_lane + q * 512 + j * 128);
+    };
+    // (one wave-uniform branch per row tile: the two column tiles of a row tile alternate, so no MFMA waits on its own result)
+    auto mma_group = [&](int q, bool d0, bool d1) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (i == 0 ? d0 : d1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][i][k], fb[q][j][k], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    dma_patch(0);
+    dma_b(0, 0);
+    dma_b(1, 1);                                        // (n_steps >= kT >= 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("; LDS reads stay below the barrier" : "+v"(a_row[0])::"memory");
+    load_group(0, As, Bs);
+    load_group(1, As, Bs);
+    int tap = 0, slot = 0, ph = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (s > 0) {
+            // filter slice s + 1 (requested during step s - 1) has landed for everyone; slot (s + 2) % 3 is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (s + 2 < n_steps) dma_b(slot2, s + 2);
+        const bool more = s + 1 < n_steps;
+        const int tap1 = tap == p.kT - 1 ? 0 : tap + 1;
+        const bool same_phase = tap1 != 0;
+        const float* Ab = As + tap1 * (kTsS * 4);
+        const float* Bb = Bs + slot1 * kB3Slot;
+        const bool prefetch = more && same_phase;
+        const bool d0 = tap >= kt_lo[0] && tap <= kt_hi[0], d1 = tap >= kt_lo[1] && tap <= kt_hi[1];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            mma_group(q, d0, d1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (prefetch) load_group(q, Ab, Bb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more && !same_phase) {
+            // phase change: every wave is done with the old patch; the next chunk's is LDS-DMA'd in place (exposed: the
+            // co-resident workgroups cover most of the wait -- profiles/r06_tstack_ab.txt)
+            __syncthreads();
+            dma_patch(ph + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            asm volatile("; LDS reads stay below the barrier" : "+v"(a_row[0])::"memory");
+            load_group(0, As, Bb);
+            load_group(1, As, Bb);
+            ++ph;
+        }
+        tap = tap1;
+        slot = slot1;
+    }
+
+    // ---- epilogue: bias (+ folded BN) (+ residual) + ReLU; lane = output channel, 16 rows per accumulator tile ----
+    const bool relu = (p.flags & PTX_EPI_RELU) != 0;
+    const bool has_res = (p.flags & PTX_EPI_RES_ADD) != 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.r_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int t = t0 + wave * RT + i;
+        if (t >= p.T) continue;                         // (wave-uniform)
+        const int m_row0 = (n * p.T + t) * p.HW + s0;   // output row of position s0 of this frame
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int co = nt * kB3BN + j * 32 + l32;
+            const bool co_ok = co < p.ncol;
+            const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+            float rv[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const unsigned off = ((unsigned)(m_row0 + sl) * (unsigned)p.ldr + (unsigned)co) * 4u;
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (co_ok && s0 + sl < p.HW) ? off : kOOB, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                float v = acc[i][j][r] + bv;
+                if (has_res) v += rv[r];
+                v = relu ? fmaxf(v, 0.f) : v;
+                const unsigned off = ((unsigned)(m_row0 + sl) * (unsigned)p.ldy + (unsigned)co) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (co_ok && s0 + sl < p.HW) ? off : kOOB, 0, 0);
+            }
+        }
+    }
+}
+
+// tile list of a T-stacked launch: frames fastest (the tiles of one position slab follow each other), an XCD owns a contiguous
+// chunk; blockIdx.y = 64-channel column tile
+__global__ void __launch_bounds__(kB3NT, 2) conv_tstack_f32_kernel(const BodyF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = xcd_remap(blockIdx.x, p.n_tall);
+    const int tt = tile % p.t_tiles, r = tile / p.t_tiles;
+    const int st = r % p.s_tiles, n = r / p.s_tiles;
+    conv_tstack_tile<8>(p, smem, n, tt * kTsF, st * kTsS, blockIdx.y);
+}
+
 // generic packed filter [tap][Co_pad][Kc] (ptx_pack_conv_weight: BN scale folded in) -> [nt][kt][chunk][kh * 3 + kw][q][g][64][4]
 // (taps = 9; taps = 1 / kT = 1 / chunks = 4 packs a pointwise filter as the chained tail's [N2 / 64][8 octets][2][64][4] image)
 __global__ void __launch_bounds__(256) pack_body_f32_kernel(const float* __restrict__ wp, float* __restrict__ out, int kT, int Co_pad,
@@ -469,9 +669,30 @@ static bool body_geom(const ptx_conv3d_desc* d, int shape, BodyGeom* g) {
 using namespace ptx;
 
 // shape 0: tall tiles + square tails; shape 1: square tiles only
+// a (kT,1,1) temporal conv the T-stacked tile serves (shape 0 only): kT in {3, 5, 7}, stride 1, pad (kT/2,0,0)
+static bool tstack_problem(const ptx_conv3d_desc* d) { return d->kH == 1 && d->kW == 1 && d->kT > 1; }
+
+static int tstack_supported(const ptx_conv3d_desc* d, int shape) {
+    if (shape != 0) return 0;
+    if (d->groups > 1 || (d->kT != 3 && d->kT != 5 && d->kT != 7)) return 0;
+    if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pH != 0 || d->pW != 0 || d->pT != d->kT / 2) return 0;
+    if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi || d->N < 1 || d->Ti < 1 || d->Hi < 1 || d->Wi < 1) return 0;
+    // channels walk in 16-wide chunks: the columns [Ci, 16 * chunks) must exist in x (zero or finite: their filter rows are zero)
+    const int kc16 = cdiv(d->Ci, kB3CK) * kB3CK;
+    if (d->Ci < 1 || d->Kc < kc16 || d->ldx < kc16 || d->ldx % 4 || d->Co < 1 || d->Co_pad % kB3BN) return 0;
+    if (d->ldy < (d->Co + 3) / 4 * 4 || d->ldy % 4) return 0;
+    if ((d->flags & PTX_EPI_RES_ADD) && (d->ldr < d->Co || d->ldr % 4)) return 0;
+    const int64_t M = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    if (M * d->ldx * 4 >= 0x80000000LL || M * d->ldy * 4 >= 0x80000000LL || M * std::max(d->ldr, 1) * 4 >= 0x80000000LL) return 0;
+    if ((int64_t)d->N * cdiv(d->Ti, kTsF) * cdiv(d->Hi * d->Wi, kTsS) > 0x7fffffffLL) return 0;
+    if ((int64_t)(d->Co_pad / kB3BN) * kc16 / kB3CK * d->kT * kB3Slot * 4 >= 0x80000000LL) return 0;
+    return 1;
+}
+
 extern "C" int ptx_conv_body_f32_supported(const ptx_conv3d_desc* d, int shape) {
     if (!d || shape < 0 || shape > 1) return 0;
     if (d->flags & ~(PTX_EPI_RELU | PTX_EPI_RES_ADD)) return 0;
+    if (tstack_problem(d)) return tstack_supported(d, shape);
     if (d->groups > 1 || d->kH != 3 || d->kW != 3 || (d->kT != 3 && d->kT != 1)) return 0;
     if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pH != 1 || d->pW != 1 || d->pT != d->kT / 2) return 0;
     if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi || d->N < 1 || d->Ti < 1 || d->Hi < 1 || d->Wi < 1) return 0;
@@ -488,6 +709,10 @@ extern "C" int ptx_conv_body_f32_supported(const ptx_conv3d_desc* d, int shape) 
 }
 
 extern "C" size_t ptx_conv_body_f32_weight_elems(const ptx_conv3d_desc* d) {
+    if (d && tstack_problem(d)) {
+        if (d->Co_pad <= 0 || d->Co_pad % kB3BN || d->Ci <= 0) return 0;
+        return (size_t)(d->Co_pad / kB3BN) * cdiv(d->Ci, kB3CK) * d->kT * kB3Slot;
+    }
     if (!d || d->Co_pad <= 0 || d->Co_pad % kB3BN || d->Ci <= 0 || d->Ci % kB3CK || (d->kT != 1 && d->kT != 3)) return 0;
     return (size_t)(d->Co_pad / kB3BN) * d->kT * (d->Ci / kB3CK) * 9 * kB3Slot;
 }
@@ -495,8 +720,15 @@ extern "C" size_t ptx_conv_body_f32_weight_elems(const ptx_conv3d_desc* d) {
 extern "C" int ptx_pack_conv_body_f32_weight(const ptx_conv3d_desc* d, const float* w_packed, float* w_body, ptx_stream_t stream) {
     if (!d || !w_packed || !w_body) return fail(PTX_ERR_INVALID, "pack_conv_body_f32: null pointer");
     const size_t total = ptx_conv_body_f32_weight_elems(d);
+    if (total && tstack_problem(d)) {
+        // [n tile][chunk][kt][2][2][64][4]: the same image with the kT temporal taps as the "taps" of a phase
+        if (d->Kc < d->Ci || total >= (1ull << 31)) return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: bad (kT,1,1) filter extents");
+        hipLaunchKernelGGL(pack_body_f32_kernel, dim3((unsigned)std::min<size_t>(cdiv64((int64_t)total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                           w_packed, w_body, 1, d->Co_pad, d->Kc, cdiv(d->Ci, kB3CK), d->kT, (int)total);
+        return hip_check(hipGetLastError(), "pack_conv_body_f32 launch");
+    }
     if (!total || d->kH != 3 || d->kW != 3 || d->Kc < d->Ci)
-        return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: a (1|3)x3x3 filter, Ci a multiple of 16, Co_pad a multiple of 64");
+        return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: a (1|3)x3x3 or (kT,1,1) filter, Ci a multiple of 16, Co_pad a multiple of 64");
     if (total >= (1ull << 31)) return fail(PTX_ERR_UNSUPPORTED, "pack_conv_body_f32: filter too large");
     hipLaunchKernelGGL(pack_body_f32_kernel, dim3((unsigned)std::min<size_t>(cdiv64((int64_t)total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
                        w_packed, w_body, d->kT, d->Co_pad, d->Kc, d->Ci / kB3CK, 9, (int)total);
@@ -545,14 +777,51 @@ static size_t body_make_args(const ptx_conv3d_desc* d, int shape, BodyF32Args& a
     return (size_t)(16 * npos + 3 * kB3Slot) * sizeof(float);
 }
 
+// the T-stacked launch of a (kT,1,1) conv (tstack_supported)
+static int launch_tstack(const ptx_conv3d_desc* d, const float* x, const float* w_body, const float* bias, const float* res, float* y,
+                         ptx_stream_t stream) {
+    BodyF32Args a{};
+    a.x = x; a.w = w_body; a.bias = bias; a.res = (d->flags & PTX_EPI_RES_ADD) ? res : nullptr; a.y = y;
+    a.N = d->N; a.T = d->Ti; a.H = d->Hi; a.W = d->Wi; a.C = d->Ci; a.ldx = d->ldx;
+    a.ldy = d->ldy; a.ldr = d->ldr > 0 ? d->ldr : d->ldy;
+    a.ncol = (d->Co + 3) / 4 * 4;
+    a.kT = d->kT; a.pT = d->pT;
+    a.chunks = cdiv(d->Ci, kB3CK);
+    a.HW = d->Hi * d->Wi;
+    a.t_tiles = cdiv(d->Ti, kTsF);
+    a.s_tiles = cdiv(a.HW, kTsS);
+    a.n_tall = d->N * a.t_tiles * a.s_tiles;
+    a.flags = d->flags;
+    const uint64_t M = (uint64_t)d->N * d->Ti * a.HW;
+    a.x_bytes = (unsigned)(M * d->ldx * 4ull);
+    a.w_bytes = (unsigned)(ptx_conv_body_f32_weight_elems(d) * 4ull);
+    a.y_bytes = (unsigned)(M * d->ldy * 4ull);
+    a.r_bytes = (unsigned)(M * a.ldr * 4ull);
+    const int npos = (kTsF + d->kT - 1) * kTsS;
+    b3_fdiv_make((unsigned)npos, a.dv_npos_tall);
+    const size_t lds = (size_t)(16 * npos + 3 * kB3Slot) * sizeof(float);     // 40 KiB at kT = 7: three / four workgroups per CU
+    static bool attr_set[64] = {};
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tstack_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((16 * (kTsF + 6) * kTsS + 3 * kB3Slot) * sizeof(float))));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(conv_tstack_f32_kernel, dim3((unsigned)a.n_tall, (unsigned)cdiv(a.ncol, kB3BN)), dim3(kB3NT), lds, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "conv_tstack_f32 launch");
+}
+
 extern "C" int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* d, const float* x, const float* w_body, const float* bias, const float* res,
                                      float* y, int shape, ptx_stream_t stream) {
     if (!d || !x || !w_body || !y) return fail(PTX_ERR_INVALID, "conv_body_f32: null pointer");
     if (((uintptr_t)x | (uintptr_t)w_body | (uintptr_t)y | (uintptr_t)res) & 15) return fail(PTX_ERR_INVALID, "conv_body_f32: pointers must be 16-byte aligned");
     if (!ptx_conv_body_f32_supported(d, shape))
         return fail(PTX_ERR_UNSUPPORTED, "conv_body_f32: needs a dense (1|3)x3x3 / stride 1 / pad (kT/2,1,1) conv, Ci a multiple of 16, Co_pad a "
-                    "multiple of 64, bias / ReLU / same-shape residual epilogue, and an input patch of at most %d positions (shape %d)", kB3PosMax, shape);
+                    "multiple of 64, bias / ReLU / same-shape residual epilogue, and an input patch of at most %d positions (shape %d) -- or a "
+                    "(3|5|7)x1x1 / stride 1 / pad (kT/2,0,0) conv on shape 0", kB3PosMax, shape);
     if ((d->flags & PTX_EPI_RES_ADD) && !res) return fail(PTX_ERR_INVALID, "conv_body_f32: PTX_EPI_RES_ADD without a residual");
+    if (tstack_problem(d)) return launch_tstack(d, x, w_body, bias, res, y, stream);
     BodyGeom g;
     BodyF32Args a{};
     const size_t lds = body_make_args(d, shape, a, g);
@@ -573,6 +842,7 @@ extern "C" int ptx_conv_body_f32_fwd(const ptx_conv3d_desc* d, const float* x, c
 extern "C" int ptx_conv_body_chain_f32_supported(const ptx_conv3d_desc* d, const ptx_conv3d_desc* t, int shape) {
     if (!d || !t) return 0;
     if ((d->flags & ~PTX_EPI_RELU) || (t->flags & ~(PTX_EPI_RELU | PTX_EPI_RES_ADD))) return 0;
+    if (tstack_problem(d)) return 0;                    // (the T-stacked tile has no chained form)
     ptx_conv3d_desc dd = *d;
     dd.ldy = (d->Co + 3) / 4 * 4;                       // the first conv's output never reaches memory
     if (!ptx_conv_body_f32_supported(&dd, shape)) return 0;

@@ -441,7 +441,7 @@ class ConvStep:
     def kernel(self):
         """Name the launch goes by in the per-launch rows: the tile configuration, or the body kernel."""
         if getattr(self, "body", None) is not None:
-            return "conv_body_f32"
+            return "conv_tstack_f32" if self.d.kH == 1 else "conv_body_f32"
         return _lib.lib().ptx_conv3d_config_name(self.cfg).decode()
 
     def issued_flop(self):
@@ -450,6 +450,8 @@ class ConvStep:
             d = self.d
             frames = sum(max(0, min(d.kT - 1, d.Ti - 1 - (t - d.pT)) - max(0, d.pT - t) + 1) for t in range(d.To))
             rows = -(-(d.Ho * d.Wo) // 32) * 32
+            if d.kH == 1:        # the T-stacked tile: 16-channel chunks, (frame, tap) pairs outside the clip are skipped
+                return 2.0 * d.N * frames * rows * (-(-d.Ci // 16) * 16) * (-(-_r4(d.Co) // 64) * 64)
             return 2.0 * d.N * frames * rows * 9 * d.Ci * (-(-_r4(d.Co) // 64) * 64)
         tile = _tile_dims(_lib.lib().ptx_conv3d_config_name(self.cfg).decode())
         return 2.0 * self.macs if tile is None else issued_conv_flop(self.d, tile)
@@ -577,6 +579,8 @@ def lanes_store(key, n):
 
 
 BODY_SHAPES = ("tall", "square")      # ptx_conv_body_f32_fwd shapes 0 / 1
+# filters the body kernels take: (1|3)x3x3 on the patch-resident tile; (3|5|7)x1x1 on the T-stacked tile (shape 0 only)
+BODY_FILTERS = ((3, 3, 3), (1, 3, 3), (3, 1, 1), (5, 1, 1), (7, 1, 1))
 
 
 def body_lookup(key):
@@ -916,7 +920,7 @@ class Plan:
         # the tuner ("body:" keys) like a tile; PTX_CONV_BODY=0 keeps every 3x3x3 conv on the implicit-GEMM tiles (A/B runs),
         # =tall / =square force a shape wherever it is supported
         st.body, st.body_w, st.body_ok = None, None, ()
-        if (not fused and x2 is None and not half and not getattr(pk, "x3", False) and (kT, kH, kW) in ((3, 3, 3), (1, 3, 3))
+        if (not fused and x2 is None and not half and not getattr(pk, "x3", False) and (kT, kH, kW) in BODY_FILTERS
                 and isinstance(pk, Packed) and not getattr(pk, "fold_kw", False) and os.environ.get("PTX_CONV_BODY", "1") != "0"):
             st.body_ok = tuple(sh for sh in (0, 1) if self.lib.ptx_conv_body_f32_supported(C.byref(d), sh))
         if st.body_ok:

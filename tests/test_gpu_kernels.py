@@ -1946,7 +1946,7 @@ def hip_conv_body(ptx, x, w, bn=None, relu=False, res=None, shape=0, reps=1):
     d = L.ConvDesc()
     d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = N, T, H, W, Ci, xd.shape[-1]
     d.To, d.Ho, d.Wo, d.Co, d.ldy = T, H, W, Co, ldy
-    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, 3, 3, 1, 1, 1, kT // 2, 1, 1
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = kT, kH, kW, 1, 1, 1, kT // 2, kH // 2, kW // 2
     d.Kc, d.Co_pad = pd.Kc, pd.Co_pad
     d.flags = (L.PTX_EPI_RELU if relu else 0) | (L.PTX_EPI_RES_ADD if res is not None else 0)
     rd = None
@@ -1995,6 +1995,63 @@ def test_conv_body_f32(ptx, N, C, Co, T, H, W, kT, shape):
     again = hip_conv_body(ptx, x, w, bn=bn, relu=True, res=res, shape=shape, reps=2)
     assert torch.equal(got, again)
     close(got, hip_conv(ptx, x, w, (1, 1, 1), (kT // 2, 1, 1), bn=bn, relu=True, res=res), tol=2e-5)
+
+
+@pytest.mark.parametrize("N,C,Co,T,H,W,kT", [
+    (1, 110, 64, 32, 8, 8, 7),           # config 3's stem conv: 110 live of 112 channels (7 chunks), four T tiles, 2 position slabs
+    (2, 144, 64, 16, 7, 9, 3),           # layer1's (3,1,1) half: 9 chunks, 63 positions (a ragged second slab)
+    (1, 288, 128, 8, 7, 7, 3),           # layer2: two column tiles, one T tile
+    (2, 32, 48, 11, 5, 5, 5),            # ragged: T = 11 (a 3-frame last tile), 25 positions, 48 of 64 columns, kT = 5
+    (1, 16, 100, 3, 6, 6, 7),            # T < kT: most taps fall outside the clip; 100 of 128 columns
+])
+def test_conv_tstack_f32(ptx, N, C, Co, T, H, W, kT):
+    """The T-stacked tile of ptx_conv_body_f32_fwd ((kT,1,1) convs, shape 0) against F.conv3d + F.batch_norm + ReLU on the CPU:
+    the temporal half of a SpatioTemporalConv (r2plus1d.py:84-88), with and without a same-shape residual."""
+    x = rnd(N, C, T, H, W, seed=11)
+    w = rnd(Co, C, kT, 1, 1, seed=12, scale=(2.0 / (C * kT)) ** 0.5)
+    bn = make_bn(Co, 13)
+    got = hip_conv_body(ptx, x, w, bn=bn, relu=True, shape=0)
+    assert got is not None
+    want = ref_conv(x, w, (1, 1, 1), (kT // 2, 0, 0), bn=bn, relu=True)
+    close(got, want)
+    res = rnd(N, Co, T, H, W, seed=14)
+    got = hip_conv_body(ptx, x, w, bn=bn, relu=False, res=res, shape=0)
+    close(got, ref_conv(x, w, (1, 1, 1), (kT // 2, 0, 0), bn=bn, relu=False, res=res))
+    again = hip_conv_body(ptx, x, w, bn=bn, relu=False, res=res, shape=0, reps=2)
+    assert torch.equal(got, again)
+    close(got, hip_conv(ptx, x, w, (1, 1, 1), (kT // 2, 0, 0), bn=bn, relu=False, res=res), tol=2e-5)
+    assert hip_conv_body(ptx, x, w, bn=bn, relu=True, shape=1) is None         # no square form
+
+
+def test_conv_tstack_f32_refusals(ptx):
+    L, lib = ptx._lib, _lib(ptx)
+    d = L.ConvDesc()
+    d.N, d.Ti, d.Hi, d.Wi, d.Ci, d.ldx = 1, 8, 14, 14, 144, 144
+    d.To, d.Ho, d.Wo, d.Co, d.ldy = 8, 14, 14, 64, 64
+    d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW = 3, 1, 1, 1, 1, 1, 1, 0, 0
+    d.Kc, d.Co_pad = 144, 128
+    assert lib.ptx_conv_body_f32_supported(C.byref(d), 0) and not lib.ptx_conv_body_f32_supported(C.byref(d), 1)
+    assert lib.ptx_conv_body_f32_weight_elems(C.byref(d)) == 2 * 9 * 3 * 1024
+    for field, bad in (("sT", 2), ("kT", 9), ("pT", 0), ("pH", 1), ("groups", 2), ("Co_pad", 96), ("flags", L.PTX_EPI_RES_PADA),
+                       ("Ci", 150), ("ldx", 140)):
+        keep = getattr(d, field)
+        setattr(d, field, bad)
+        assert not lib.ptx_conv_body_f32_supported(C.byref(d), 0), field
+        setattr(d, field, keep)
+    d.Ci = 110              # 110 live channels in 112-float rows: the last chunk's missing filter rows are zero
+    d.Kc = d.ldx = 112
+    assert lib.ptx_conv_body_f32_supported(C.byref(d), 0)
+    d.Kc = d.ldx = 108      # < 112: the last chunk would read past the row
+    assert not lib.ptx_conv_body_f32_supported(C.byref(d), 0)
+    # the chained form exists for the (1|3)x3x3 body conv only
+    t = L.ConvDesc()
+    t.N, t.Ti, t.Hi, t.Wi, t.Ci, t.ldx = 1, 8, 14, 14, 64, 64
+    t.To, t.Ho, t.Wo, t.Co, t.ldy = 8, 14, 14, 256, 256
+    t.kT = t.kH = t.kW = t.sT = t.sH = t.sW = 1
+    t.Kc, t.Co_pad = 64, 256
+    d.Kc = d.ldx = 112
+    d.flags = L.PTX_EPI_RELU
+    assert not lib.ptx_conv_body_chain_f32_supported(C.byref(d), C.byref(t), 0)
 
 
 def test_conv_body_f32_refusals(ptx):
