@@ -37,7 +37,6 @@ struct StemF32Args {
     int PR, PC, plane;    // patch rows, floats per patch row (multiple of 4), PR * PC
     int shift, wbase;     // patch column 0 is input column wbase (<= 0, multiple of 4); a window starts at wo*sW + shift
     int tiles_per_frame, n_tiles, n_pieces, w_tiles;
-    int nt_loop;          // 2: ONE workgroup walks both 64-channel column tiles over the patch it staged once (kT == 1 only)
     unsigned flags;
     unsigned x_bytes, w_bytes, y_bytes;
     unsigned dv_wo[2];
@@ -96,9 +95,7 @@ __device__ unsigned long long* g_stem_tl = nullptr;
 
 // NP: 16-byte patch pieces per thread (4, 8 or 12).  STAGE: the next frame's patch waits in registers (2 workgroups per CU);
 // else it is LDS-DMA'd at the frame change, exposed, and a third workgroup per CU covers the wait (<= 168 registers).
-// NTL: ONE workgroup walks the TWO 64-channel column tiles of a <= 128-channel output over the patch it staged once (kT == 1:
-// a single-frame patch).
-template <int NP, bool STAGE, bool NTL = false>
+template <int NP, bool STAGE>
 __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PTX_STEM_TL(0);
@@ -112,7 +109,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tile order: the frames of one band of rows follow each other (temporal L2 reuse of the kT-frame window), an XCD
     // owns a contiguous chunk of the list
-    const int nt0 = blockIdx.y;
+    const int nt = blockIdx.y;
     int to, t_;                                         // output frame, (n, band) group
     if (p.lpt) {
         const int xcd = blockIdx.x % kNumXCD, l = blockIdx.x / kNumXCD;      // workgroup b runs on XCD b % 8
@@ -155,10 +152,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     }
     unsigned b_src[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b_src[i] = (unsigned)((nt0 * kF32BTile + (tid + kF32NT * i) * 4) * 4);
-    // (column-tile loop, VERDICT r5 #2c: the (1,7,7) stem of the (2+1)D nets has 110 output channels = two 64-wide tiles over
-    //  the SAME single-frame patch; the second tile re-runs the kH steps on the resident patch instead of being a second
-    //  workgroup that stages it again)
+    for (int i = 0; i < 2; ++i) b_src[i] = (unsigned)((nt * kF32BTile + (tid + kF32NT * i) * 4) * 4);
 
     // ---- valid temporal taps (uniform): frames outside the clip contribute nothing ----
     const int t_first = to * p.sT - p.pT;
@@ -213,7 +207,6 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
         a_base[i][4] = a_row[i] + 2 * p.plane + 6;        // j = 10   : (c = 2, kw = 6) | g = 1 multiplies a zero
     }
 
-    auto run_tile = [&](const int nt, const bool first_tile) {
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -255,15 +248,11 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     };
     if (n_steps > 0) {
         // prologue: the first patch (through registers), filter tiles 0 and 1; then the fragments of step 0
-        // (a later column tile of the loop: the patch is resident, every wave is past its reads of the filter slots)
-        if (!first_tile) __syncthreads();
-        if (first_tile) {
-            if (STAGE) fetch_patch(kt_lo);
-            else PTX_STEM_DMA_PATCH(kt_lo);
-        }
+        if (STAGE) fetch_patch(kt_lo);
+        else PTX_STEM_DMA_PATCH(kt_lo);
         issue_b(0, kt_lo, 0);
         if (n_steps > 1) issue_b(1, kt_lo, 1);           // (kH >= 2)
-        if (STAGE && first_tile) store_patch();
+        if (STAGE) store_patch();
         PTX_STEM_TL(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -321,8 +310,7 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
     PTX_STEM_TL(3);
     const bool relu = (p.flags & PTX_EPI_RELU) != 0;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    int m_frame = (n * p.To + to) * frame_out;
-    if (NTL) asm volatile("; (opaque: the 32 row offsets of the stores are recomputed per column tile, not hoisted into registers)" : "+s"(m_frame));
+    const int m_frame = (n * p.To + to) * frame_out;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = nt * kF32BN + j * 32 + l32;
@@ -341,14 +329,6 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
             }
         }
     }
-    if (NTL) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) b_src[i] += (unsigned)(kF32BTile * 4);
-    }
-    };
-    // (straight-line, not a loop: with a back edge hipcc keeps ~60 more registers live)
-    run_tile(nt0, true);
-    if (NTL) run_tile(nt0 + 1, false);
 #ifdef PTX_STEM_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PTX_STEM_TL(5);
@@ -356,17 +336,17 @@ __global__ void __launch_bounds__(kF32NT, 2) conv_stem_f32_kernel(const StemF32A
 }
 
 
-template <int NP, bool STAGE, bool NTL = false>
+template <int NP, bool STAGE>
 static int launch_stem_f32(const StemF32Args& a, dim3 grid, size_t lds, ptx_stream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_f32_kernel<NP, STAGE, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_f32_kernel<NP, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)((kF32PatchMax + 3 * kF32BTile) * sizeof(float))));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_f32_kernel<NP, STAGE, NTL>), grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_f32_kernel<NP, STAGE>), grid, dim3(kF32NT), lds, (hipStream_t)stream, a);
     return PTX_OK;
 }
 
@@ -524,16 +504,9 @@ extern "C" int ptx_conv_stem_f32_fwd(const ptx_conv3d_desc* d, const float* x, i
     // 1.54 ms); PTX_STEM_F32_MODE=2 stages the next patch through registers instead (two workgroups per CU: 1.62 ms)
     static const int mode_env = getenv("PTX_STEM_F32_MODE") ? atoi(getenv("PTX_STEM_F32_MODE")) : 1;
     const bool stage = mode_env == 2;
-    // a single-frame filter (kT == 1) with several column tiles: one workgroup per row tile walks them over its resident patch
-    // (PTX_STEM_F32_NTLOOP=0: one workgroup per (row tile, column tile), the A/B knob of profiles/r06_stem_ntloop_ab.txt)
-    static const bool ntloop_env = !(getenv("PTX_STEM_F32_NTLOOP") && atoi(getenv("PTX_STEM_F32_NTLOOP")) == 0);
-    const int col_tiles = cdiv(a.ncol, kF32BN);
-    a.nt_loop = (ntloop_env && d->kT == 1 && col_tiles == 2 && !stage) ? 2 : 0;
-    const dim3 grid((unsigned)a.n_tiles, (unsigned)(a.nt_loop > 1 ? 1 : col_tiles));
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)cdiv(a.ncol, kF32BN));
     int rc;
-    if (a.nt_loop > 1) rc = np <= 4 ? launch_stem_f32<4, false, true>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, false, true>(a, grid, lds, stream)
-                                                                                             : launch_stem_f32<12, false, true>(a, grid, lds, stream);
-    else if (stage) rc = np <= 4 ? launch_stem_f32<4, true>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, true>(a, grid, lds, stream)
+    if (stage) rc = np <= 4 ? launch_stem_f32<4, true>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, true>(a, grid, lds, stream)
                                                                                       : launch_stem_f32<12, true>(a, grid, lds, stream);
     else rc = np <= 4 ? launch_stem_f32<4, false>(a, grid, lds, stream) : np <= 8 ? launch_stem_f32<8, false>(a, grid, lds, stream)
                                                                                   : launch_stem_f32<12, false>(a, grid, lds, stream);
