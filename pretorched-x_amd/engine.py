@@ -1852,7 +1852,7 @@ class Engine:
         # HBM-bound passes overlap the other's matrix-bound kernels: +2.0-2.5 % on configs 2 and 4 with two lanes on MI355X,
         # nothing on config 3, a loss with four.
         #   "auto" (default, round 6)  what the tuned table holds for this (architecture, input shape): 2 where
-        #                              Engine.autotune measured two lanes >= 1.5 % faster than one ("lanes:" keys, the same
+        #                              Engine.autotune measured two lanes >= 1 % faster than one ("lanes:" keys, the same
         #                              kind of measured accept rule as the chained launches' "alt:" keys), else 1;
         #   1 .. 8                     forced.
         # Per-clip results with n lanes are those of the slice-sized batch (another tile / split-K choice than the full
@@ -1888,7 +1888,8 @@ class Engine:
 
     def tune_lanes(self, model, x, iters=8, verbose=False):
         """Measure forward(model, x) with one and with two clip lanes (each on its own tuned plans) and record the verdict in
-        the tuned table: two lanes must win by 1.5 % (the lanes double the activation buffers).  Returns the lanes kept."""
+        the tuned table: two lanes must win by 1 % (the lanes double the activation buffers; config 2 gains 1.4-2.2 % across the
+        boxes of rounds 5 and 6, which a 1.5 % bar turned into a coin flip).  Returns the lanes kept."""
         x = _dense16(x)
         key = lanes_key(model, x.shape, self._precision)
         if self.use_graph or x.shape[0] < 2 or x.shape[0] % 2:
@@ -1913,7 +1914,7 @@ class Engine:
         finally:
             self._lanes = keep
         ms = {n: sorted(v)[len(v) // 2] for n, v in ms.items()}
-        best = 2 if ms[2] < 0.985 * ms[1] else 1
+        best = 2 if ms[2] < 0.99 * ms[1] else 1
         lanes_store(key, best)
         if verbose:
             print("tune clip lanes %s: 1 lane %.3f ms | 2 lanes %.3f ms -> %d" % (key, ms[1], ms[2], best))

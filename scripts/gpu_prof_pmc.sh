@@ -9,7 +9,7 @@ W=${W:-cfg5}
 OUT=$REPO/gpurun_out/prof_$W$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --workload $W --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-x3 --no-lanes ${BENCH_ARGS}"
+CMD="python $REPO/bench.py --workload $W --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-x3 --no-lanes --lanes 1 ${BENCH_ARGS}"   # (single plan: under clip lanes two kernels share the chip)
 NOTUNE="--no-autotune"
 if [ -n "$PROF_CMD" ]; then CMD="$PROF_CMD"; NOTUNE=""; fi      # any other command (a kernel probe script): W / TAG only name the output
 # the trace pass runs with the tuned table too (--no-autotune): tuner launches would pollute the per-kernel averages

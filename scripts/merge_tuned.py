@@ -16,6 +16,7 @@ lib = _lib.lib()
 names = {lib.ptx_conv3d_config_name(i).decode() for i in range(lib.ptx_conv3d_num_configs())}
 names |= {lib.ptx_conv3d_chain_config_name(i).decode() for i in range(lib.ptx_conv3d_chain_num_configs())}     # "chain:" keys
 names |= {"chain", "pair"}                                                                                       # "alt:" keys
+names |= {"igemm", "lanes", "program", "launches"} | set(engine.BODY_SHAPES)                                     # "body:" / "lanes:" / "prog:" keys
 path = os.path.join(ROOT, "pretorched-x_amd", "tuned_gfx950.json")
 table = json.load(open(path))
 n0 = len(table)

@@ -339,7 +339,11 @@ def test_tuned_table_stores_config_names(ptx):
     # chained launch and the two launches it replaces
     chain_names = {lib.ptx_conv3d_chain_config_name(i).decode() for i in range(lib.ptx_conv3d_chain_num_configs())}
     for k, v in table.items():
-        pool = chain_names if k.startswith("chain:") else {"chain", "pair"} if k.startswith("alt:") else names
+        # round 6: "body:" keys hold the body kernels' verdict (a shape of ptx_conv_body_f32_fwd, or "igemm" = the generic tile
+        # stays), "lanes:" keys the clip-lane count of an (architecture, shape), "prog:" keys program-or-launches
+        pool = (chain_names if k.startswith("chain:") else {"chain", "pair"} if k.startswith("alt:")
+                else {"igemm"} | set(engine.BODY_SHAPES) if k.startswith("body:") else {"lanes"} if k.startswith("lanes:")
+                else {"program", "launches"} if k.startswith("prog:") else names)
         assert isinstance(v[0], str) and v[0] in pool and v[1] >= 1, (k[:40], v)
     assert any(k.startswith("chain:") for k in table) and any(k.startswith("alt:") for k in table)
     key = next(k for k in table if not k.startswith(("chain:", "alt:")))
