@@ -183,6 +183,9 @@ def measure(args, scaling, world, rank, local, dev, backend, first=True):
                     eng.autotune(model, x, iters=int(os.environ.get("PTX_TUNE_ITERS", "2")), verbose=args.verbose)      # every candidate tile of every conv problem
                 else:
                     run()                              # first call compiles the plan and times untuned tiles
+                    if fwd is None and eng.lanes == "auto":
+                        # ... and what the table lacks of this workload: the clip-lanes verdict of its (architecture, shape)
+                        eng.autotune(model, x, iters=int(os.environ.get("PTX_TUNE_ITERS", "2")), verbose=args.verbose, only_untuned=True)
                 torch.cuda.synchronize()
             if world > 1:
                 # the other ranks sit in this broadcast while rank 0 tunes: the process group's timeout (PTX_BENCH_TIMEOUT,

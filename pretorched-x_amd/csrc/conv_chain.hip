@@ -234,6 +234,7 @@ extern "C" int ptx_conv3d_chain_fwd(const ptx_conv3d_desc* conv, const ptx_conv3
     a.split_k = 1;
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 && a.pW == 0 &&
                         a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo) ? 1 : 0;
+    a.prune_analytic = prune_analytic_ok(a);
     a.w2 = w2_packed; a.bias2 = bias2;
     a.ldw2 = tail->Kc; a.kB2 = tail->Kc; a.w2_rows = tail->Co_pad; a.Co2 = tail->Co; a.ncol2 = (tail->Co + 3) / 4 * 4;
     a.flags2 = tail->flags & (PTX_EPI_RELU | PTX_EPI_RES_ADD);

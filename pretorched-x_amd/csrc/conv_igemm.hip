@@ -736,6 +736,7 @@ int finalize_conv_args(ConvArgs& a, int BM, int BN, int BK, int kwr, bool direct
     a.counters = nullptr;
     a.unit_pointwise = (a.kT * a.kH * a.kW == 1 && a.sT == 1 && a.sH == 1 && a.sW == 1 && a.pT == 0 && a.pH == 0 &&
                         a.pW == 0 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && !a.up2) ? 1 : 0;
+    a.prune_analytic = prune_analytic_ok(a);
     return PTX_OK;
 }
 

@@ -31,6 +31,7 @@ struct ConvArgs {
     long long bs_x, bs_w, bs_y;   // batched-GEMM strides (elements); 0 for a plain conv
     int unit_pointwise;   // 1x1x1 / stride 1 / pad 0: skip the position decode
     int k_live;           // live (possibly non-zero) K columns per tap = desc.Ci
+    int prune_analytic;   // tap-plane pruning from the tile's row span in scalar arithmetic (no workgroup reduction)
     int tiles_per_plane;  // > 0: frame-fastest tile order (temporal L2 reuse), = Ho*Wo/BM
     // dual-source pointwise conv (ptx_conv3d_dual_fwd): K chunks [0, kc1) read x, chunks [kc1, kchunks) read x2
     const float* x2;
@@ -61,6 +62,17 @@ struct ConvArgs {
     int ldw2, kB2, w2_rows, Co2, ncol2;
     unsigned w2_bytes, flags2;   // flags2: PTX_EPI_RELU | PTX_EPI_RES_ADD of the tail
 };
+
+// Tap-plane pruning without the workgroup OR-reduction (three barriers in every workgroup's prologue): legal when every
+// output coordinate of the T and H axes has at least one tap inside the image -- then the union of the rows' tap ranges over
+// a tile's raster span follows from the span's two ends (conv_igemm_tile).  PTX_PRUNE_ANALYTIC=0: the reduction everywhere.
+inline int prune_analytic_ok(const ConvArgs& a) {
+    static const bool on = !(getenv("PTX_PRUNE_ANALYTIC") && atoi(getenv("PTX_PRUNE_ANALYTIC")) == 0);
+    auto axis_ok = [](int k, int pad, int s, int in, int out) {
+        return pad >= 0 && pad <= k - 1 && s >= 1 && out >= 1 && in - 1 + pad - (out - 1) * s >= 0;
+    };
+    return (on && a.kT * a.kH > 1 && !a.up2 && axis_ok(a.kT, a.pT, a.sT, a.Ti, a.To) && axis_ok(a.kH, a.pH, a.sH, a.Hi, a.Ho)) ? 1 : 0;
+}
 
 // n / d for n < 2^31 without the ~30-instruction integer division sequence: d == 1 -> mul == 0; else
 // l = ceil(log2 d), mul = ceil(2^(31+l) / d) (< 2^32), q = umulhi(n, mul) >> (l - 1).  Exact: the rounding error of
@@ -731,7 +743,27 @@ __device__ __forceinline__ void conv_igemm_tile(const Args& p, const int tile, c
     // row of this tile is skipped.  Exact for any tile (also when it straddles frames or clips): the
     // per-row validity bitmasks are OR-reduced over the workgroup (wave shuffles + one LDS word). ----
     int kt_lo = 0, kt_hi = p.kT - 1, kh_lo = 0, kh_hi = p.kH - 1;
-    if (p.kT * p.kH > 1) {
+    if (!KWR && p.prune_analytic) {
+        // The same ranges WITHOUT a workgroup reduction (round 6): the tile's rows m0 .. m1 are a contiguous raster span, so
+        // the output frames / output rows they touch are one interval (or, when the span wraps a clip / frame boundary or is
+        // longer than one, everything), and a tap axis' valid range is monotone in the output coordinate: lo from the largest
+        // coordinate, hi from the smallest.  Scalar arithmetic, identical in every wave; the host sets `prune_analytic` only
+        // when every output coordinate has a non-empty tap range on both axes (then this equals the OR of the row masks).
+        const unsigned um0 = (unsigned)m0, um1 = (unsigned)(min(m0 + BM, p.M) - 1);
+        const unsigned r0 = fastdiv(um0, p.dv_wo), r1 = fastdiv(um1, p.dv_wo);          // (frame, row) index of both ends
+        const unsigned f0 = fastdiv(r0, p.dv_ho), f1 = fastdiv(r1, p.dv_ho);            // frame index n * To + to
+        const int h0 = (int)(r0 - f0 * (unsigned)p.Ho), h1 = (int)(r1 - f1 * (unsigned)p.Ho);
+        const bool h_one = f0 == f1;                                                    // (then h0 <= h1)
+        const int h_min = h_one ? h0 : 0, h_max = h_one ? h1 : p.Ho - 1;
+        const unsigned n0_ = fastdiv(f0, p.dv_to), n1_ = fastdiv(f1, p.dv_to);
+        const int t0 = (int)(f0 - n0_ * (unsigned)p.To), t1 = (int)(f1 - n1_ * (unsigned)p.To);
+        const bool t_one = n0_ == n1_;
+        const int t_min = t_one ? t0 : 0, t_max = t_one ? t1 : p.To - 1;
+        kt_lo = max(0, p.pT - t_max * p.sT);
+        kt_hi = min(p.kT - 1, p.Ti - 1 + p.pT - t_min * p.sT);
+        kh_lo = max(0, p.pH - h_max * p.sH);
+        kh_hi = min(p.kH - 1, p.Hi - 1 + p.pH - h_min * p.sH);
+    } else if (p.kT * p.kH > 1) {
         unsigned m_or = 0;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) m_or |= a_mask[i];
