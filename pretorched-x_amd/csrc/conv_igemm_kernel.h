@@ -67,7 +67,8 @@ struct ConvArgs {
 // output coordinate of the T and H axes has at least one tap inside the image -- then the union of the rows' tap ranges over
 // a tile's raster span follows from the span's two ends (conv_igemm_tile).  PTX_PRUNE_ANALYTIC=0: the reduction everywhere.
 inline int prune_analytic_ok(const ConvArgs& a) {
-    static const bool on = !(getenv("PTX_PRUNE_ANALYTIC") && atoi(getenv("PTX_PRUNE_ANALYTIC")) == 0);
+    const char* e = getenv("PTX_PRUNE_ANALYTIC");       // (read per launch: the GPU test flips it inside one process)
+    const bool on = !(e && atoi(e) == 0);
     auto axis_ok = [](int k, int pad, int s, int in, int out) {
         return pad >= 0 && pad <= k - 1 && s >= 1 && out >= 1 && in - 1 + pad - (out - 1) * s >= 0;
     };

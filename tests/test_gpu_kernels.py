@@ -1924,6 +1924,40 @@ def test_conv1x1_pro_f16_kernel(ptx, N, H, W, K, Co, affine, relu):
     assert not lib.ptx_conv1x1_pro_f16_supported(C.byref(d))
 
 
+@pytest.mark.parametrize("N,C,Co,T,H,W,k,s,p", [
+    (3, 16, 64, 5, 9, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 315-row clips: tiles straddle frames AND clips
+    (2, 8, 32, 6, 14, 14, (3, 3, 3), (2, 2, 2), (1, 1, 1)),      # strided: the last output coordinate's window hangs over the edge
+    (2, 12, 64, 9, 6, 6, (7, 1, 1), (1, 1, 1), (3, 0, 0)),       # a temporal filter longer than half the clip
+    (1, 8, 64, 2, 20, 20, (1, 5, 5), (1, 1, 1), (0, 2, 2)),      # kT == 1: only the row axis prunes
+    (2, 8, 64, 4, 10, 10, (3, 3, 3), (1, 1, 1), (2, 2, 2)),      # padding == k - 1: every coordinate still owns a tap
+])
+def test_analytic_tap_pruning_matches_the_reduction(ptx, monkeypatch, N, C, Co, T, H, W, k, s, p):
+    """Round 6: the generic tile derives its pruned (kt, kh) ranges from the tile's row span in scalar arithmetic instead of
+    OR-reducing the rows' tap masks over the workgroup (conv_igemm_kernel.h, `prune_analytic`).  Same k-space => the same bits,
+    on every tile shape family, and both agree with F.conv3d."""
+    x = rnd(N, C, T, H, W, seed=21)
+    w = rnd(Co, C, *k, seed=22, scale=(2.0 / (C * k[0] * k[1] * k[2])) ** 0.5)
+    bn = make_bn(Co, 23)
+    lib = _lib(ptx)
+    want = ref_conv(x, w, s, p, bn=bn, relu=True)
+    seen = 0
+    for cfg in range(lib.ptx_conv3d_num_configs()):
+        name = lib.ptx_conv3d_config_name(cfg).decode()
+        if any(t in name for t in ("f16", "x3", "direct", "kwr")) or cfg % 3 != 0:       # every third fp32 tile: all families
+            continue
+        monkeypatch.setenv("PTX_PRUNE_ANALYTIC", "1")
+        try:
+            a = hip_conv(ptx, x, w, s, p, bn=bn, relu=True, cfg=cfg)
+        except ptx.PtxError:                # this tile does not take the problem (K chunking, channel counts)
+            continue
+        monkeypatch.setenv("PTX_PRUNE_ANALYTIC", "0")
+        b = hip_conv(ptx, x, w, s, p, bn=bn, relu=True, cfg=cfg)
+        assert torch.equal(a, b), name
+        close(a, want)
+        seen += 1
+    assert seen >= 3
+
+
 def hip_conv_body(ptx, x, w, bn=None, relu=False, res=None, shape=0, reps=1):
     """x NCDHW cpu, w [Co,Ci,kT,3,3] cpu -> NCDHW cpu output of ptx_conv_body_f32_fwd (round 6: the patch-resident 3x3x3
     body kernel).  The filter goes through ptx_pack_conv_weight (BN fold) and then ptx_pack_conv_body_f32_weight."""
