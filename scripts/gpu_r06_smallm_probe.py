@@ -22,6 +22,12 @@ PROBLEMS = [
     ("layer4 conv1.temporal 409->512", "8,2,4,4,409,512,1,1,0"),
     ("layer4 conv3.spatial  512->409", "8,2,4,4,512,409,1,1,0"),
     ("layer4 conv3.temporal 409->2048 +res", "8,2,4,4,409,2048,1,1,0,res"),
+    ("cfg3 layer3 conv2.spatial (1,3,3) 256->576", "8,4,7,7,256,576,133,1,1"),
+    ("cfg3 layer3 conv2.temporal (3,1,1) 576->256", "8,4,7,7,576,256,311,1,1"),
+    ("cfg2 layer3 conv1 1024->256 (M=3136)", "8,2,14,14,1024,256,1,1,0"),
+    ("cfg2 layer3 conv3 256->1024 +res", "8,2,14,14,256,1024,1,1,0,res"),
+    ("cfg2 layer3 conv2 3x3x3 256->256", "8,2,14,14,256,256,333,1,1"),
+    ("cfg2 layer4 conv1 2048->512 (M=392)", "8,1,7,7,2048,512,1,1,0"),
 ]
 
 
